@@ -1,0 +1,189 @@
+/*
+ * isokann_hip.h -- C ABI of the MI355X-native ISOKANN training engine.
+ *
+ * Drop-in boundary for the per-iteration hot path of axsk/ISOKANN.jl (v2.0.0):
+ * featurize -> MLP forward over the D x K x N Koopman samples -> K-mean ->
+ * shift-scale / ISA target -> MLP forward/backward + optimizer on xs.
+ *
+ * The reference has NO FFI/plugin interface on this path (it is Julia multiple
+ * dispatch on a Flux.Chain); each entry point below names the reference function
+ * (file:line, relative to the reference repo) whose role it takes when a Julia
+ * host binds this library with `ccall` (see INTEGRATION.md for the Julia shim).
+ *
+ * Conventions
+ *  - Every array is Julia column-major, passed as a plain pointer + sizes:
+ *      xs (D, N), ys (D, K, N), model outputs (nout, N), weights W (out, in).
+ *    In C terms xs is [N][D], ys is [N][K][D]: one sample's D values contiguous.
+ *  - The flat parameter vector is Flux's trainables order
+ *      [LayerNorm.scale, LayerNorm.bias, W1, b1, W2, b2, ...], W column-major.
+ *  - Caller owns every host buffer.  The engine copies on set_* and writes results
+ *    into caller-allocated buffers; it owns all device memory.
+ *  - Every function returns an isk_status; nothing throws across the ABI.
+ *    isk_last_error() gives a thread-local message for the last failure.
+ *  - An engine handle is not thread-safe; distinct handles are independent.
+ *  - Pointers are HOST pointers unless the parameter name ends in `_dev`.
+ */
+#ifndef ISOKANN_HIP_H
+#define ISOKANN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISK_MAX_LAYERS 8
+#define ISK_ABI_VERSION 1
+
+typedef struct isk_engine isk_engine;
+
+typedef enum isk_status {
+    ISK_OK = 0,
+    ISK_EINVAL = 1,        /* bad shape / argument (the reference's @assert failures, isotarget.jl:37,102) */
+    ISK_EHIP = 2,          /* HIP runtime error */
+    ISK_ENOMEM = 3,
+    ISK_ECONSTANT_CHI = 4, /* DomainError "chi function is constant"          src/isotarget.jl:39     */
+    ISK_ECOLLAPSED = 5,    /* DomainError "model collapsed under training"    src/iso.jl:186-189      */
+    ISK_ESINGULAR = 6,     /* DomainError "simplex transformation ... singular" src/isotarget.jl:94-97 */
+    ISK_EUNSUPPORTED = 7,  /* configuration outside what the kernels cover */
+    ISK_ESTATE = 8         /* call order (e.g. train before set_data) */
+} isk_status;
+
+typedef enum { ISK_ACT_IDENTITY = 0, ISK_ACT_SIGMOID = 1, ISK_ACT_TANH = 2, ISK_ACT_RELU = 3, ISK_ACT_SWISH = 4 } isk_act;
+typedef enum { ISK_FEAT_IDENTITY = 0, ISK_FEAT_ALLPAIRS = 1, ISK_FEAT_PAIRLIST = 2 } isk_featurizer;
+typedef enum { ISK_OPT_ADAM = 0, ISK_OPT_NESTEROV = 1 } isk_opt;
+typedef enum { ISK_TARGET_SHIFTSCALE = 0, ISK_TARGET_ISA = 1 } isk_target_kind;
+/* Flux `normalise` epsilon placement: 0 = (x-mu)/sqrt(var+eps^2) [Flux >= 0.14, default],
+ * 1 = (x-mu)/(std+eps) [Flux <= 0.13], 2 = (x-mu)/sqrt(var+eps) [PyTorch] */
+typedef enum { ISK_LN_VAR_EPS2 = 0, ISK_LN_STD_EPS = 1, ISK_LN_VAR_EPS = 2 } isk_ln_mode;
+
+/* Mirrors the keyword arguments of Iso(...) (src/iso.jl:17-25), pairnet/densenet
+ * (src/models.jl:65,87), the optimizer constructors (src/models.jl:12,20) and the
+ * featurizer structs (src/utils/features.jl:22-35). */
+typedef struct isk_config {
+    int32_t abi_version;                 /* ISK_ABI_VERSION */
+    int32_t device;                      /* HIP device ordinal */
+    /* model: densenet(layers = widths[0..n_layers]) */
+    int32_t n_layers;                    /* number of Dense layers, 1..ISK_MAX_LAYERS */
+    int32_t widths[ISK_MAX_LAYERS + 1];  /* in, hidden..., nout */
+    int32_t activation;                  /* isk_act, hidden layers (Flux.sigmoid default) */
+    int32_t lastactivation;              /* isk_act, last layer (identity default) */
+    int32_t layernorm;                   /* leading Flux.LayerNorm(widths[0]) */
+    int32_t ln_mode;                     /* isk_ln_mode */
+    float   ln_eps;                      /* 1e-5 */
+    /* optimizer: OptimiserChain(WeightDecay(reg), Adam(lr) | Nesterov(lr, rho)) */
+    int32_t opt_kind;                    /* isk_opt */
+    float   lr, reg, beta1, beta2, opt_eps, rho;
+    /* featurizer */
+    int32_t featurizer;                  /* isk_featurizer */
+    int32_t n_atoms;                     /* coords have 3*n_atoms rows (ALLPAIRS / PAIRLIST) */
+    int32_t n_pairs;                     /* PAIRLIST: number of pairs (= widths[0]) */
+    const int32_t* pairs;                /* PAIRLIST: 2*n_pairs 0-based atom indices (a0,b0,a1,b1,...);
+                                            copied by isk_create.  ALLPAIRS over an atom subset
+                                            (FeaturesAtoms) is expressed as a PAIRLIST by the host. */
+    int32_t featurize_every_iteration;   /* 1: pdist runs inside every isk_run iteration (north-star
+                                            hot path); 0: features cached at isk_set_data, as the
+                                            reference does (src/simulation.jl:110-114) */
+    /* target transform */
+    int32_t target_kind;                 /* isk_target_kind; ISA needs nout > 1 */
+    int32_t isa_permute;                 /* TransformISA.permute  (default 1) */
+    int32_t isa_whitening;               /* TransformISA.whitening (default 0) */
+    int32_t minibatch;                   /* Iso.minibatch (default 100; 0 = full batch) */
+    uint64_t seed;                       /* shuffle seed for DataLoader(shuffle=true) when no
+                                            permutation is injected */
+} isk_config;
+
+/* ---- library ------------------------------------------------------------------ */
+int  isk_abi_version(void);
+int  isk_device_count(int32_t* count);
+const char* isk_last_error(void);
+const char* isk_status_string(int status);
+void isk_config_default(isk_config* cfg);           /* the reference's defaults */
+
+/* ---- lifetime: Iso(...) / gpu(iso)   src/iso.jl:17-43, 256 -------------------- */
+int  isk_create(const isk_config* cfg, isk_engine** out);
+void isk_destroy(isk_engine* e);
+int  isk_synchronize(isk_engine* e);
+int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's stream (e.g. torch's) */
+
+/* ---- parameters / optimizer state: Flux.setup, cpu(iso), save/load
+ *      src/iso.jl:27,74,257,405-420 ----------------------------------------------- */
+int  isk_nparams(isk_engine* e, int64_t* n);
+int  isk_set_params(isk_engine* e, const float* flat, int64_t n);
+int  isk_get_params(isk_engine* e, float* flat, int64_t n);
+/* Adam: m = first moment, v = second moment, bt = (beta1^t, beta2^t).
+ * Nesterov: m = velocity, v ignored (may be NULL). */
+int  isk_set_opt_state(isk_engine* e, const float* m, const float* v, int64_t n, const double bt[2]);
+int  isk_get_opt_state(isk_engine* e, float* m, float* v, int64_t n, double bt[2]);
+int  isk_reset_opt_state(isk_engine* e);            /* Flux.setup(opt, model) */
+
+/* ---- data: SimulationData(xs, ys; featurizer)   src/simulation.jl:100-114 ------ */
+/* xs (D, N), ys (D, K, N).  D = 3*n_atoms for pdist featurizers, widths[0] for
+ * identity.  Uploads, featurizes (pdist) and LayerNorm-standardises once. */
+int  isk_set_data(isk_engine* e, const float* xs, const float* ys, int64_t D, int64_t K, int64_t N);
+int  isk_set_data_dev(isk_engine* e, const float* xs_dev, const float* ys_dev, int64_t D, int64_t K, int64_t N);
+int  isk_data_shape(isk_engine* e, int64_t* D, int64_t* K, int64_t* N);
+
+/* ---- featurizer: f(coords)   src/utils/features.jl:22-35, pairdists.jl:6-24,109-127 */
+/* coords (D, ncols) -> out (F, ncols) */
+int  isk_features(isk_engine* e, const float* coords, int64_t D, int64_t ncols, float* out);
+
+/* ---- model call: iso.model(x)   src/iso.jl:185,203; src/isotarget.jl:18,101 ---- */
+/* x (F, ncols) features -> out (nout, ncols) */
+int  isk_forward(isk_engine* e, const float* x, int64_t F, int64_t ncols, float* out);
+/* chicoords(iso, coords)   src/iso.jl:211 : coords (D, ncols) -> (nout, ncols) */
+int  isk_chicoords(isk_engine* e, const float* coords, int64_t D, int64_t ncols, float* out);
+/* chis(iso)   src/iso.jl:203 : (nout, N) on the resident xs */
+int  isk_chis(isk_engine* e, float* out);
+/* koopman(iso) = expectation(model, propfeatures)   src/isotarget.jl:18,20 : (nout, N) */
+int  isk_koopman(isk_engine* e, float* out);
+
+/* ---- target: isotarget(iso)   src/isotarget.jl:10-42, 74-127 ------------------- */
+/* Computes the target on the resident data, keeps it on the device for training and,
+ * if out != NULL, copies it to out (nout, N). */
+int  isk_target(isk_engine* e, float* out);
+
+/* ---- training: train_batch!   src/iso.jl:179-194 ------------------------------- */
+/* One epoch.  target (nout, N) host array, or NULL to use the device-resident one from
+ * the last isk_target.  perm: N 0-based indices (the DataLoader shuffle order) or NULL
+ * for the engine's own seeded shuffle.  minibatch < 0 uses cfg.minibatch.
+ * Returns sum-of-batch-losses / N in *loss (Float64, src/iso.jl:193). */
+int  isk_train_batch(isk_engine* e, const float* target, int32_t minibatch, const int32_t* perm, double* loss);
+/* Gradient of  l / numobs  for one batch of column indices, Flux trainables order
+ * (what Zygote hands to update!, src/iso.jl:184-191).  No parameter update.
+ * l (the un-normalised batch loss) is returned in *loss. */
+int  isk_batch_grads(isk_engine* e, const float* target, const int32_t* idx, int32_t nidx, float* grads, double* loss);
+
+/* ---- run!(iso, n, epochs)   src/iso.jl:72-94 ----------------------------------- */
+/* perms: n*epochs permutations of N (consumed in order) or NULL.  losses: n*epochs. */
+int  isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* perms, double* losses);
+
+/* ---- data-parallel hooks (one process per GPU; collectives stay with the host) -- */
+/* local (unreduced) statistics the target needs across shards */
+int  isk_dp_koopman_local(isk_engine* e);                       /* ks for the local shard, stays on device */
+int  isk_dp_minmax_local(isk_engine* e, float mm[2]);           /* local min, max of ks (1-D) */
+int  isk_dp_shiftscale_apply(isk_engine* e, float gmin, float gmax);   /* target = (ks-gmin)/(gmax-gmin) */
+int  isk_dp_get_ks_chi(isk_engine* e, float* ks, float* chi);   /* local (nout, N) slices for the ISA gather */
+int  isk_dp_isa_apply(isk_engine* e, const double* At, const int32_t* rowperm); /* target = (A' ks)[perm] */
+int  isk_dp_set_loss_weights(isk_engine* e, const float* w);    /* global 1/std(target) */
+/* device pointer + length of the flat gradient/loss buffer: [grads (nparams) | batch loss] */
+int  isk_dp_grad_buffer(isk_engine* e, void** buf_dev, int64_t* nfloats);
+/* local batch -> this rank's contribution to the gradient of (global batch loss / global_batch),
+ * written into the buffer together with the local batch loss; nothing is updated */
+int  isk_dp_local_grads(isk_engine* e, const int32_t* idx, int32_t nidx, int64_t global_batch);
+/* after the host all-reduced (sum) the buffer: one optimizer step from it; *batch_loss = the
+ * all-reduced batch loss.  A non-finite loss skips the update and returns ISK_ECOLLAPSED. */
+int  isk_dp_apply(isk_engine* e, double* batch_loss);
+
+/* ---- instrumentation -------------------------------------------------------------- */
+typedef enum { ISK_T_FEATURIZE = 0, ISK_T_FWD_YS = 1, ISK_T_FWD_XS = 2, ISK_T_TARGET = 3,
+               ISK_T_TRAIN = 4, ISK_T_COUNT = 5 } isk_timer_id;
+/* HIP-event timing of the named phase on the engine's stream (enable before the run) */
+int  isk_timers_enable(isk_engine* e, int32_t on);
+int  isk_timers_read(isk_engine* e, double total_ms[ISK_T_COUNT], int64_t count[ISK_T_COUNT]);
+int  isk_timers_reset(isk_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISOKANN_HIP_H */

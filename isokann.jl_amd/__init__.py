@@ -1,0 +1,18 @@
+"""isokann.jl_amd -- MI355X-native engine for the ISOKANN.jl train-step hot path.
+
+Layout:
+    csrc/     HIP kernels (gfx950) + the C-ABI engine  -> lib/libisokann_hip.so
+    capi.py   ctypes binding of include/isokann_hip.h
+    api.py    host-side mirror of the reference interface (Iso / run / SimulationData ...)
+    dp.py     data-parallel driver over N (one process per GPU, torch.distributed)
+
+The directory name is not a Python identifier; load it with
+`__graft_entry__.load_package()` (registers it as module `isokann_jl_amd`).
+"""
+from . import capi  # noqa: F401
+from .api import (  # noqa: F401
+    AdamRegularized, DomainError, FeaturesAll, FeaturesAtoms, FeaturesPairs, HipModel, IskError, Iso, ModelSpec,
+    NesterovRegularized, OptSpec, SimulationData, TransformISA, TransformShiftscale, batch_grads, chicoords, chis,
+    coords, densenet, featuredim, features, halfinds, identity, inputdim, isotarget, koopman, outputdim, pairnet,
+    pairnet_widths, propcoords, propfeatures, run, train_batch,
+)

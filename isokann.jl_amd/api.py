@@ -1,0 +1,482 @@
+"""Host-side mirror of the reference's interface for the hot path, above the C ABI.
+
+Same names, argument meaning and error behaviour as axsk/ISOKANN.jl v2.0.0
+(files relative to the reference repo):
+
+    SimulationData(xs, ys; featurizer)       src/simulation.jl:71-76, 100-114
+    FeaturesAll / FeaturesAtoms / FeaturesPairs   src/utils/features.jl:22-35
+    pairnet / densenet                        src/models.jl:65-69, 87-92
+    AdamRegularized / NesterovRegularized     src/models.jl:12, 20
+    TransformShiftscale / TransformISA        src/isotarget.jl:32, 74-77
+    Iso(data; opt, model, target, minibatch)  src/iso.jl:3-43
+    run(iso, n, epochs)  [run!]               src/iso.jl:72-94
+    train_batch(iso, target, ...) [train_batch!]  src/iso.jl:179-194
+    isotarget / koopman                       src/isotarget.jl:10-23
+    chis / chicoords                          src/iso.jl:203, 211
+
+Arrays keep Julia's shapes: xs (D, N), ys (D, K, N), outputs (nout, N).  Atom and
+pair indices are 0-based here (Python), 1-based in the reference.  Everything numeric
+happens in the HIP library; this file only marshals.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import capi
+from .capi import DomainError, IskError  # noqa: F401  (re-exported)
+
+
+# ------------------------------------------------------------------------ featurizers --
+def halfinds(n: int) -> List[Tuple[int, int]]:
+    """src/utils/pairdists.jl:50-56: upper-triangle indices in column-major order"""
+    return [(i, j) for j in range(1, n) for i in range(j)]
+
+
+@dataclass(frozen=True)
+class FeaturesAll:
+    """pairwise distances between all atoms (src/utils/features.jl:22-23)"""
+    def pairs(self, n_atoms):
+        return None                       # the engine builds the halfinds list itself
+
+    def featuredim(self, d):
+        a = d // 3
+        return a * (a - 1) // 2
+
+
+@dataclass(frozen=True)
+class FeaturesAtoms:
+    """pairwise distances between the given atoms (src/utils/features.jl:26-29)"""
+    atominds: Tuple[int, ...]
+
+    def __init__(self, atominds):
+        object.__setattr__(self, "atominds", tuple(int(i) for i in atominds))
+
+    def pairs(self, n_atoms):
+        ix = self.atominds
+        return [(ix[i], ix[j]) for (i, j) in halfinds(len(ix))]
+
+    def featuredim(self, d):
+        n = len(self.atominds)
+        return n * (n - 1) // 2
+
+
+@dataclass(frozen=True)
+class FeaturesPairs:
+    """distances for an explicit pair list (src/utils/features.jl:31-34)"""
+    pairlist: Tuple[Tuple[int, int], ...]
+
+    def __init__(self, pairs):
+        object.__setattr__(self, "pairlist", tuple((int(a), int(b)) for a, b in pairs))
+
+    def pairs(self, n_atoms):
+        return list(self.pairlist)
+
+    def featuredim(self, d):
+        return len(self.pairlist)
+
+
+identity = None      # featurizer(::IsoSimulation) = identity  (src/simulation.jl:15)
+
+
+# ----------------------------------------------------------------------------- model ---
+def pairnet_widths(n: int, layers: int = 3, nout: int = 1) -> List[int]:
+    """src/models.jl:66-67 (Julia's round(Int, x) and Python's round both round half to even)"""
+    return [int(round(n ** (l / layers))) for l in range(layers, 0, -1)] + [nout]
+
+
+@dataclass
+class ModelSpec:
+    """what densenet(...) builds: Chain([LayerNorm(n)], Dense..., Dense) (src/models.jl:87-92)"""
+    widths: List[int]
+    activation: str = "sigmoid"
+    lastactivation: str = "identity"
+    layernorm: bool = False
+    params: Optional[np.ndarray] = None          # flat, Flux trainables order
+    ln_eps: float = 1e-5
+    ln_mode: str = "var_eps2"
+
+    def nparams(self) -> int:
+        n = 2 * self.widths[0] if self.layernorm else 0
+        for a, b in zip(self.widths[:-1], self.widths[1:]):
+            n += a * b + b
+        return n
+
+    def init_glorot(self, rng: np.random.Generator) -> np.ndarray:
+        """Flux defaults: glorot_uniform weights, zero bias, LayerNorm scale 1 / bias 0"""
+        parts = []
+        if self.layernorm:
+            parts += [np.ones(self.widths[0], np.float32), np.zeros(self.widths[0], np.float32)]
+        for fin, fout in zip(self.widths[:-1], self.widths[1:]):
+            lim = math.sqrt(6.0 / (fin + fout))
+            parts += [rng.uniform(-lim, lim, size=fin * fout).astype(np.float32), np.zeros(fout, np.float32)]
+        self.params = np.concatenate(parts)
+        return self.params
+
+
+def densenet(layers: Sequence[int], activation="sigmoid", lastactivation="identity", layernorm=False,
+             seed: Optional[int] = 0) -> ModelSpec:
+    """src/models.jl:87-92"""
+    m = ModelSpec([int(w) for w in layers], activation, lastactivation, bool(layernorm))
+    m.init_glorot(np.random.default_rng(seed))
+    return m
+
+
+def pairnet(data=None, *, n: Optional[int] = None, layers=3, activation="sigmoid", lastactivation="identity",
+            nout=1, layernorm=True, seed: Optional[int] = 0) -> ModelSpec:
+    """src/models.jl:59, 65-69"""
+    if n is None:
+        n = featuredim(data)
+    return densenet(pairnet_widths(n, layers, nout), activation, lastactivation, layernorm, seed)
+
+
+def inputdim(m: ModelSpec) -> int:
+    """src/models.jl:26-27"""
+    return m.widths[0]
+
+
+def outputdim(m: ModelSpec) -> int:
+    """src/models.jl:30-31"""
+    return m.widths[-1]
+
+
+# ------------------------------------------------------------------------- optimisers --
+@dataclass
+class OptSpec:
+    kind: str
+    lr: float = 1e-3
+    reg: float = 1e-4
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-8
+    rho: float = 0.9
+
+
+def AdamRegularized(adam=1e-3, reg=1e-4) -> OptSpec:
+    """src/models.jl:12: OptimiserChain(WeightDecay(reg), Adam(adam))"""
+    return OptSpec("adam", adam, reg)
+
+
+def NesterovRegularized(lr=1e-3, reg=1e-4) -> OptSpec:
+    """src/models.jl:20: OptimiserChain(WeightDecay(reg), Nesterov(lr)); the default (src/iso.jl:18)"""
+    return OptSpec("nesterov", lr, reg)
+
+
+# ---------------------------------------------------------------------------- targets --
+@dataclass
+class TransformShiftscale:
+    """src/isotarget.jl:32"""
+
+
+@dataclass
+class TransformISA:
+    """src/isotarget.jl:74-77"""
+    permute: bool = True
+    whitening: bool = False
+
+
+# ------------------------------------------------------------------------------- data --
+class SimulationData:
+    """SimulationData(xs, ys; featurizer) (src/simulation.jl:100-114): coords = (xs, ys).
+    The Float32 features the reference caches at construction live on the GPU, inside the
+    engine that `Iso` creates; `features(data)` recomputes them through the same kernel."""
+
+    def __init__(self, xs, ys, featurizer=identity):
+        xs = np.asarray(xs)
+        ys = np.asarray(ys)
+        if xs.ndim != 2 or ys.ndim != 3:
+            raise ValueError("xs must be (D, N) and ys (D, K, N)")
+        if xs.shape[0] != ys.shape[0] or xs.shape[1] != ys.shape[2]:
+            raise ValueError("xs (D, N) and ys (D, K, N) disagree")
+        if featurizer is not identity and xs.shape[0] % 3 != 0:
+            raise ValueError("pairwise-distance featurizers need 3*n_atoms coordinate rows")
+        self.coords = (capi.f32(xs), capi.f32(ys))
+        self.featurizer = featurizer
+
+    def __len__(self):                               # src/simulation.jl:131
+        return self.coords[0].shape[1]
+
+    def __getitem__(self, i):                        # src/simulation.jl:135
+        xs, ys = self.coords
+        i = np.arange(len(self))[i]
+        return SimulationData(xs[:, i], ys[:, :, i], self.featurizer)
+
+    @property
+    def nk(self):                                    # src/simulation.jl:129
+        return self.coords[1].shape[1]
+
+
+def coords(d):
+    return (d.data if isinstance(d, Iso) else d).coords[0]          # src/simulation.jl:140
+
+
+def propcoords(d):
+    return (d.data if isinstance(d, Iso) else d).coords[1]          # src/simulation.jl:142
+
+
+def featuredim(d) -> int:
+    """src/simulation.jl:128"""
+    d = d.data if isinstance(d, Iso) else d
+    dim = d.coords[0].shape[0]
+    return dim if d.featurizer is identity else d.featurizer.featuredim(dim)
+
+
+# -------------------------------------------------------------------------------- Iso --
+def _make_config(data: SimulationData, model: ModelSpec, opt: OptSpec, target, minibatch: int, device: int,
+                 featurize_every_iteration: bool, seed: int):
+    lib = capi.load()
+    cfg = capi.Config()
+    lib.isk_config_default(C.byref(cfg))
+    cfg.device = device
+    cfg.n_layers = len(model.widths) - 1
+    if cfg.n_layers > capi.ISK_MAX_LAYERS:
+        raise ValueError("too many layers")
+    for i, w in enumerate(model.widths):
+        cfg.widths[i] = w
+    cfg.activation = capi.ACT[model.activation]
+    cfg.lastactivation = capi.ACT[model.lastactivation]
+    cfg.layernorm = int(model.layernorm)
+    cfg.ln_mode = capi.LN_MODE[model.ln_mode]
+    cfg.ln_eps = model.ln_eps
+    cfg.opt_kind = capi.OPT[opt.kind]
+    cfg.lr, cfg.reg, cfg.beta1, cfg.beta2, cfg.opt_eps, cfg.rho = opt.lr, opt.reg, opt.beta1, opt.beta2, opt.eps, opt.rho
+    keep = None
+    dim = data.coords[0].shape[0]
+    f = data.featurizer
+    if f is identity:
+        cfg.featurizer = capi.FEAT_IDENTITY
+    else:
+        cfg.n_atoms = dim // 3
+        pl = f.pairs(cfg.n_atoms)
+        if pl is None:
+            cfg.featurizer = capi.FEAT_ALLPAIRS
+        else:
+            cfg.featurizer = capi.FEAT_PAIRLIST
+            keep = np.ascontiguousarray(np.asarray(pl, dtype=np.int32).reshape(-1))
+            cfg.n_pairs = len(pl)
+            cfg.pairs = capi.ptr_i32(keep)
+    cfg.featurize_every_iteration = int(featurize_every_iteration)
+    if isinstance(target, TransformISA):
+        cfg.target_kind = capi.TARGET_ISA
+        cfg.isa_permute = int(target.permute)
+        cfg.isa_whitening = int(target.whitening)
+    elif isinstance(target, TransformShiftscale):
+        cfg.target_kind = capi.TARGET_SHIFTSCALE
+    else:
+        raise TypeError(f"unsupported target transform {target!r}")
+    cfg.minibatch = int(minibatch)
+    cfg.seed = int(seed)
+    return cfg, keep
+
+
+class HipModel:
+    """stands where `iso.model` (a Flux.Chain) stands: callable on (F, N) and (F, K, N)
+    Float32 feature arrays (callers: src/isotarget.jl:18,101; src/iso.jl:185,203)."""
+
+    def __init__(self, iso: "Iso"):
+        self._iso = iso
+
+    @property
+    def layers(self):
+        return self._iso.modelspec.widths
+
+    def __call__(self, x):
+        x = capi.f32(x)
+        f, s = x.shape[0], x.shape[1:]
+        ncols = int(np.prod(s)) if s else 1
+        out = np.empty((self._iso.nout, ncols), dtype=np.float32, order="F")
+        capi.check(self._iso._lib.isk_forward(self._iso._h, capi.ptr_f32(x), f, ncols, capi.ptr_f32(out)))
+        return out.reshape((self._iso.nout,) + s, order="F")
+
+    def get_params(self) -> np.ndarray:
+        n = self._iso.modelspec.nparams()
+        flat = np.empty(n, dtype=np.float32)
+        capi.check(self._iso._lib.isk_get_params(self._iso._h, capi.ptr_f32(flat), n))
+        return flat
+
+    def set_params(self, flat):
+        flat = np.ascontiguousarray(flat, dtype=np.float32)
+        capi.check(self._iso._lib.isk_set_params(self._iso._h, capi.ptr_f32(flat), flat.size))
+
+
+class Iso:
+    """Iso(data; opt=NesterovRegularized(), model=defaultmodel(data), target, minibatch=100)
+    (src/iso.jl:3-43).  `gpu` is implied: the engine lives on `device`."""
+
+    def __init__(self, data: SimulationData, *, opt: Optional[OptSpec] = None, model: Optional[ModelSpec] = None,
+                 target=None, minibatch: int = 100, loggers=None, device: int = 0,
+                 featurize_every_iteration: bool = False, seed: int = 0):
+        self.data = data
+        self.optspec = opt if opt is not None else NesterovRegularized()          # src/iso.jl:18
+        self.modelspec = model if model is not None else pairnet(data)            # src/simulation.jl:126-127
+        if self.modelspec.widths[0] != featuredim(data):
+            raise ValueError("model input dimension does not match the feature dimension")
+        if target is None:                                                        # src/iso.jl:28-34
+            target = TransformShiftscale() if outputdim(self.modelspec) == 1 else TransformISA()
+        self.target = target
+        self.minibatch = minibatch
+        self.losses: List[float] = []
+        self.loggers = list(loggers or [])
+        self.nout = outputdim(self.modelspec)
+        self._lib = capi.load()
+        cfg, keep = _make_config(data, self.modelspec, self.optspec, target, minibatch, device,
+                                 featurize_every_iteration, seed)
+        h = C.c_void_p()
+        capi.check(self._lib.isk_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        del keep
+        self.model = HipModel(self)
+        if self.modelspec.params is None:
+            self.modelspec.init_glorot(np.random.default_rng(seed))
+        self.model.set_params(self.modelspec.params)
+        xs, ys = data.coords
+        d, k, n = ys.shape
+        capi.check(self._lib.isk_set_data(self._h, capi.ptr_f32(xs), capi.ptr_f32(ys), d, k, n))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.isk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- optimizer state (Flux.setup / save / load) -------------------------------------
+    def get_opt_state(self):
+        n = self.modelspec.nparams()
+        m = np.empty(n, np.float32)
+        v = np.empty(n, np.float32)
+        bt = np.zeros(2, np.float64)
+        capi.check(self._lib.isk_get_opt_state(self._h, capi.ptr_f32(m), capi.ptr_f32(v), n, capi.ptr_f64(bt)))
+        return m, v, bt
+
+    def set_opt_state(self, m, v, bt):
+        m = np.ascontiguousarray(m, np.float32)
+        v = np.ascontiguousarray(v, np.float32)
+        bt = np.ascontiguousarray(bt, np.float64)
+        capi.check(self._lib.isk_set_opt_state(self._h, capi.ptr_f32(m), capi.ptr_f32(v), m.size, capi.ptr_f64(bt)))
+
+    # -- instrumentation ----------------------------------------------------------------
+    def timers(self, enable: Optional[bool] = None, reset: bool = False):
+        if enable is not None:
+            capi.check(self._lib.isk_timers_enable(self._h, int(enable)))
+        ms = np.zeros(capi.T_COUNT, np.float64)
+        cnt = np.zeros(capi.T_COUNT, np.int64)
+        capi.check(self._lib.isk_timers_read(self._h, capi.ptr_f64(ms), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
+        if reset:
+            capi.check(self._lib.isk_timers_reset(self._h))
+        return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(capi.TIMER_NAMES)}
+
+
+def _perm_array(perm, n):
+    if perm is None:
+        return None
+    p = np.ascontiguousarray(perm, dtype=np.int32)
+    if p.shape[-1] != n:
+        raise ValueError("permutation length must equal the number of samples")
+    return p
+
+
+def run(iso: Iso, n: int = 1, epochs: int = 1, perms=None, showprogress: bool = False) -> Iso:
+    """run!(iso, n, epochs) (src/iso.jl:72-94).  `perms`: optional (n*epochs, N) injected
+    DataLoader shuffle orders (parity tests); otherwise the engine's seeded shuffle."""
+    N = len(iso.data)
+    p = _perm_array(perms, N)
+    if p is not None and p.size != n * epochs * N:
+        raise ValueError("need one permutation per (iteration, epoch)")
+    if not iso.loggers:
+        losses = np.zeros(n * epochs, np.float64)
+        capi.check(iso._lib.isk_run(iso._h, n, epochs, capi.ptr_i32(p) if p is not None else None, capi.ptr_f64(losses)))
+        iso.losses.extend(float(l) for l in losses)
+        return iso
+    # loggers run after every outer iteration on the host (src/iso.jl:84-91)
+    p2 = None if p is None else p.reshape(n, epochs, N)
+    for it in range(n):
+        losses = np.zeros(epochs, np.float64)
+        pi = None if p2 is None else np.ascontiguousarray(p2[it])
+        capi.check(iso._lib.isk_run(iso._h, 1, epochs, capi.ptr_i32(pi) if pi is not None else None, capi.ptr_f64(losses)))
+        iso.losses.extend(float(l) for l in losses)
+        for logger in iso.loggers:
+            logger(iso=iso)
+    return iso
+
+
+def isotarget(iso: Iso) -> np.ndarray:
+    """isotarget(iso) (src/isotarget.jl:10-12) -> (nout, N)"""
+    out = np.empty((iso.nout, len(iso.data)), np.float32, order="F")
+    capi.check(iso._lib.isk_target(iso._h, capi.ptr_f32(out)))
+    return out
+
+
+def train_batch(iso: Iso, target=None, minibatch: Optional[int] = None, perm=None) -> float:
+    """train_batch!(model, xs, target, opt, minibatch) (src/iso.jl:179-194) on the resident xs.
+    target=None reuses the device-resident target of the last isotarget(iso)."""
+    t = None if target is None else capi.f32(target)
+    if t is not None and t.shape != (iso.nout, len(iso.data)):
+        raise ValueError("target must be (nout, N)")
+    p = _perm_array(perm, len(iso.data))
+    loss = C.c_double(0)
+    capi.check(iso._lib.isk_train_batch(iso._h, capi.ptr_f32(t) if t is not None else None,
+                                        iso.minibatch if minibatch is None else minibatch,
+                                        capi.ptr_i32(p) if p is not None else None, C.byref(loss)))
+    return float(loss.value)
+
+
+def batch_grads(iso: Iso, target, idx) -> Tuple[np.ndarray, float]:
+    """gradient of l/numobs for one batch (what Zygote hands to update!, src/iso.jl:184-191),
+    flat in Flux trainables order, and the batch loss l"""
+    t = None if target is None else capi.f32(target)
+    idx = np.ascontiguousarray(idx, np.int32)
+    g = np.empty(iso.modelspec.nparams(), np.float32)
+    loss = C.c_double(0)
+    capi.check(iso._lib.isk_batch_grads(iso._h, capi.ptr_f32(t) if t is not None else None, capi.ptr_i32(idx), idx.size,
+                                        capi.ptr_f32(g), C.byref(loss)))
+    return g, float(loss.value)
+
+
+def chis(iso: Iso) -> np.ndarray:
+    """chis(iso) (src/iso.jl:203) -> (nout, N)"""
+    out = np.empty((iso.nout, len(iso.data)), np.float32, order="F")
+    capi.check(iso._lib.isk_chis(iso._h, capi.ptr_f32(out)))
+    return out
+
+
+def koopman(iso: Iso) -> np.ndarray:
+    """koopman(iso) = expectation(model, propfeatures) (src/isotarget.jl:18,20) -> (nout, N)"""
+    out = np.empty((iso.nout, len(iso.data)), np.float32, order="F")
+    capi.check(iso._lib.isk_koopman(iso._h, capi.ptr_f32(out)))
+    return out
+
+
+def chicoords(iso: Iso, xs) -> np.ndarray:
+    """chicoords(iso, xs) (src/iso.jl:211): featurize raw coordinates, then the model"""
+    x = capi.f32(xs)
+    d, s = x.shape[0], x.shape[1:]
+    ncols = int(np.prod(s)) if s else 1
+    out = np.empty((iso.nout, ncols), np.float32, order="F")
+    capi.check(iso._lib.isk_chicoords(iso._h, capi.ptr_f32(x), d, ncols, capi.ptr_f32(out)))
+    return out.reshape((iso.nout,) + s, order="F")
+
+
+def features(iso: Iso, coords_=None) -> np.ndarray:
+    """features(data) / features(data, coords) (src/simulation.jl:121-124, 141): the featurizer
+    applied to coords (default: the resident xs)"""
+    x = capi.f32(iso.data.coords[0] if coords_ is None else coords_)
+    d, s = x.shape[0], x.shape[1:]
+    ncols = int(np.prod(s)) if s else 1
+    F = featuredim(iso)
+    out = np.empty((F, ncols), np.float32, order="F")
+    capi.check(iso._lib.isk_features(iso._h, capi.ptr_f32(x), d, ncols, capi.ptr_f32(out)))
+    return out.reshape((F,) + s, order="F")
+
+
+def propfeatures(iso: Iso) -> np.ndarray:
+    """propfeatures(data) (src/simulation.jl:143)"""
+    return features(iso, iso.data.coords[1])

@@ -1,0 +1,1084 @@
+// Host side of the MI355X ISOKANN engine: owns device memory, sequences the kernels of
+// kernels_fwd.hip / kernels_train.hip on one HIP stream, implements the C ABI of
+// include/isokann_hip.h.  The Float64 inner-simplex (ISA) solve runs on the host, as it does
+// in the reference (src/isotarget.jl:81-107 pulls chi and ks to the CPU).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "isk_internal.h"
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            return fail(_e == hipErrorOutOfMemory ? ISK_ENOMEM : ISK_EHIP,                                \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                               \
+    } while (0)
+
+#define CHK(expr)                      \
+    do {                               \
+        int _r = (expr);               \
+        if (_r != ISK_OK) return _r;   \
+    } while (0)
+
+extern "C" const char* isk_last_error(void) { return g_err.c_str(); }
+
+extern "C" const char* isk_status_string(int s) {
+    switch (s) {
+        case ISK_OK: return "ok";
+        case ISK_EINVAL: return "invalid argument";
+        case ISK_EHIP: return "HIP error";
+        case ISK_ENOMEM: return "out of memory";
+        case ISK_ECONSTANT_CHI: return "DomainError: Could not compute the shift-scale. chi function is constant";
+        case ISK_ECOLLAPSED: return "DomainError: The ISOKANN model collapsed under training. Try reducing the learning rate or increasing regularization";
+        case ISK_ESINGULAR: return "DomainError: Could not compute the simplex transformation. The subspace might be singular/collapsed";
+        case ISK_EUNSUPPORTED: return "unsupported configuration";
+        case ISK_ESTATE: return "invalid call order";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int isk_abi_version(void) { return ISK_ABI_VERSION; }
+
+extern "C" int isk_device_count(int32_t* count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(ISK_EHIP, hipGetErrorString(e)); }
+    *count = n;
+    return ISK_OK;
+}
+
+extern "C" void isk_config_default(isk_config* c) {
+    std::memset(c, 0, sizeof(*c));
+    c->abi_version = ISK_ABI_VERSION;
+    c->device = 0;
+    c->n_layers = 0;
+    c->activation = ISK_ACT_SIGMOID;        // pairnet default, src/models.jl:65
+    c->lastactivation = ISK_ACT_IDENTITY;
+    c->layernorm = 1;
+    c->ln_mode = ISK_LN_VAR_EPS2;
+    c->ln_eps = 1e-5f;
+    c->opt_kind = ISK_OPT_NESTEROV;         // src/iso.jl:18
+    c->lr = 1e-3f; c->reg = 1e-4f;          // src/models.jl:12,20
+    c->beta1 = 0.9f; c->beta2 = 0.999f; c->opt_eps = 1e-8f; c->rho = 0.9f;
+    c->featurizer = ISK_FEAT_IDENTITY;
+    c->featurize_every_iteration = 0;
+    c->target_kind = ISK_TARGET_SHIFTSCALE;
+    c->isa_permute = 1; c->isa_whitening = 0;   // src/isotarget.jl:74-77
+    c->minibatch = 100;                     // src/iso.jl:10
+    c->seed = 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------------------
+struct EventPair { hipEvent_t a, b; int id; };
+
+struct isk_engine {
+    isk_config cfg;
+    int L = 0, F = 0, Fp = 0, Din = 0, nout = 0;
+    long long nparams = 0, off_lns = -1, off_lnb = -1;
+    long long off_W[ISK_MAX_LAYERS], off_b[ISK_MAX_LAYERS];
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // parameters
+    float *d_theta = nullptr, *d_grad = nullptr, *d_m = nullptr, *d_v = nullptr;
+    float* d_Wt[ISK_MAX_LAYERS] = {nullptr};
+    float* d_bias[ISK_MAX_LAYERS] = {nullptr};
+    double* d_loss_acc = nullptr;
+    int* d_status = nullptr;
+    float* d_mm = nullptr;
+    int2* d_pairs = nullptr;
+    double bt1 = 0.9, bt2 = 0.999;
+    // data
+    long long N = 0, K = 0, D = 0;
+    float *d_in_xs = nullptr, *d_in_ys = nullptr;   // raw coords / raw features
+    float* d_xhat = nullptr;                         // [(N*K + N)][Fp]  ys rows first, then xs rows
+    float* d_out = nullptr;                          // [(N*K + N)][nout]
+    float *d_ks = nullptr, *d_target = nullptr, *d_lossw = nullptr;
+    bool have_target = false, have_ks = false;
+    // training workspace
+    float *d_z1 = nullptr, *d_delta1 = nullptr, *d_part = nullptr;
+    int* d_perm = nullptr;
+    float* d_At = nullptr;
+    int* d_rowperm = nullptr;
+    uint64_t rng[4];
+    // timers
+    bool timers_on = false;
+    std::vector<EventPair> ev_live, ev_free;
+    double t_ms[ISK_T_COUNT] = {0};
+    long long t_cnt[ISK_T_COUNT] = {0};
+};
+
+static void free_dev(void* p) { if (p) (void)hipFree(p); }
+
+static void free_data(isk_engine* e) {
+    free_dev(e->d_in_xs); free_dev(e->d_in_ys); free_dev(e->d_xhat); free_dev(e->d_out); free_dev(e->d_ks);
+    free_dev(e->d_target); free_dev(e->d_z1); free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm);
+    e->d_in_xs = e->d_in_ys = e->d_xhat = e->d_out = e->d_ks = e->d_target = e->d_z1 = e->d_delta1 = e->d_part = nullptr;
+    e->d_perm = nullptr;
+    e->N = e->K = e->D = 0;
+    e->have_target = e->have_ks = false;
+}
+
+// splitmix64 / xoshiro256** (documented shuffle stream; Julia's cannot be reproduced)
+static uint64_t splitmix(uint64_t& x) {
+    uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static uint64_t xoshiro(uint64_t s[4]) {
+    const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+    return r;
+}
+static void shuffle_perm(isk_engine* e, std::vector<int32_t>& p) {
+    for (size_t i = 0; i < p.size(); ++i) p[i] = (int32_t)i;
+    for (size_t i = p.size(); i > 1; --i) {
+        const size_t j = (size_t)(xoshiro(e->rng) % i);
+        std::swap(p[i - 1], p[j]);
+    }
+}
+
+// ---- timers ---------------------------------------------------------------------------
+struct ScopedTimer {
+    isk_engine* e; EventPair ep; bool on;
+    ScopedTimer(isk_engine* e_, int id) : e(e_), on(e_->timers_on) {
+        if (!on) return;
+        if (!e->ev_free.empty()) { ep = e->ev_free.back(); e->ev_free.pop_back(); }
+        else { (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b); }
+        ep.id = id;
+        (void)hipEventRecord(ep.a, e->stream);
+    }
+    ~ScopedTimer() {
+        if (!on) return;
+        (void)hipEventRecord(ep.b, e->stream);
+        e->ev_live.push_back(ep);
+    }
+};
+
+static void drain_timers(isk_engine* e) {
+    for (auto& ep : e->ev_live) {
+        (void)hipEventSynchronize(ep.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { e->t_ms[ep.id] += ms; e->t_cnt[ep.id] += 1; }
+        e->ev_free.push_back(ep);
+    }
+    e->ev_live.clear();
+}
+
+// ---- argument builders ----------------------------------------------------------------
+static int act_of_layer(const isk_engine* e, int l) { return l == e->L - 1 ? e->cfg.lastactivation : e->cfg.activation; }
+
+static MlpFwdArgs fwd_args(const isk_engine* e, const float* X, long long S, float* out) {
+    MlpFwdArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.X = X; a.rows = nullptr; a.S = S; a.Fp = e->Fp; a.nchunks = e->Fp / 16;
+    a.W1t = e->d_Wt[0]; a.bias1 = e->d_bias[0];
+    a.act1 = act_of_layer(e, 0);
+    a.H1 = e->cfg.widths[1];
+    a.nt1 = isk_pad16(a.H1) / 16;
+    a.ntail = e->L - 1;
+    int sa = 0, sb = 0;
+    for (int l = 1; l < e->L; ++l) {
+        TailLayer& t = a.tail[l - 1];
+        t.Wt = e->d_Wt[l]; t.bias = e->d_bias[l];
+        t.kchunks = isk_pad16(e->cfg.widths[l]) / 16;
+        t.ntiles = isk_pad16(e->cfg.widths[l + 1]) / 16;
+        t.act = act_of_layer(e, l);
+        t.width = e->cfg.widths[l + 1];
+    }
+    // scratch A holds the outputs of layers 0,2,4,..; scratch B of layers 1,3,..
+    for (int l = 0; l < e->L - 1; ++l) {
+        const int w = isk_pad16(e->cfg.widths[l + 1]) + 4;
+        if (l % 2 == 0) sa = std::max(sa, w); else sb = std::max(sb, w);
+    }
+    a.stride_a = std::max(sa, 4); a.stride_b = std::max(sb, 4);
+    a.out = out; a.nout = e->nout;
+    return a;
+}
+
+static TrainShape train_shape(const isk_engine* e) {
+    TrainShape s;
+    std::memset(&s, 0, sizeof(s));
+    s.nlayers = e->L;
+    for (int i = 0; i <= e->L; ++i) s.widths[i] = e->cfg.widths[i];
+    s.act = e->cfg.activation; s.lastact = e->cfg.lastactivation;
+    s.layernorm = e->cfg.layernorm;
+    s.off_lns = e->off_lns; s.off_lnb = e->off_lnb;
+    for (int l = 0; l < e->L; ++l) { s.off_W[l] = e->off_W[l]; s.off_b[l] = e->off_b[l]; }
+    s.nparams = e->nparams;
+    return s;
+}
+
+static TrainBuffers train_buffers(const isk_engine* e) {
+    TrainBuffers b;
+    std::memset(&b, 0, sizeof(b));
+    b.xhat_xs = e->d_xhat + (long long)e->N * e->K * e->Fp;
+    b.target = e->d_target; b.lossw = e->d_lossw; b.theta = e->d_theta;
+    b.W1t = e->d_Wt[0]; b.bias1 = e->d_bias[0];
+    b.a1 = e->d_z1; b.delta1 = e->d_delta1; b.part = e->d_part; b.grad = e->d_grad;
+    b.loss_acc = e->d_loss_acc; b.Fp = e->Fp;
+    return b;
+}
+
+static void launch_fold(isk_engine* e) {
+    FoldArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.theta = e->d_theta; a.nlayers = e->L;
+    for (int i = 0; i <= e->L; ++i) a.widths[i] = e->cfg.widths[i];
+    a.off_lns = e->off_lns; a.off_lnb = e->off_lnb;
+    for (int l = 0; l < e->L; ++l) { a.off_W[l] = e->off_W[l]; a.off_b[l] = e->off_b[l]; a.Wt[l] = e->d_Wt[l]; a.bias[l] = e->d_bias[l]; }
+    isk_launch_fold(a, e->stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// lifetime
+// ---------------------------------------------------------------------------------------
+extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
+    if (!cfg || !out) return fail(ISK_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != ISK_ABI_VERSION) return fail(ISK_EINVAL, "abi_version mismatch");
+    if (cfg->n_layers < 1 || cfg->n_layers > ISK_MAX_LAYERS) return fail(ISK_EINVAL, "n_layers out of range");
+    for (int i = 0; i <= cfg->n_layers; ++i)
+        if (cfg->widths[i] < 1) return fail(ISK_EINVAL, "layer width < 1");
+    if (cfg->activation < 0 || cfg->activation > ISK_ACT_SWISH || cfg->lastactivation < 0 || cfg->lastactivation > ISK_ACT_SWISH)
+        return fail(ISK_EINVAL, "unknown activation");
+    if (cfg->opt_kind != ISK_OPT_ADAM && cfg->opt_kind != ISK_OPT_NESTEROV) return fail(ISK_EINVAL, "unknown optimizer");
+    const int nout = cfg->widths[cfg->n_layers];
+    if (cfg->target_kind == ISK_TARGET_SHIFTSCALE && nout != 1)
+        return fail(ISK_EINVAL, "TransformShiftscale only works with one dimensional chi functions");
+    if (cfg->target_kind == ISK_TARGET_ISA && nout < 2)
+        return fail(ISK_EINVAL, "TransformISA does not work with one dimensional chi functions");
+    if (cfg->target_kind == ISK_TARGET_ISA && nout > 8) return fail(ISK_EUNSUPPORTED, "ISA fixperm is brute force over d! permutations; d <= 8");
+    if (isk_pad16(cfg->widths[1]) / 16 > ISK_MAX_NT)
+        return fail(ISK_EUNSUPPORTED, "first hidden width > 160 is not covered by the fused f32 forward kernel yet");
+    for (int l = 2; l <= cfg->n_layers; ++l)
+        if (cfg->widths[l] > 256) return fail(ISK_EUNSUPPORTED, "tail layer width > 256 not covered yet");
+    int F = cfg->widths[0], Din = F;
+    std::vector<int2> pairs;
+    if (cfg->featurizer == ISK_FEAT_ALLPAIRS) {
+        const int A = cfg->n_atoms;
+        if (A < 2) return fail(ISK_EINVAL, "n_atoms < 2");
+        if ((long long)A * (A - 1) / 2 != F) return fail(ISK_EINVAL, "widths[0] != n_atoms*(n_atoms-1)/2");
+        // halfinds order (src/utils/pairdists.jl:50-56): for j in 2:n, for i in 1:j-1
+        for (int j = 1; j < A; ++j)
+            for (int i = 0; i < j; ++i) pairs.push_back(make_int2(i, j));
+        Din = 3 * A;
+    } else if (cfg->featurizer == ISK_FEAT_PAIRLIST) {
+        if (cfg->n_pairs != F || !cfg->pairs) return fail(ISK_EINVAL, "n_pairs must equal widths[0] and pairs be non-null");
+        for (int i = 0; i < F; ++i) {
+            const int a = cfg->pairs[2 * i], b = cfg->pairs[2 * i + 1];
+            if (a < 0 || b < 0 || a >= cfg->n_atoms || b >= cfg->n_atoms) return fail(ISK_EINVAL, "pair index out of range");
+            pairs.push_back(make_int2(a, b));
+        }
+        Din = 3 * cfg->n_atoms;
+    } else if (cfg->featurizer != ISK_FEAT_IDENTITY) {
+        return fail(ISK_EINVAL, "unknown featurizer");
+    }
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(ISK_EINVAL, "device ordinal out of range");
+    HIPCHK(hipSetDevice(cfg->device));
+
+    isk_engine* e = new isk_engine();
+    e->cfg = *cfg;
+    e->cfg.pairs = nullptr;
+    e->L = cfg->n_layers; e->F = F; e->Fp = isk_pad16(F); e->Din = Din; e->nout = nout;
+    long long off = 0;
+    if (cfg->layernorm) { e->off_lns = off; off += F; e->off_lnb = off; off += F; }
+    for (int l = 0; l < e->L; ++l) {
+        e->off_W[l] = off; off += (long long)cfg->widths[l] * cfg->widths[l + 1];
+        e->off_b[l] = off; off += cfg->widths[l + 1];
+    }
+    e->nparams = off;
+    uint64_t sm = cfg->seed ^ 0x1234567887654321ull;
+    for (int i = 0; i < 4; ++i) e->rng[i] = splitmix(sm);
+    e->bt1 = cfg->beta1; e->bt2 = cfg->beta2;
+
+#define ALLOC(ptr, bytes)                                                          \
+    do {                                                                           \
+        hipError_t _e = hipMalloc((void**)&(ptr), (bytes));                        \
+        if (_e != hipSuccess) { isk_destroy(e); return fail(ISK_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(_e)); } \
+    } while (0)
+    hipError_t se = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) { delete e; return fail(ISK_EHIP, hipGetErrorString(se)); }
+    e->own_stream = true;
+    const size_t pb = (size_t)(e->nparams + 2) * sizeof(float);
+    ALLOC(e->d_theta, pb); ALLOC(e->d_grad, pb); ALLOC(e->d_m, pb); ALLOC(e->d_v, pb);
+    ALLOC(e->d_loss_acc, 2 * sizeof(double)); ALLOC(e->d_status, sizeof(int)); ALLOC(e->d_mm, 2 * sizeof(float));
+    ALLOC(e->d_lossw, (size_t)nout * sizeof(float));
+    ALLOC(e->d_At, (size_t)nout * nout * sizeof(float)); ALLOC(e->d_rowperm, (size_t)nout * sizeof(int));
+    for (int l = 0; l < e->L; ++l) {
+        ALLOC(e->d_Wt[l], (size_t)isk_pad16(cfg->widths[l]) * isk_pad16(cfg->widths[l + 1]) * sizeof(float));
+        ALLOC(e->d_bias[l], (size_t)isk_pad16(cfg->widths[l + 1]) * sizeof(float));
+    }
+    if (!pairs.empty()) {
+        ALLOC(e->d_pairs, pairs.size() * sizeof(int2));
+        (void)hipMemcpy(e->d_pairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice);
+    }
+#undef ALLOC
+    (void)hipMemset(e->d_theta, 0, pb); (void)hipMemset(e->d_grad, 0, pb);
+    (void)hipMemset(e->d_m, 0, pb); (void)hipMemset(e->d_v, 0, pb);
+    (void)hipMemset(e->d_loss_acc, 0, 2 * sizeof(double)); (void)hipMemset(e->d_status, 0, sizeof(int));
+    std::vector<float> ones(nout, 1.0f);
+    (void)hipMemcpy(e->d_lossw, ones.data(), nout * sizeof(float), hipMemcpyHostToDevice);
+    launch_fold(e);
+    (void)hipStreamSynchronize(e->stream);
+    *out = e;
+    return ISK_OK;
+}
+
+extern "C" void isk_destroy(isk_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    free_data(e);
+    free_dev(e->d_theta); free_dev(e->d_grad); free_dev(e->d_m); free_dev(e->d_v);
+    free_dev(e->d_loss_acc); free_dev(e->d_status); free_dev(e->d_mm); free_dev(e->d_lossw);
+    free_dev(e->d_At); free_dev(e->d_rowperm); free_dev(e->d_pairs);
+    for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_Wt[l]); free_dev(e->d_bias[l]); }
+    drain_timers(e);
+    for (auto& ep : e->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int isk_synchronize(isk_engine* e) {
+    if (!e) return fail(ISK_EINVAL, "null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return ISK_OK;
+}
+
+extern "C" int isk_set_stream(isk_engine* e, void* s) {
+    if (!e) return fail(ISK_EINVAL, "null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->own_stream) { (void)hipStreamDestroy(e->stream); e->own_stream = false; }
+    e->stream = (hipStream_t)s;
+    return ISK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// parameters / optimizer state
+// ---------------------------------------------------------------------------------------
+extern "C" int isk_nparams(isk_engine* e, int64_t* n) {
+    if (!e || !n) return fail(ISK_EINVAL, "null argument");
+    *n = e->nparams;
+    return ISK_OK;
+}
+
+extern "C" int isk_set_params(isk_engine* e, const float* flat, int64_t n) {
+    if (!e || !flat) return fail(ISK_EINVAL, "null argument");
+    if (n != e->nparams) return fail(ISK_EINVAL, "parameter count mismatch");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipMemcpyAsync(e->d_theta, flat, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    launch_fold(e);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->have_target = false; e->have_ks = false;
+    return ISK_OK;
+}
+
+extern "C" int isk_get_params(isk_engine* e, float* flat, int64_t n) {
+    if (!e || !flat) return fail(ISK_EINVAL, "null argument");
+    if (n != e->nparams) return fail(ISK_EINVAL, "parameter count mismatch");
+    HIPCHK(hipMemcpyAsync(flat, e->d_theta, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return ISK_OK;
+}
+
+extern "C" int isk_set_opt_state(isk_engine* e, const float* m, const float* v, int64_t n, const double bt[2]) {
+    if (!e || !m) return fail(ISK_EINVAL, "null argument");
+    if (n != e->nparams) return fail(ISK_EINVAL, "parameter count mismatch");
+    HIPCHK(hipMemcpyAsync(e->d_m, m, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    if (v) HIPCHK(hipMemcpyAsync(e->d_v, v, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (bt) { e->bt1 = bt[0]; e->bt2 = bt[1]; }
+    return ISK_OK;
+}
+
+extern "C" int isk_get_opt_state(isk_engine* e, float* m, float* v, int64_t n, double bt[2]) {
+    if (!e) return fail(ISK_EINVAL, "null argument");
+    if (n != e->nparams) return fail(ISK_EINVAL, "parameter count mismatch");
+    if (m) HIPCHK(hipMemcpyAsync(m, e->d_m, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (v) HIPCHK(hipMemcpyAsync(v, e->d_v, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (bt) { bt[0] = e->bt1; bt[1] = e->bt2; }
+    return ISK_OK;
+}
+
+extern "C" int isk_reset_opt_state(isk_engine* e) {
+    if (!e) return fail(ISK_EINVAL, "null engine");
+    HIPCHK(hipMemsetAsync(e->d_m, 0, (size_t)e->nparams * sizeof(float), e->stream));
+    HIPCHK(hipMemsetAsync(e->d_v, 0, (size_t)e->nparams * sizeof(float), e->stream));
+    e->bt1 = e->cfg.beta1; e->bt2 = e->cfg.beta2;
+    return ISK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// data
+// ---------------------------------------------------------------------------------------
+static void featurize_rows(isk_engine* e, const float* in, long long S, float* xhat) {
+    FeatArgs a;
+    a.in = in; a.pairs = e->d_pairs; a.xhat = xhat; a.S = S; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
+    a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
+    isk_launch_featurize(a, e->stream);
+}
+
+static void featurize_resident(isk_engine* e) {
+    ScopedTimer t(e, ISK_T_FEATURIZE);
+    featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat);
+    featurize_rows(e, e->d_in_xs, e->N, e->d_xhat + (long long)e->N * e->K * e->Fp);
+}
+
+static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_t D, int64_t K, int64_t N, hipMemcpyKind kind) {
+    if (!e || !xs || !ys) return fail(ISK_EINVAL, "null argument");
+    if (D != e->Din) return fail(ISK_EINVAL, "coordinate dimension does not match the featurizer / model input");
+    if (K < 1 || N < 1) return fail(ISK_EINVAL, "K and N must be positive");
+    if (N > 2000000000ll / 16) return fail(ISK_EUNSUPPORTED, "N too large for 32-bit batch indices");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    free_data(e);
+    e->N = N; e->K = K; e->D = D;
+    const long long S = N * K + N;
+    const long long Bpad = ((N + 15) / 16) * 16;
+    const int H1p = isk_pad16(e->cfg.widths[1]);
+    HIPCHK(hipMalloc((void**)&e->d_in_xs, (size_t)N * D * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&e->d_in_ys, (size_t)N * K * D * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&e->d_xhat, (size_t)S * e->Fp * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&e->d_out, (size_t)S * e->nout * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&e->d_ks, (size_t)N * e->nout * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&e->d_target, (size_t)N * e->nout * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&e->d_z1, (size_t)Bpad * H1p * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&e->d_delta1, (size_t)Bpad * H1p * sizeof(float)));
+    const TrainShape ts = train_shape(e);
+    HIPCHK(hipMalloc((void**)&e->d_part, (size_t)isk_train_part_floats(ts, (int)N) * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&e->d_perm, (size_t)N * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(e->d_in_xs, xs, (size_t)N * D * sizeof(float), kind, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_in_ys, ys, (size_t)N * K * D * sizeof(float), kind, e->stream));
+    featurize_resident(e);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    return ISK_OK;
+}
+
+extern "C" int isk_set_data(isk_engine* e, const float* xs, const float* ys, int64_t D, int64_t K, int64_t N) {
+    return set_data_impl(e, xs, ys, D, K, N, hipMemcpyHostToDevice);
+}
+extern "C" int isk_set_data_dev(isk_engine* e, const float* xs, const float* ys, int64_t D, int64_t K, int64_t N) {
+    return set_data_impl(e, xs, ys, D, K, N, hipMemcpyDeviceToDevice);
+}
+extern "C" int isk_data_shape(isk_engine* e, int64_t* D, int64_t* K, int64_t* N) {
+    if (!e) return fail(ISK_EINVAL, "null engine");
+    if (D) *D = e->D; if (K) *K = e->K; if (N) *N = e->N;
+    return ISK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// featurizer / forward on caller-provided columns (not the resident data)
+// ---------------------------------------------------------------------------------------
+struct TmpBuf {
+    void* p = nullptr;
+    ~TmpBuf() { if (p) (void)hipFree(p); }
+};
+
+extern "C" int isk_features(isk_engine* e, const float* coords, int64_t D, int64_t ncols, float* out) {
+    if (!e || !coords || !out) return fail(ISK_EINVAL, "null argument");
+    if (D != e->Din) return fail(ISK_EINVAL, "coordinate dimension mismatch");
+    if (ncols <= 0) return ISK_OK;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    TmpBuf in, xh;
+    HIPCHK(hipMalloc(&in.p, (size_t)ncols * D * sizeof(float)));
+    HIPCHK(hipMalloc(&xh.p, (size_t)ncols * e->Fp * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(in.p, coords, (size_t)ncols * D * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    FeatArgs a;
+    a.in = (const float*)in.p; a.pairs = e->d_pairs; a.xhat = (float*)xh.p; a.S = ncols; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
+    a.normalize = 0; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;   // raw features: the featurizer alone
+    isk_launch_featurize(a, e->stream);
+    HIPCHK(hipMemcpy2DAsync(out, (size_t)e->F * sizeof(float), xh.p, (size_t)e->Fp * sizeof(float), (size_t)e->F * sizeof(float),
+                            (size_t)ncols, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    return ISK_OK;
+}
+
+// x rows already on the device as raw features [ncols][F] or coords [ncols][Din]
+static int forward_cols(isk_engine* e, const float* host_in, int64_t rowlen, int64_t ncols, bool is_coords, float* out) {
+    TmpBuf in, xh, o;
+    HIPCHK(hipMalloc(&in.p, (size_t)ncols * rowlen * sizeof(float)));
+    HIPCHK(hipMalloc(&xh.p, (size_t)ncols * e->Fp * sizeof(float)));
+    HIPCHK(hipMalloc(&o.p, (size_t)ncols * e->nout * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(in.p, host_in, (size_t)ncols * rowlen * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    FeatArgs a;
+    a.in = (const float*)in.p; a.pairs = is_coords ? e->d_pairs : nullptr; a.xhat = (float*)xh.p; a.S = ncols;
+    a.D = (int)rowlen; a.F = e->F; a.Fp = e->Fp;
+    a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
+    isk_launch_featurize(a, e->stream);
+    MlpFwdArgs f = fwd_args(e, (const float*)xh.p, ncols, (float*)o.p);
+    if (isk_launch_mlp_fwd(f, e->stream) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
+    HIPCHK(hipMemcpyAsync(out, o.p, (size_t)ncols * e->nout * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    return ISK_OK;
+}
+
+extern "C" int isk_forward(isk_engine* e, const float* x, int64_t F, int64_t ncols, float* out) {
+    if (!e || !x || !out) return fail(ISK_EINVAL, "null argument");
+    if (F != e->F) return fail(ISK_EINVAL, "feature dimension mismatch");
+    if (ncols <= 0) return ISK_OK;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    return forward_cols(e, x, F, ncols, false, out);
+}
+
+extern "C" int isk_chicoords(isk_engine* e, const float* coords, int64_t D, int64_t ncols, float* out) {
+    if (!e || !coords || !out) return fail(ISK_EINVAL, "null argument");
+    if (D != e->Din) return fail(ISK_EINVAL, "coordinate dimension mismatch");
+    if (ncols <= 0) return ISK_OK;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    return forward_cols(e, coords, D, ncols, e->cfg.featurizer != ISK_FEAT_IDENTITY, out);
+}
+
+// ---------------------------------------------------------------------------------------
+// resident forward, koopman, target
+// ---------------------------------------------------------------------------------------
+static int need_data(isk_engine* e) {
+    if (!e) return fail(ISK_EINVAL, "null engine");
+    if (e->N == 0) return fail(ISK_ESTATE, "no data: call isk_set_data first");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    return ISK_OK;
+}
+
+// which: 1 = ys rows, 2 = xs rows, 3 = both (single launch over the contiguous slab)
+static int forward_resident(isk_engine* e, int which) {
+    const long long nys = e->N * e->K;
+    const float* X = e->d_xhat;
+    float* out = e->d_out;
+    long long S = nys + e->N;
+    int tid = ISK_T_FWD_YS;
+    if (which == 1) S = nys;
+    if (which == 2) { X += nys * e->Fp; out += nys * e->nout; S = e->N; tid = ISK_T_FWD_XS; }
+    ScopedTimer t(e, tid);
+    MlpFwdArgs f = fwd_args(e, X, S, out);
+    if (isk_launch_mlp_fwd(f, e->stream) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
+    return ISK_OK;
+}
+
+static void launch_kmean(isk_engine* e) {
+    KmeanArgs k;
+    k.out_ys = e->d_out; k.ks = e->d_ks; k.N = e->N; k.K = (int)e->K; k.nout = e->nout;
+    isk_launch_kmean(k, e->stream);
+    e->have_ks = true;
+}
+
+extern "C" int isk_chis(isk_engine* e, float* out) {
+    CHK(need_data(e));
+    if (!out) return fail(ISK_EINVAL, "null argument");
+    CHK(forward_resident(e, 2));
+    HIPCHK(hipMemcpyAsync(out, e->d_out + e->N * e->K * e->nout, (size_t)e->N * e->nout * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    return ISK_OK;
+}
+
+extern "C" int isk_koopman(isk_engine* e, float* out) {
+    CHK(need_data(e));
+    if (!out) return fail(ISK_EINVAL, "null argument");
+    CHK(forward_resident(e, 1));
+    launch_kmean(e);
+    HIPCHK(hipMemcpyAsync(out, e->d_ks, (size_t)e->N * e->nout * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    return ISK_OK;
+}
+
+// ---- host Float64 ISA (src/isotarget.jl:81-127; PCCAPlus.indexmap restated) -----------
+static std::vector<int> indexmap_host(std::vector<double> X /* N x d row-major */, long long N, int d) {
+    std::vector<int> ind(d);
+    std::vector<double> rn(N);
+    for (int j = 0; j < d; ++j) {
+        long long best = 0;
+        double bv = -1.0;
+        for (long long n = 0; n < N; ++n) {
+            double s = 0;
+            for (int k = 0; k < d; ++k) s += X[n * d + k] * X[n * d + k];
+            rn[n] = std::sqrt(s);
+            if (rn[n] > bv) { bv = rn[n]; best = n; }      // first maximum, like Julia's argmax
+        }
+        ind[j] = (int)best;
+        if (j == 0) {
+            std::vector<double> x0(X.begin() + best * d, X.begin() + best * d + d);
+            for (long long n = 0; n < N; ++n)
+                for (int k = 0; k < d; ++k) X[n * d + k] -= x0[k];
+        } else {
+            const double inv = 1.0 / rn[best];
+            for (auto& v : X) v *= inv;
+            std::vector<double> vt(X.begin() + best * d, X.begin() + best * d + d);
+            for (long long n = 0; n < N; ++n) {
+                double dot = 0;
+                for (int k = 0; k < d; ++k) dot += X[n * d + k] * vt[k];
+                for (int k = 0; k < d; ++k) X[n * d + k] -= dot * vt[k];
+            }
+        }
+    }
+    return ind;
+}
+
+// Gauss-Jordan inverse with partial pivoting; false if singular / non-finite
+static bool invert_host(std::vector<double>& A, int d) {
+    std::vector<double> M(d * 2 * d, 0.0);
+    for (int i = 0; i < d; ++i) {
+        for (int j = 0; j < d; ++j) M[i * 2 * d + j] = A[i * d + j];
+        M[i * 2 * d + d + i] = 1.0;
+    }
+    for (int c = 0; c < d; ++c) {
+        int p = c;
+        for (int r = c + 1; r < d; ++r)
+            if (std::fabs(M[r * 2 * d + c]) > std::fabs(M[p * 2 * d + c])) p = r;
+        const double pv = M[p * 2 * d + c];
+        if (!(std::fabs(pv) > 0.0) || !std::isfinite(pv)) return false;
+        if (p != c)
+            for (int j = 0; j < 2 * d; ++j) std::swap(M[p * 2 * d + j], M[c * 2 * d + j]);
+        const double inv = 1.0 / pv;
+        for (int j = 0; j < 2 * d; ++j) M[c * 2 * d + j] *= inv;
+        for (int r = 0; r < d; ++r) {
+            if (r == c) continue;
+            const double f = M[r * 2 * d + c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < 2 * d; ++j) M[r * 2 * d + j] -= f * M[c * 2 * d + j];
+        }
+    }
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            A[i * d + j] = M[i * 2 * d + d + j];
+            if (!std::isfinite(A[i * d + j])) return false;
+        }
+    return true;
+}
+
+// symmetric C -> C^(-1/2) by cyclic Jacobi (whitening option, src/isotarget.jl:85-89)
+static bool inv_sqrt_sym(std::vector<double>& C, int d) {
+    std::vector<double> V(d * d, 0.0), A = C;
+    for (int i = 0; i < d; ++i) V[i * d + i] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0;
+        for (int i = 0; i < d; ++i)
+            for (int j = i + 1; j < d; ++j) off += A[i * d + j] * A[i * d + j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < d; ++p)
+            for (int q = p + 1; q < d; ++q) {
+                if (std::fabs(A[p * d + q]) < 1e-300) continue;
+                const double theta = (A[q * d + q] - A[p * d + p]) / (2 * A[p * d + q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+                const double c = 1 / std::sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < d; ++k) {
+                    const double akp = A[k * d + p], akq = A[k * d + q];
+                    A[k * d + p] = c * akp - s * akq; A[k * d + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < d; ++k) {
+                    const double apk = A[p * d + k], aqk = A[q * d + k];
+                    A[p * d + k] = c * apk - s * aqk; A[q * d + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < d; ++k) {
+                    const double vkp = V[k * d + p], vkq = V[k * d + q];
+                    V[k * d + p] = c * vkp - s * vkq; V[k * d + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < d; ++i)
+        if (!(A[i * d + i] > 0)) return false;
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            double s = 0;
+            for (int k = 0; k < d; ++k) s += V[i * d + k] * V[j * d + k] / std::sqrt(A[k * d + k]);
+            C[i * d + j] = s;
+        }
+    return true;
+}
+
+// ks, chi: [N][d] (fp32, as downloaded).  Produces At (A' row-major: target = At * ks[n]) and the row permutation.
+static int isa_solve_host(const isk_engine* e, const std::vector<float>& ks, const std::vector<float>& chi, long long N, int d,
+                          std::vector<double>& At, std::vector<int>& rowperm, std::vector<double>* target_out) {
+    for (float v : ks)
+        if (!std::isfinite(v)) return fail(ISK_ESINGULAR, isk_status_string(ISK_ESINGULAR));
+    std::vector<double> X(ks.begin(), ks.end());           // X = Float64.(ks')  (N x d)
+    std::vector<int> ind;
+    if (e->cfg.isa_whitening) {
+        std::vector<double> C(d * d, 0.0);
+        for (long long n = 0; n < N; ++n)
+            for (int i = 0; i < d; ++i)
+                for (int j = 0; j < d; ++j) C[i * d + j] += X[n * d + i] * X[n * d + j];
+        for (auto& v : C) v /= (double)N;
+        if (!inv_sqrt_sym(C, d)) return fail(ISK_ESINGULAR, isk_status_string(ISK_ESINGULAR));
+        std::vector<double> XW((size_t)N * d);
+        for (long long n = 0; n < N; ++n)
+            for (int j = 0; j < d; ++j) {
+                double s = 0;
+                for (int k = 0; k < d; ++k) s += X[n * d + k] * C[k * d + j];
+                XW[n * d + j] = s;
+            }
+        ind = indexmap_host(XW, N, d);
+    } else {
+        ind = indexmap_host(X, N, d);
+    }
+    std::vector<double> A(d * d);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) A[i * d + j] = X[(long long)ind[i] * d + j];
+    if (!invert_host(A, d)) return fail(ISK_ESINGULAR, isk_status_string(ISK_ESINGULAR));
+    // target = A' * ks  ->  target[n][a] = sum_b A[b][a] ks[n][b]
+    At.assign(d * d, 0.0);
+    for (int a = 0; a < d; ++a)
+        for (int b = 0; b < d; ++b) At[a * d + b] = A[b * d + a];
+    rowperm.resize(d);
+    std::iota(rowperm.begin(), rowperm.end(), 0);
+    std::vector<double> tgt((size_t)N * d);
+    for (long long n = 0; n < N; ++n)
+        for (int a = 0; a < d; ++a) {
+            double s = 0;
+            for (int b = 0; b < d; ++b) s += At[a * d + b] * X[n * d + b];
+            tgt[n * d + a] = s;
+        }
+    if (e->cfg.isa_permute) {
+        // fixperm (src/isotarget.jl:120-127): cost(p) = sum_i sum_n |new[p_i, n] - old[i, n]|
+        std::vector<double> Cst(d * d, 0.0);
+        for (long long n = 0; n < N; ++n)
+            for (int a = 0; a < d; ++a)
+                for (int i = 0; i < d; ++i) Cst[a * d + i] += std::fabs(tgt[n * d + a] - (double)chi[n * d + i]);
+        std::vector<int> p(d), best(d);
+        std::iota(p.begin(), p.end(), 0);
+        double bc = INFINITY;
+        bool first = true;
+        do {
+            double c = 0;
+            for (int i = 0; i < d; ++i) c += Cst[p[i] * d + i];
+            if (first || c < bc) { bc = c; best = p; first = false; }
+        } while (std::next_permutation(p.begin(), p.end()));
+        rowperm = best;
+    }
+    if (target_out) {
+        target_out->resize((size_t)N * d);
+        for (long long n = 0; n < N; ++n)
+            for (int i = 0; i < d; ++i) (*target_out)[n * d + i] = tgt[n * d + rowperm[i]];
+    }
+    return ISK_OK;
+}
+
+// loss weights 1 ./ std(target, dims=2) (corrected), src/iso.jl:183
+static void loss_weights_host(const std::vector<float>& tgt, long long N, int d, std::vector<float>& w) {
+    w.assign(d, 1.0f);
+    if (d <= 1) return;
+    for (int i = 0; i < d; ++i) {
+        double mean = 0;
+        for (long long n = 0; n < N; ++n) mean += tgt[n * d + i];
+        mean /= (double)N;
+        double ss = 0;
+        for (long long n = 0; n < N; ++n) { const double t = tgt[n * d + i] - mean; ss += t * t; }
+        w[i] = (float)(1.0 / std::sqrt(ss / (double)(N - 1)));
+    }
+}
+
+static int check_status(isk_engine* e) {
+    int st = 0;
+    HIPCHK(hipMemcpyAsync(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (st & 1) {
+        HIPCHK(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
+        return fail(ISK_ECONSTANT_CHI, isk_status_string(ISK_ECONSTANT_CHI));
+    }
+    return ISK_OK;
+}
+
+// computes the target on the device-resident data; leaves target + loss weights on the device
+static int compute_target(isk_engine* e, bool check) {
+    const int d = e->nout;
+    if (e->cfg.target_kind == ISK_TARGET_SHIFTSCALE) {
+        CHK(forward_resident(e, 1));
+        ScopedTimer t(e, ISK_T_TARGET);
+        launch_kmean(e);
+        isk_launch_minmax(e->d_ks, e->N, e->d_mm, e->stream);
+        isk_launch_shiftscale(e->d_ks, e->d_mm, e->d_target, e->N, e->d_status, e->stream);
+        e->have_target = true;
+        if (check) CHK(check_status(e));
+        return ISK_OK;
+    }
+    // ISA: chi = model(xs), ks = E[model(ys)] in one launch over the contiguous slab
+    CHK(forward_resident(e, 3));
+    ScopedTimer t(e, ISK_T_TARGET);
+    launch_kmean(e);
+    std::vector<float> ks((size_t)e->N * d), chi((size_t)e->N * d);
+    HIPCHK(hipMemcpyAsync(ks.data(), e->d_ks, ks.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(chi.data(), e->d_out + e->N * e->K * d, chi.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    std::vector<double> At, tgt;
+    std::vector<int> rp;
+    CHK(isa_solve_host(e, ks, chi, e->N, d, At, rp, &tgt));
+    std::vector<float> tf(tgt.begin(), tgt.end()), w;      // T(target): back to Float32
+    loss_weights_host(tf, e->N, d, w);
+    HIPCHK(hipMemcpyAsync(e->d_target, tf.data(), tf.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_lossw, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));               // tf / w are stack-owned
+    e->have_target = true;
+    return ISK_OK;
+}
+
+extern "C" int isk_target(isk_engine* e, float* out) {
+    CHK(need_data(e));
+    CHK(compute_target(e, true));
+    if (out) {
+        HIPCHK(hipMemcpyAsync(out, e->d_target, (size_t)e->N * e->nout * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    HIPCHK(hipGetLastError());
+    return ISK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// training
+// ---------------------------------------------------------------------------------------
+static void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div) {
+    const TrainShape s = train_shape(e);
+    const TrainBuffers b = train_buffers(e);
+    isk_launch_train_fwd1(s, b, d_idx, B, e->stream);
+    isk_launch_train_tail(s, b, d_idx, B, inv_div, e->stream);
+    isk_launch_train_grad1(s, b, d_idx, B, 1, e->stream);
+}
+
+static void launch_opt(isk_engine* e, float gscale) {
+    OptArgs a;
+    a.theta = e->d_theta; a.grad = e->d_grad; a.m = e->d_m; a.v = e->d_v; a.n = e->nparams;
+    a.kind = e->cfg.opt_kind; a.lr = e->cfg.lr; a.reg = e->cfg.reg; a.beta1 = e->cfg.beta1; a.beta2 = e->cfg.beta2;
+    a.eps = e->cfg.opt_eps; a.rho = e->cfg.rho;
+    a.bc1 = (float)(1.0 - e->bt1); a.bc2 = (float)(1.0 - e->bt2);
+    a.gscale = gscale; a.loss_acc = e->d_loss_acc;
+    isk_launch_opt_step(a, e->stream);
+    e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2;
+    launch_fold(e);
+}
+
+static int upload_target(isk_engine* e, const float* target) {
+    HIPCHK(hipMemcpyAsync(e->d_target, target, (size_t)e->N * e->nout * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    std::vector<float> tf(target, target + (size_t)e->N * e->nout), w;
+    loss_weights_host(tf, e->N, e->nout, w);
+    HIPCHK(hipMemcpyAsync(e->d_lossw, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->have_target = true;
+    return ISK_OK;
+}
+
+// one epoch on the device-resident target; perm on host or nullptr (engine shuffle)
+static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, double* loss) {
+    const long long N = e->N;
+    const int mb = minibatch < 0 ? e->cfg.minibatch : minibatch;
+    const long long bs = (mb == 0 || N < mb) ? N : mb;          // src/iso.jl:180
+    const long long nb = N / bs;                                 // partial=false drops the tail
+    std::vector<int32_t> p;
+    if (perm) {
+        for (long long i = 0; i < N; ++i)
+            if (perm[i] < 0 || perm[i] >= N) return fail(ISK_EINVAL, "permutation entry out of range");
+    } else {
+        p.resize(N);
+        shuffle_perm(e, p);
+        perm = p.data();
+    }
+    HIPCHK(hipMemcpyAsync(e->d_perm, perm, (size_t)N * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(e->d_loss_acc, 0, 2 * sizeof(double), e->stream));
+    {
+        ScopedTimer t(e, ISK_T_TRAIN);
+        for (long long b = 0; b < nb; ++b) {
+            launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs);
+            launch_opt(e, 1.0f);
+        }
+    }
+    double acc[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(acc, e->d_loss_acc, sizeof(acc), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));                     // also keeps `p` alive until the copy is done
+    HIPCHK(hipGetLastError());
+    if (acc[1] != 0.0) return fail(ISK_ECOLLAPSED, isk_status_string(ISK_ECOLLAPSED));
+    if (loss) *loss = acc[0] / (double)N;                        // src/iso.jl:193
+    return ISK_OK;
+}
+
+extern "C" int isk_train_batch(isk_engine* e, const float* target, int32_t minibatch, const int32_t* perm, double* loss) {
+    CHK(need_data(e));
+    if (target) CHK(upload_target(e, target));
+    if (!e->have_target) return fail(ISK_ESTATE, "no target: pass one or call isk_target first");
+    return train_epoch(e, minibatch, perm, loss);
+}
+
+extern "C" int isk_batch_grads(isk_engine* e, const float* target, const int32_t* idx, int32_t nidx, float* grads, double* loss) {
+    CHK(need_data(e));
+    if (!idx || !grads || nidx < 1 || nidx > e->N) return fail(ISK_EINVAL, "bad batch");
+    for (int i = 0; i < nidx; ++i)
+        if (idx[i] < 0 || idx[i] >= e->N) return fail(ISK_EINVAL, "batch index out of range");
+    if (target) CHK(upload_target(e, target));
+    if (!e->have_target) return fail(ISK_ESTATE, "no target: pass one or call isk_target first");
+    HIPCHK(hipMemcpyAsync(e->d_perm, idx, (size_t)nidx * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    launch_grads(e, e->d_perm, nidx, 1.0f / (float)nidx);
+    std::vector<float> g((size_t)e->nparams + 1);
+    HIPCHK(hipMemcpyAsync(g.data(), e->d_grad, g.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    std::memcpy(grads, g.data(), (size_t)e->nparams * sizeof(float));
+    if (loss) *loss = (double)g[e->nparams];
+    return ISK_OK;
+}
+
+extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* perms, double* losses) {
+    CHK(need_data(e));
+    if (n < 0 || epochs < 0) return fail(ISK_EINVAL, "negative iteration count");
+    long long k = 0;
+    for (int it = 0; it < n; ++it) {
+        if (e->cfg.featurize_every_iteration) featurize_resident(e);
+        // the constant-chi check needs the device status word; it is read together with the loss
+        CHK(compute_target(e, false));
+        for (int ep = 0; ep < epochs; ++ep) {
+            double l = 0;
+            const int32_t* p = perms ? perms + k * e->N : nullptr;
+            int r = train_epoch(e, -1, p, &l);
+            if (e->cfg.target_kind == ISK_TARGET_SHIFTSCALE) {
+                int st = 0;
+                HIPCHK(hipMemcpy(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
+                if (st & 1) {
+                    HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
+                    return fail(ISK_ECONSTANT_CHI, isk_status_string(ISK_ECONSTANT_CHI));
+                }
+            }
+            if (r != ISK_OK) return r;
+            if (losses) losses[k] = l;
+            ++k;
+        }
+        if (epochs == 0 && e->cfg.target_kind == ISK_TARGET_SHIFTSCALE) CHK(check_status(e));
+    }
+    return ISK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// data-parallel hooks
+// ---------------------------------------------------------------------------------------
+extern "C" int isk_dp_koopman_local(isk_engine* e) {
+    CHK(need_data(e));
+    if (e->cfg.featurize_every_iteration) featurize_resident(e);
+    CHK(forward_resident(e, e->cfg.target_kind == ISK_TARGET_ISA ? 3 : 1));
+    ScopedTimer t(e, ISK_T_TARGET);
+    launch_kmean(e);
+    return ISK_OK;
+}
+
+extern "C" int isk_dp_minmax_local(isk_engine* e, float mm[2]) {
+    CHK(need_data(e));
+    if (!e->have_ks) return fail(ISK_ESTATE, "call isk_dp_koopman_local first");
+    isk_launch_minmax(e->d_ks, e->N * e->nout, e->d_mm, e->stream);
+    HIPCHK(hipMemcpyAsync(mm, e->d_mm, 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return ISK_OK;
+}
+
+extern "C" int isk_dp_shiftscale_apply(isk_engine* e, float gmin, float gmax) {
+    CHK(need_data(e));
+    if (!e->have_ks) return fail(ISK_ESTATE, "call isk_dp_koopman_local first");
+    if (!(gmax > gmin)) return fail(ISK_ECONSTANT_CHI, isk_status_string(ISK_ECONSTANT_CHI));
+    const float mm[2] = {gmin, gmax};
+    HIPCHK(hipMemcpyAsync(e->d_mm, mm, sizeof(mm), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    isk_launch_shiftscale(e->d_ks, e->d_mm, e->d_target, e->N, e->d_status, e->stream);
+    e->have_target = true;
+    return ISK_OK;
+}
+
+extern "C" int isk_dp_get_ks_chi(isk_engine* e, float* ks, float* chi) {
+    CHK(need_data(e));
+    if (!e->have_ks) return fail(ISK_ESTATE, "call isk_dp_koopman_local first");
+    const size_t nb = (size_t)e->N * e->nout * sizeof(float);
+    if (ks) HIPCHK(hipMemcpyAsync(ks, e->d_ks, nb, hipMemcpyDeviceToHost, e->stream));
+    if (chi) HIPCHK(hipMemcpyAsync(chi, e->d_out + e->N * e->K * e->nout, nb, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return ISK_OK;
+}
+
+extern "C" int isk_dp_isa_apply(isk_engine* e, const double* At, const int32_t* rowperm) {
+    CHK(need_data(e));
+    if (!e->have_ks || !At || !rowperm) return fail(ISK_ESTATE, "call isk_dp_koopman_local first / null argument");
+    const int d = e->nout;
+    std::vector<float> Af(d * d);
+    for (int i = 0; i < d * d; ++i) Af[i] = (float)At[i];
+    HIPCHK(hipMemcpyAsync(e->d_At, Af.data(), Af.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_rowperm, rowperm, d * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    isk_launch_isa_apply(e->d_ks, e->d_At, e->d_rowperm, e->d_target, e->N, d, e->stream);
+    e->have_target = true;
+    return ISK_OK;
+}
+
+extern "C" int isk_dp_set_loss_weights(isk_engine* e, const float* w) {
+    if (!e || !w) return fail(ISK_EINVAL, "null argument");
+    HIPCHK(hipMemcpyAsync(e->d_lossw, w, (size_t)e->nout * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return ISK_OK;
+}
+
+extern "C" int isk_dp_grad_buffer(isk_engine* e, void** buf, int64_t* n) {
+    if (!e || !buf || !n) return fail(ISK_EINVAL, "null argument");
+    *buf = e->d_grad;
+    *n = e->nparams + 1;
+    return ISK_OK;
+}
+
+extern "C" int isk_dp_local_grads(isk_engine* e, const int32_t* idx, int32_t nidx, int64_t global_batch) {
+    CHK(need_data(e));
+    if (!e->have_target) return fail(ISK_ESTATE, "no target");
+    if (!idx || nidx < 1 || nidx > e->N || global_batch < nidx) return fail(ISK_EINVAL, "bad batch");
+    for (int i = 0; i < nidx; ++i)
+        if (idx[i] < 0 || idx[i] >= e->N) return fail(ISK_EINVAL, "batch index out of range");
+    HIPCHK(hipMemcpyAsync(e->d_perm, idx, (size_t)nidx * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));                 // idx is caller-owned
+    launch_grads(e, e->d_perm, nidx, 1.0f / (float)global_batch);
+    return ISK_OK;
+}
+
+extern "C" int isk_dp_apply(isk_engine* e, double* batch_loss) {
+    CHK(need_data(e));
+    HIPCHK(hipMemsetAsync(e->d_loss_acc, 0, 2 * sizeof(double), e->stream));
+    launch_opt(e, 1.0f);
+    double acc[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(acc, e->d_loss_acc, sizeof(acc), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (acc[1] != 0.0) return fail(ISK_ECOLLAPSED, isk_status_string(ISK_ECOLLAPSED));
+    if (batch_loss) *batch_loss = acc[0];
+    return ISK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// instrumentation
+// ---------------------------------------------------------------------------------------
+extern "C" int isk_timers_enable(isk_engine* e, int32_t on) {
+    if (!e) return fail(ISK_EINVAL, "null engine");
+    e->timers_on = on != 0;
+    return ISK_OK;
+}
+extern "C" int isk_timers_read(isk_engine* e, double total_ms[ISK_T_COUNT], int64_t count[ISK_T_COUNT]) {
+    if (!e) return fail(ISK_EINVAL, "null engine");
+    drain_timers(e);
+    for (int i = 0; i < ISK_T_COUNT; ++i) { if (total_ms) total_ms[i] = e->t_ms[i]; if (count) count[i] = e->t_cnt[i]; }
+    return ISK_OK;
+}
+extern "C" int isk_timers_reset(isk_engine* e) {
+    if (!e) return fail(ISK_EINVAL, "null engine");
+    drain_timers(e);
+    for (int i = 0; i < ISK_T_COUNT; ++i) { e->t_ms[i] = 0; e->t_cnt[i] = 0; }
+    return ISK_OK;
+}

@@ -1,0 +1,119 @@
+// Internal declarations shared by the HIP kernels and the host engine.
+// gfx950 (MI355X) only: wave64, v_mfma_f32_16x16x4_f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/isokann_hip.h"
+
+#define ISK_TILE 16          // MFMA 16x16x4 tile edge; every width is padded to a multiple
+#define ISK_MAX_NT 10        // layer-1 output tiles the fused forward kernel keeps in registers (H1 <= 160)
+#define ISK_NUM_CU 256
+
+static inline int isk_pad16(int x) { return (x + 15) & ~15; }
+
+// ---------------------------------------------------------------- featurize -------
+// coords/features rows -> (optionally LayerNorm-standardised) zero-padded feature rows
+struct FeatArgs {
+    const float* in;        // [S][D]   (D = 3*n_atoms for pdist, = F for identity)
+    const int2*  pairs;     // [F] 0-based atom pairs (pdist) or nullptr (identity)
+    float* xhat;            // [S][Fp]
+    long long S;
+    int D, F, Fp;
+    int normalize;          // 1: (x-mu)*rstd, Flux normalise over the feature axis
+    int ln_mode;            // isk_ln_mode
+    float eps;
+};
+void isk_launch_featurize(const FeatArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------- forward ---------
+// Weight layout "fragment-linear": for layer with Kp inputs (multiple of 16) and Np outputs
+// (multiple of 16):  Wt[((c*(Np/16) + t)*64 + lane)*4 + j] = W[o = t*16 + (lane&15)][k = c*16 + 4*(lane>>4) + j]
+// i.e. exactly the B operand of 4 consecutive v_mfma_f32_16x16x4_f32 for k-chunk c and output tile t,
+// so one coalesced 1 KiB dwordx4 load per wave fetches it.
+struct TailLayer {
+    const float* Wt;        // fragment-linear, [kchunks][ntiles][64][4]
+    const float* bias;      // [ntiles*16], zero padded
+    int kchunks, ntiles, act, width;
+};
+struct MlpFwdArgs {
+    const float* X;         // [S][Fp] standardised features (row-major, zero padded)
+    const int*   rows;      // optional gather: logical row r reads X[rows[r]] (nullptr = identity)
+    long long S;
+    int Fp, nchunks;        // nchunks = Fp/16
+    const float* W1t;       // fragment-linear layer-1 weights with LayerNorm scale folded in
+    const float* bias1;     // [NT*16] layer-1 bias with W1*ln_bias folded in
+    int act1, H1, nt1;
+    int ntail;
+    TailLayer tail[ISK_MAX_LAYERS];
+    float* out;             // [S][nout]
+    int nout;
+    int stride_a, stride_b; // floats per row of the two per-wave LDS ping-pong buffers (padded width + 4)
+};
+int  isk_launch_mlp_fwd(const MlpFwdArgs& a, hipStream_t st);   // returns 0 or ISK_EUNSUPPORTED
+
+// parameter "fold": flat Flux-order theta -> fragment-linear weights and folded bias
+struct FoldArgs {
+    const float* theta;
+    int nlayers;
+    int widths[ISK_MAX_LAYERS + 1];
+    long long off_lns, off_lnb;           // offsets in theta, -1 if no LayerNorm
+    long long off_W[ISK_MAX_LAYERS], off_b[ISK_MAX_LAYERS];
+    float* Wt[ISK_MAX_LAYERS];            // fragment-linear per layer
+    float* bias[ISK_MAX_LAYERS];          // padded per layer (layer 0: folded)
+};
+void isk_launch_fold(const FoldArgs& a, hipStream_t st);
+
+// K-mean  (expectation, src/isotarget.jl:18) + min/max for shift-scale
+struct KmeanArgs {
+    const float* out_ys;    // [N*K][nout]
+    float* ks;              // [N][nout]
+    long long N; int K, nout;
+};
+void isk_launch_kmean(const KmeanArgs& a, hipStream_t st);
+void isk_launch_minmax(const float* v, long long n, float* mm /*[2] device*/, hipStream_t st);
+// target = (ks - min)/(max - min); status[0] |= 1 if !(max > min)
+void isk_launch_shiftscale(const float* ks, const float* mm, float* target, long long n, int* status, hipStream_t st);
+// target[n][a] = sum_b At[a][b]*ks[n][b] rows permuted: target[n][i] = (At ks)[rowperm[i]]
+void isk_launch_isa_apply(const float* ks, const float* At /*[d*d] device, row-major At[a][b]*/, const int* rowperm,
+                          float* target, long long N, int d, hipStream_t st);
+
+// ---------------------------------------------------------------- training --------
+struct TrainShape {
+    int nlayers;
+    int widths[ISK_MAX_LAYERS + 1];
+    int act, lastact;
+    int layernorm;
+    long long off_lns, off_lnb;
+    long long off_W[ISK_MAX_LAYERS], off_b[ISK_MAX_LAYERS];
+    long long nparams;
+};
+struct TrainBuffers {
+    const float* xhat_xs;   // [N][Fp]
+    const float* target;    // [N][nout]
+    const float* lossw;     // [nout]
+    const float* theta;     // flat params
+    const float* W1t;       // folded layer-1 weights (fragment-linear)
+    const float* bias1;     // folded layer-1 bias
+    float* a1;              // [Bpad][H1p]     layer-1 activations of the batch
+    float* delta1;          // [Bpad][H1p]     dL/dz1
+    float* part;            // per-workgroup partial sums from the tail kernel
+    float* grad;            // flat gradient [nparams] + [loss, nonfinite]
+    double* loss_acc;       // [2]: epoch loss sum (double), collapsed flag (as double)
+    int Fp;
+};
+// batch rows are perm[first .. first+B)
+void isk_launch_train_fwd1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, hipStream_t st);
+void isk_launch_train_tail(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div, hipStream_t st);
+void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int accumulate_loss, hipStream_t st);
+int  isk_train_tail_nblocks(int B);
+long long isk_train_part_floats(const TrainShape& s, int maxB);
+
+struct OptArgs {
+    float* theta; const float* grad; float* m; float* v;
+    long long n;
+    int kind; float lr, reg, beta1, beta2, eps, rho;
+    float bc1, bc2;         // 1 - beta1^t, 1 - beta2^t for this step
+    float gscale;           // gradient multiplier (1, or 1/global_batch in data-parallel mode)
+    const double* loss_acc; // collapsed flag at [1]: skip the update when set (src/iso.jl:186-189 throws before update!)
+};
+void isk_launch_opt_step(const OptArgs& a, hipStream_t st);

@@ -1,0 +1,472 @@
+// Forward-path kernels for gfx950 (MI355X): featurizer (pdist + LayerNorm standardisation),
+// parameter fold, fused MLP forward (f32 MFMA), K-mean, min/max, shift-scale, ISA apply.
+//
+// Reference semantics restated (files relative to the reference repo):
+//   pdist            src/utils/pairdists.jl:109-127 (pdists), :6-24 (flatpairdists, halfinds order)
+//   LayerNorm/Dense  src/models.jl:87-92 (Flux.LayerNorm, Flux.Dense)
+//   K-mean           src/isotarget.jl:18 (expectation)
+//   shift-scale      src/isotarget.jl:36-42
+#include "isk_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ float act_apply(int act, float z) {
+    switch (act) {
+        case ISK_ACT_SIGMOID: {
+            // NNlib sigmoid_fast semantics: overflow-free 1/(1+exp(-z))
+            float e = __expf(-fabsf(z));
+            float r = 1.0f / (1.0f + e);
+            return z >= 0.f ? r : e * r;
+        }
+        case ISK_ACT_TANH: return tanhf(z);
+        case ISK_ACT_RELU: return fmaxf(z, 0.f);
+        case ISK_ACT_SWISH: {
+            float e = __expf(-fabsf(z));
+            float r = 1.0f / (1.0f + e);
+            return z * (z >= 0.f ? r : e * r);
+        }
+        default: return z;
+    }
+}
+
+// =====================================================================================
+// featurize: one wave per sample.  The sample's 3A coordinates are staged in LDS
+// (coalesced HBM read of the ys slab), every lane gathers its atom pairs from LDS,
+// the raw distances are stashed in LDS, the wave reduces mean / variance with
+// shuffles (two-pass variance, as Flux's var(mean=mu)), then writes the standardised,
+// zero-padded row with 16-B stores.
+// Algorithmic bytes per sample: 4*D read + 4*Fp written.  HBM-bound.
+// =====================================================================================
+template <bool PDIST>
+__global__ __launch_bounds__(256) void featurize_kernel(FeatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Dp = PDIST ? ((a.D + 3) & ~3) : 0;
+    float* coords = smem + wave * (Dp + a.Fp);
+    float* stash = coords + Dp;
+    const long long nw = (long long)gridDim.x * 4;
+    for (long long s0 = (long long)blockIdx.x * 4; s0 < a.S; s0 += nw) {
+        const long long s = s0 + wave;
+        const bool active = s < a.S;                 // wave-uniform
+        const float* row = a.in + (active ? s : 0) * (long long)a.D;
+        if (PDIST) {
+            if (active)
+                for (int i = lane; i < a.D; i += WAVE) coords[i] = row[i];
+        }
+        __syncthreads();
+        float sum = 0.f;
+        if (active) {
+            for (int f = lane; f < a.F; f += WAVE) {
+                float d;
+                if (PDIST) {
+                    const int2 p = a.pairs[f];
+                    const float dx = coords[3 * p.x] - coords[3 * p.y];
+                    const float dy = coords[3 * p.x + 1] - coords[3 * p.y + 1];
+                    const float dz = coords[3 * p.x + 2] - coords[3 * p.y + 2];
+                    d = sqrtf(dx * dx + dy * dy + dz * dz);
+                } else {
+                    d = row[f];
+                }
+                stash[f] = d;
+                sum += d;
+            }
+            for (int f = a.F + lane; f < a.Fp; f += WAVE) stash[f] = 0.f;
+        }
+        float mu = 0.f, rstd = 1.f;
+        if (a.normalize) {
+            mu = wave_sum(sum) / (float)a.F;
+            float ss = 0.f;
+            if (active)
+                for (int f = lane; f < a.F; f += WAVE) {
+                    const float t = stash[f] - mu;
+                    ss += t * t;
+                }
+            const float var = wave_sum(ss) / (float)a.F;
+            if (a.ln_mode == ISK_LN_VAR_EPS2) rstd = 1.0f / sqrtf(var + a.eps * a.eps);
+            else if (a.ln_mode == ISK_LN_STD_EPS) rstd = 1.0f / (sqrtf(var) + a.eps);
+            else rstd = 1.0f / sqrtf(var + a.eps);
+        }
+        __syncthreads();
+        if (active) {
+            float* orow = a.xhat + s * (long long)a.Fp;
+            for (int c = lane * 4; c < a.Fp; c += WAVE * 4) {
+                f32x4 v = *(const f32x4*)(stash + c);
+                if (a.normalize) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (c + j < a.F) ? (v[j] - mu) * rstd : 0.f;
+                }
+                *(f32x4*)(orow + c) = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void isk_launch_featurize(const FeatArgs& a, hipStream_t st) {
+    if (a.S <= 0) return;
+    const bool pd = a.pairs != nullptr;
+    const int Dp = pd ? ((a.D + 3) & ~3) : 0;
+    const size_t lds = (size_t)4 * (Dp + a.Fp) * sizeof(float);
+    long long blocks = (a.S + 3) / 4;
+    const long long cap = (long long)ISK_NUM_CU * 8;
+    if (blocks > cap) blocks = cap;
+    if (pd) hipLaunchKernelGGL(featurize_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(featurize_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, st, a);
+}
+
+// =====================================================================================
+// fold: theta (Flux order) -> fragment-linear weights, LayerNorm affine folded into layer 1:
+//   W1g[o][k] = W1[o][k]*g[k],   bias1[o] = b1[o] + sum_k W1[o][k]*beta[k]
+// so that  W1*(g.*xhat + beta) + b1 == W1g*xhat + bias1  and the forward kernel consumes the
+// standardised rows directly.
+// =====================================================================================
+__global__ __launch_bounds__(256) void fold_kernel(FoldArgs a) {
+    const int layer = blockIdx.y;
+    if (layer >= a.nlayers) return;
+    const int K = a.widths[layer], N = a.widths[layer + 1];
+    const int Kp = (K + 15) & ~15, Np = (N + 15) & ~15;
+    const int nt = Np / 16;
+    const float* W = a.theta + a.off_W[layer];
+    const float* b = a.theta + a.off_b[layer];
+    const bool ln = (layer == 0 && a.off_lns >= 0);
+    const float* g = ln ? a.theta + a.off_lns : nullptr;
+    const float* beta = ln ? a.theta + a.off_lnb : nullptr;
+    const long long total = (long long)Kp * Np;
+    float* Wt = a.Wt[layer];
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int j = e & 3;
+        const int lane = (e >> 2) & 63;
+        const long long ct = e >> 8;
+        const int t = (int)(ct % nt);
+        const int c = (int)(ct / nt);
+        const int o = t * 16 + (lane & 15);
+        const int k = c * 16 + 4 * (lane >> 4) + j;
+        float v = 0.f;
+        if (o < N && k < K) {
+            v = W[o + (long long)k * N];
+            if (ln) v *= g[k];
+        }
+        Wt[e] = v;
+    }
+    // bias: one wave per output row, waves strided over the whole grid.x
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int o = gw; o < Np; o += gridDim.x * 4) {
+        float v = 0.f;
+        if (o < N) {
+            if (ln) {
+                float s = 0.f;
+                for (int k = lane; k < K; k += WAVE) s += W[o + (long long)k * N] * beta[k];
+                s = wave_sum(s);
+                v = b[o] + s;
+            } else {
+                v = b[o];
+            }
+        }
+        if (lane == 0) a.bias[layer][o] = v;
+    }
+}
+
+void isk_launch_fold(const FoldArgs& a, hipStream_t st) {
+    int maxel = 0;
+    for (int l = 0; l < a.nlayers; ++l) {
+        int e = isk_pad16(a.widths[l]) * isk_pad16(a.widths[l + 1]);
+        if (e > maxel) maxel = e;
+    }
+    int bx = (maxel + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(fold_kernel, dim3(bx, a.nlayers), dim3(256), 0, st, a);
+}
+
+// =====================================================================================
+// Fused MLP forward.  One wave owns 16-row "units" of the sample matrix and ALL output
+// columns of layer 1; two units are processed per pass so every weight fragment feeds 8
+// MFMAs.  Operands go global -> VGPR directly in MFMA fragment shape:
+//   A (samples): lane (i = lane&15, q = lane>>4) loads 16 B = X[row i][16c + 4q .. +3]
+//   B (weights): lane loads 16 B of the fragment-linear image (coalesced 1 KiB per wave)
+// and MFMA step j of chunk c contracts k = 16c + 4q + j on both sides.  The f32 MFMA
+// (v_mfma_f32_16x16x4_f32, 256 FLOP/clk/CU) is slow enough that neither operand needs
+// LDS: X is private to the wave (read once from HBM), the layer-1 weights (<= 1 MB) stay
+// L2-resident.  The narrow tail layers run as MFMA over an LDS transpose buffer
+// (accumulator layout -> A-operand layout) inside the same kernel, so only nout floats
+// per sample are written.
+// Bound: f32 MFMA (2*Fp*H1p flop per sample vs 4*Fp bytes).
+// =====================================================================================
+template <int NT>
+struct Frags {
+    f32x4 w[NT];
+    f32x4 x0, x1;
+};
+
+template <int NT, bool TWO>
+__device__ __forceinline__ void load_frags(Frags<NT>& f, const f32x4* __restrict__ Wp, const float* __restrict__ x0,
+                                           const float* __restrict__ x1, int c) {
+    f.x0 = *(const f32x4*)(x0 + c * 16);
+    if (TWO) f.x1 = *(const f32x4*)(x1 + c * 16);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) f.w[t] = Wp[(long long)(c * NT + t) * 64];
+}
+
+template <int NT, bool TWO>
+__device__ __forceinline__ void mma_frags(const Frags<NT>& f, f32x4 (&acc0)[NT], f32x4 (&acc1)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x0[j], f.w[t][j], acc0[t], 0, 0, 0);
+            if (TWO) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x1[j], f.w[t][j], acc1[t], 0, 0, 0);
+        }
+    }
+}
+
+template <int NT, bool TWO>
+__device__ __forceinline__ void layer1_gemm(const MlpFwdArgs& a, const float* x0, const float* x1, int lane,
+                                            f32x4 (&acc0)[NT], f32x4 (&acc1)[NT]) {
+    const f32x4* Wp = (const f32x4*)a.W1t + lane;
+    const int nch = a.nchunks;
+    Frags<NT> fa, fb;
+    load_frags<NT, TWO>(fa, Wp, x0, x1, 0);
+    for (int c = 0; c < nch; c += 2) {
+        const int c1 = (c + 1 < nch) ? c + 1 : nch - 1;
+        load_frags<NT, TWO>(fb, Wp, x0, x1, c1);
+        mma_frags<NT, TWO>(fa, acc0, acc1);
+        const int c2 = (c + 2 < nch) ? c + 2 : nch - 1;
+        load_frags<NT, TWO>(fa, Wp, x0, x1, c2);
+        if (c + 1 < nch) mma_frags<NT, TWO>(fb, acc0, acc1);
+    }
+}
+
+// epilogue + tail layers for one 16-row unit whose layer-1 pre-activations sit in acc[NT]
+template <int NT>
+__device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT], long long row_base, float* scrA,
+                                          float* scrB, int lane) {
+    const int li = lane & 15, lq = lane >> 4;
+    int stride = a.stride_a;
+    if (a.ntail == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = t * 16 + li;
+            const float bcol = a.bias1[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long grow = row_base + lq * 4 + r;
+                if (col < a.nout && grow < a.S) a.out[grow * a.nout + col] = act_apply(a.act1, acc[t][r] + bcol);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = t * 16 + li;
+        const float bcol = a.bias1[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scrA[(lq * 4 + r) * stride + col] = act_apply(a.act1, acc[t][r] + bcol);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* in = scrA;
+    float* ob = scrB;
+    int ostride = a.stride_b;
+    for (int l = 0; l < a.ntail; ++l) {
+        const TailLayer L = a.tail[l];
+        const bool last = (l == a.ntail - 1);
+        const f32x4* Wp = (const f32x4*)L.Wt + lane;
+        for (int t2 = 0; t2 < L.ntiles; ++t2) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < L.kchunks; ++c) {
+                const f32x4 xa = *(const f32x4*)(in + li * stride + c * 16 + lq * 4);
+                const f32x4 wf = Wp[(long long)(c * L.ntiles + t2) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], wf[j], z, 0, 0, 0);
+            }
+            const int col = t2 * 16 + li;
+            const float bcol = L.bias[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = act_apply(L.act, z[r] + bcol);
+                if (last) {
+                    const long long grow = row_base + lq * 4 + r;
+                    if (col < a.nout && grow < a.S) a.out[grow * a.nout + col] = v;
+                } else {
+                    ob[(lq * 4 + r) * ostride + col] = v;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        float* tmp = in; in = ob; ob = tmp;
+        const int ts = stride; stride = ostride; ostride = ts;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a, long long units, long long units_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    float* scrA = smem + (size_t)wave * 16 * (a.stride_a + a.stride_b);
+    float* scrB = scrA + 16 * a.stride_a;
+    const long long gw = (long long)blockIdx.x * 4 + wave;
+    long long u = gw * units_per_wave;
+    long long uend = u + units_per_wave;
+    if (uend > units) uend = units;
+    for (; u < uend; u += 2) {
+        const bool two = (u + 1 < uend);            // wave-uniform
+        long long r0 = u * 16 + li, r1 = r0 + 16;
+        if (r0 > a.S - 1) r0 = a.S - 1;
+        if (r1 > a.S - 1) r1 = a.S - 1;
+        if (a.rows) { r0 = a.rows[r0]; r1 = a.rows[r1]; }
+        const float* x0 = a.X + r0 * (long long)a.Fp + lq * 4;
+        const float* x1 = a.X + r1 * (long long)a.Fp + lq * 4;
+        f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        if (two) layer1_gemm<NT, true>(a, x0, x1, lane, acc0, acc1);
+        else layer1_gemm<NT, false>(a, x0, x1, lane, acc0, acc1);
+        unit_tail<NT>(a, acc0, u * 16, scrA, scrB, lane);
+        if (two) unit_tail<NT>(a, acc1, (u + 1) * 16, scrA, scrB, lane);
+    }
+}
+
+template <int NT>
+static void launch_fwd_nt(const MlpFwdArgs& a, hipStream_t st) {
+    const long long units = (a.S + 15) / 16;
+    const long long waves_max = (long long)ISK_NUM_CU * 4;
+    long long upw = (units + waves_max - 1) / waves_max;     // units per wave
+    if (upw < 1) upw = 1;
+    const long long nwaves = (units + upw - 1) / upw;
+    const long long blocks = (nwaves + 3) / 4;
+    const size_t lds = (size_t)4 * 16 * (a.stride_a + a.stride_b) * sizeof(float);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(mlp_fwd_kernel<NT>, dim3((unsigned)blocks), dim3(256), lds, st, a, units, upw);
+}
+
+int isk_launch_mlp_fwd(const MlpFwdArgs& a, hipStream_t st) {
+    if (a.S <= 0) return 0;
+    switch (a.nt1) {
+        case 1: launch_fwd_nt<1>(a, st); break;
+        case 2: launch_fwd_nt<2>(a, st); break;
+        case 3: launch_fwd_nt<3>(a, st); break;
+        case 4: launch_fwd_nt<4>(a, st); break;
+        case 5: launch_fwd_nt<5>(a, st); break;
+        case 6: launch_fwd_nt<6>(a, st); break;
+        case 7: launch_fwd_nt<7>(a, st); break;
+        case 8: launch_fwd_nt<8>(a, st); break;
+        case 9: launch_fwd_nt<9>(a, st); break;
+        case 10: launch_fwd_nt<10>(a, st); break;
+        default: return ISK_EUNSUPPORTED;
+    }
+    return 0;
+}
+
+// =====================================================================================
+// K-mean: ks[n][o] = (sum_k out[n*K + k][o]) / K      (expectation, src/isotarget.jl:18)
+// One wave per start point; lanes stride over the K*nout contiguous outputs of that
+// start, then a shuffle reduction combines lanes that hold the same output index o.
+// =====================================================================================
+__global__ __launch_bounds__(256) void kmean_kernel(KmeanArgs a) {
+    const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= a.N) return;
+    const float* base = a.out_ys + n * (long long)a.K * a.nout;
+    const int tot = a.K * a.nout;
+    if (a.nout <= 64 && (64 % a.nout) == 0) {
+        // lane l always sees output index l % nout (stride 64 is a multiple of nout)
+        float s = 0.f;
+        for (int i = lane; i < tot; i += WAVE) s += base[i];
+        for (int o = 32; o >= a.nout; o >>= 1) s += __shfl_xor(s, o, WAVE);
+        if (lane < a.nout) a.ks[n * a.nout + lane] = s / (float)a.K;
+    } else {
+        for (int o = lane; o < a.nout; o += WAVE) {
+            float s = 0.f;
+            for (int k = 0; k < a.K; ++k) s += base[k * a.nout + o];
+            a.ks[n * a.nout + o] = s / (float)a.K;
+        }
+    }
+}
+
+void isk_launch_kmean(const KmeanArgs& a, hipStream_t st) {
+    if (a.N <= 0) return;
+    hipLaunchKernelGGL(kmean_kernel, dim3((unsigned)((a.N + 3) / 4)), dim3(256), 0, st, a);
+}
+
+// min / max over n values: single workgroup, wavefront shuffles + one LDS exchange
+__global__ __launch_bounds__(1024) void minmax_kernel(const float* v, long long n, float* mm) {
+    __shared__ float smin[16], smax[16];
+    float lo = INFINITY, hi = -INFINITY;
+    bool nan = false;
+    for (long long i = threadIdx.x; i < n; i += 1024) {
+        const float x = v[i];
+        nan |= (x != x);
+        lo = fminf(lo, x);
+        hi = fmaxf(hi, x);
+    }
+    if (nan) { lo = NAN; hi = NAN; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float l2 = __shfl_xor(lo, o, WAVE), h2 = __shfl_xor(hi, o, WAVE);
+        lo = (lo != lo || l2 != l2) ? NAN : fminf(lo, l2);
+        hi = (hi != hi || h2 != h2) ? NAN : fmaxf(hi, h2);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smin[w] = lo; smax[w] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) {
+            lo = (lo != lo || smin[i] != smin[i]) ? NAN : fminf(lo, smin[i]);
+            hi = (hi != hi || smax[i] != smax[i]) ? NAN : fmaxf(hi, smax[i]);
+        }
+        mm[0] = lo;
+        mm[1] = hi;
+    }
+}
+
+void isk_launch_minmax(const float* v, long long n, float* mm, hipStream_t st) {
+    hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(1024), 0, st, v, n, mm);
+}
+
+__global__ __launch_bounds__(256) void shiftscale_kernel(const float* ks, const float* mm, float* target, long long n,
+                                                         int* status) {
+    const float lo = mm[0], hi = mm[1];
+    const bool ok = hi > lo;                       // false for NaN too (src/isotarget.jl:39)
+    if (!ok && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(status, 1);
+    const float inv = hi - lo;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        target[i] = (ks[i] - lo) / inv;
+}
+
+void isk_launch_shiftscale(const float* ks, const float* mm, float* target, long long n, int* status, hipStream_t st) {
+    long long b = (n + 255) / 256;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(shiftscale_kernel, dim3((unsigned)b), dim3(256), 0, st, ks, mm, target, n, status);
+}
+
+__global__ __launch_bounds__(256) void isa_apply_kernel(const float* ks, const float* At, const int* rowperm, float* target,
+                                                        long long N, int d) {
+    const long long tot = N * d;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+        const long long n = e / d;
+        const int i = (int)(e % d);
+        const int a = rowperm[i];
+        float s = 0.f;
+        for (int b = 0; b < d; ++b) s += At[a * d + b] * ks[n * d + b];
+        target[e] = s;
+    }
+}
+
+void isk_launch_isa_apply(const float* ks, const float* At, const int* rowperm, float* target, long long N, int d,
+                          hipStream_t st) {
+    long long b = (N * d + 255) / 256;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(isa_apply_kernel, dim3((unsigned)b), dim3(256), 0, st, ks, At, rowperm, target, N, d);
+}

@@ -1,0 +1,89 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol that
+include/isokann_hip.h declares, struct layout is what the C side sees, host-side logic of
+the reference-interface mirror, and the product path fails loudly without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.capi.load()
+    hdr = open(os.path.join(ROOT, "include", "isokann_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(isk_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(pkg.capi.PROTOTYPES), declared ^ set(pkg.capi.PROTOTYPES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.isk_abi_version() == pkg.capi.ISK_ABI_VERSION
+
+
+def test_config_layout_and_reference_defaults(pkg):
+    lib = pkg.capi.load()
+    cfg = pkg.capi.Config()
+    C.memset(C.byref(cfg), 0xFF, C.sizeof(cfg))
+    lib.isk_config_default(C.byref(cfg))
+    assert cfg.abi_version == 1 and cfg.device == 0 and cfg.n_layers == 0
+    assert cfg.activation == pkg.capi.ACT["sigmoid"] and cfg.lastactivation == pkg.capi.ACT["identity"]   # src/models.jl:65
+    assert cfg.layernorm == 1 and cfg.ln_mode == 0 and cfg.ln_eps == pytest.approx(1e-5)
+    assert cfg.opt_kind == pkg.capi.OPT["nesterov"]                                                       # src/iso.jl:18
+    assert cfg.lr == pytest.approx(1e-3) and cfg.reg == pytest.approx(1e-4) and cfg.rho == pytest.approx(0.9)
+    assert cfg.beta1 == pytest.approx(0.9) and cfg.beta2 == pytest.approx(0.999) and cfg.opt_eps == pytest.approx(1e-8)
+    assert cfg.minibatch == 100 and cfg.isa_permute == 1 and cfg.isa_whitening == 0                       # src/iso.jl:10
+    assert cfg.seed == 0 and not cfg.pairs
+
+
+def test_status_strings_name_the_reference_domain_errors(pkg):
+    lib = pkg.capi.load()
+    assert b"chi function is constant" in lib.isk_status_string(pkg.capi.ECONSTANT_CHI)
+    assert b"collapsed under training" in lib.isk_status_string(pkg.capi.ECOLLAPSED)
+    assert b"simplex transformation" in lib.isk_status_string(pkg.capi.ESINGULAR)
+
+
+def test_product_path_fails_loudly_without_a_device(pkg):
+    if pkg.capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    xs = np.random.default_rng(0).normal(size=(4, 8))
+    ys = np.random.default_rng(1).normal(size=(4, 2, 8))
+    with pytest.raises(pkg.IskError):
+        pkg.Iso(pkg.SimulationData(xs, ys))
+
+
+def test_missing_library_is_an_error_not_a_fallback(pkg, monkeypatch):
+    monkeypatch.setattr(pkg.capi, "_lib", None)
+    monkeypatch.setattr(pkg.capi, "LIB_PATH", "/nonexistent/libisokann_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.capi.load()
+
+
+def test_host_mirror_shapes_and_defaults(pkg):
+    assert pkg.pairnet_widths(2) == [2, 2, 1, 1]
+    assert pkg.pairnet_widths(231) == [231, 38, 6, 1]
+    assert pkg.pairnet_widths(1700, nout=3) == [1700, 142, 12, 3]
+    assert pkg.halfinds(4) == [(0, 1), (0, 2), (1, 2), (0, 3), (1, 3), (2, 3)]
+    m = pkg.pairnet(n=231)
+    assert m.layernorm and m.activation == "sigmoid" and m.lastactivation == "identity"
+    assert m.nparams() == 9519 and m.params.shape == (9519,)
+    assert pkg.pairnet(n=1700, nout=3).nparams() == 246697
+    assert not pkg.densenet([5, 3, 1]).layernorm                             # src/models.jl:87 default
+    assert pkg.NesterovRegularized().kind == "nesterov" and pkg.AdamRegularized(1e-4, 1e-5).lr == 1e-4
+    fa = pkg.FeaturesAtoms([4, 1, 7])
+    assert fa.pairs(10) == [(4, 1), (4, 7), (1, 7)] and fa.featuredim(30) == 3
+    assert pkg.FeaturesAll().featuredim(66) == 231
+
+    xs = np.arange(12.0).reshape(6, 2)
+    ys = np.arange(36.0).reshape(6, 3, 2)
+    d = pkg.SimulationData(xs, ys, pkg.FeaturesAll())
+    assert len(d) == 2 and d.nk == 3 and pkg.featuredim(d) == 1
+    assert d.coords[0].dtype == np.float32 and d.coords[0].flags.f_contiguous and d.coords[1].flags.f_contiguous
+    sub = d[1:2]
+    assert len(sub) == 1 and np.array_equal(sub.coords[1][:, :, 0], ys[:, :, 1].astype(np.float32))
+    with pytest.raises(ValueError):
+        pkg.SimulationData(xs, ys[:, :, :1])
+    with pytest.raises(ValueError):
+        pkg.SimulationData(xs[:5], ys[:5], pkg.FeaturesAll())

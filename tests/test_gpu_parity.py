@@ -1,0 +1,326 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the CPU
+oracle on the same seeded inputs, and against the committed golden vectors.
+
+Tolerances (fp32 path vs the fp64 oracle), per BASELINE.json north_star / SURVEY 8d:
+  features      rel 2e-6       (direct-difference pdist, one sqrt)
+  model output  abs 2e-5       (K <= 1712 f32 MFMA fma-chain + sigmoid)
+  chi after training   abs 1e-5 at minibatch = full batch / small nets (north-star gate),
+                       abs 5e-5 for the multi-iteration golden runs
+  losses        rel 1e-4
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import isokann_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _mk_model(pkg, om: O.Model):
+    m = pkg.densenet(om.widths, activation=om.activation, lastactivation=om.lastactivation, layernorm=om.layernorm)
+    m.ln_mode = om.ln_mode
+    m.params = om.get_flat().astype(np.float32)
+    return m
+
+
+def _rand_model(widths, seed, ln=True, act="sigmoid", lastact="identity"):
+    rng = np.random.default_rng(seed)
+    om = O.glorot_model(widths, rng, layernorm=ln, activation=act, lastactivation=lastact)
+    for b in om.b:
+        b[...] = 0.1 * rng.normal(size=b.shape)
+    if ln:
+        om.ln_scale[...] = 1 + 0.1 * rng.normal(size=widths[0])
+        om.ln_bias[...] = 0.1 * rng.normal(size=widths[0])
+    return om
+
+
+# ------------------------------------------------------------------ featurizer --------
+@pytest.mark.parametrize("A,N,K", [(4, 5, 3), (22, 100, 4), (57, 33, 2)])
+def test_features_allpairs(gpu_pkg, A, N, K):
+    pkg = gpu_pkg
+    xs, ys = O.synthetic_coords(A, N, K, seed=A)
+    data = pkg.SimulationData(xs, ys, pkg.FeaturesAll())
+    iso = pkg.Iso(data, minibatch=0)
+    f = pkg.features(iso)
+    want = O.flatpairdists(np.asarray(xs, np.float64))
+    assert f.shape == want.shape == (A * (A - 1) // 2, N)
+    np.testing.assert_allclose(f, want, rtol=2e-6, atol=1e-7)
+    fy = pkg.propfeatures(iso)
+    np.testing.assert_allclose(fy, O.flatpairdists(np.asarray(ys, np.float64)), rtol=2e-6, atol=1e-7)
+    iso.close()
+
+
+def test_features_pairlist_and_atoms(gpu_pkg):
+    pkg = gpu_pkg
+    A, N, K = 40, 64, 3
+    xs, ys = O.synthetic_coords(A, N, K, seed=9)
+    pairs = O.random_pairs(A, 100, seed=3) + [(7, 7), (5, 2)]      # a zero distance and an unsorted pair
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), minibatch=0)
+    np.testing.assert_allclose(pkg.features(iso), O.pdists(np.asarray(xs, np.float64), pairs), rtol=2e-6, atol=1e-7)
+    iso.close()
+    atoms = [3, 0, 17, 21, 39]
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesAtoms(atoms)), minibatch=0)
+    np.testing.assert_allclose(pkg.features(iso), O.flatpairdists(np.asarray(xs, np.float64), atoms), rtol=2e-6, atol=1e-7)
+    iso.close()
+
+
+# ------------------------------------------------------------------ forward -----------
+@pytest.mark.parametrize("widths,ln,act", [
+    ([2, 2, 1, 1], True, "sigmoid"),            # C1 default net
+    ([231, 38, 6, 1], True, "sigmoid"),         # C2 default net
+    ([100, 22, 5, 3], True, "sigmoid"),
+    ([33, 160, 17, 40, 2], True, "tanh"),       # widest supported layer 1, deeper tail
+    ([48, 16, 1], False, "relu"),
+    ([20, 7], True, "sigmoid"),                 # single Dense layer
+    ([65, 30, 9, 2], True, "swish"),
+])
+@pytest.mark.parametrize("mode", ["var_eps2", "std_eps"])
+def test_model_forward(gpu_pkg, widths, ln, act, mode):
+    pkg = gpu_pkg
+    if not ln and mode != "var_eps2":
+        pytest.skip("mode irrelevant without LayerNorm")
+    om = _rand_model(widths, seed=sum(widths), ln=ln, act=act)
+    om.ln_mode = mode
+    rng = np.random.default_rng(1)
+    N, K = 70, 3
+    xs = rng.normal(size=(widths[0], N)) + 1.0
+    ys = rng.normal(size=(widths[0], K, N)) + 1.0
+    nout = widths[-1]
+    tgt = pkg.TransformShiftscale() if nout == 1 else pkg.TransformISA()
+    iso = pkg.Iso(pkg.SimulationData(xs, ys), model=_mk_model(pkg, om), target=tgt, minibatch=0)
+    x32 = np.asarray(xs, np.float32).astype(np.float64)
+    y32 = np.asarray(ys, np.float32).astype(np.float64)
+    np.testing.assert_allclose(iso.model(xs), om(x32), atol=2e-5, rtol=1e-5)
+    out3 = iso.model(ys)
+    assert out3.shape == (nout, K, N)
+    np.testing.assert_allclose(out3, om(y32), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(pkg.chis(iso), om(x32), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(pkg.koopman(iso), O.expectation(om, y32), atol=2e-5, rtol=1e-5)
+    iso.close()
+
+
+def test_forward_ragged_row_counts(gpu_pkg):
+    """every row count around the 16-row MFMA unit and the 2-unit pass"""
+    pkg = gpu_pkg
+    om = _rand_model([37, 20, 4, 1], seed=2)
+    rng = np.random.default_rng(3)
+    xs = rng.normal(size=(37, 4)) + 1
+    ys = rng.normal(size=(37, 2, 4)) + 1
+    iso = pkg.Iso(pkg.SimulationData(xs, ys), model=_mk_model(pkg, om), minibatch=0)
+    for n in [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 64, 65, 1000, 4097]:
+        x = np.asarray(rng.normal(size=(37, n)) + 1, np.float32)
+        np.testing.assert_allclose(iso.model(x), om(x.astype(np.float64)), atol=2e-5, rtol=1e-5)
+    iso.close()
+
+
+# ------------------------------------------------------------------ targets -----------
+def _coords_case(pkg, A, F, N, K, nout, seed, layers=3):
+    xs, ys = O.synthetic_coords(A, N, K, seed=seed)
+    pairs = O.random_pairs(A, F, seed=seed + 1)
+    widths = O.pairnet_widths(F, layers=layers, nout=nout)
+    om = _rand_model(widths, seed=seed + 2)
+    feat = O.FeaturesPairs(pairs)
+    odata = O.SimulationData(np.asarray(xs, np.float64), np.asarray(ys, np.float64), feat)
+    data = pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs))
+    return data, odata, om
+
+
+def test_isotarget_shiftscale(gpu_pkg):
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 30, 120, 200, 5, 1, seed=4)
+    iso = pkg.Iso(data, model=_mk_model(pkg, om), minibatch=0)
+    t = pkg.isotarget(iso)
+    want = O.isotarget(O.TransformShiftscale(), om, *odata.features)
+    assert t.min() == 0.0 and t.max() == 1.0
+    np.testing.assert_allclose(t, want, atol=2e-5)
+    iso.close()
+
+
+@pytest.mark.parametrize("nout,whitening,permute", [(2, False, True), (3, False, True), (3, True, True), (4, False, False)])
+def test_isotarget_isa(gpu_pkg, nout, whitening, permute):
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 30, 150, 300, 4, nout, seed=5 + nout)
+    tr = pkg.TransformISA(permute=permute, whitening=whitening)
+    iso = pkg.Iso(data, model=_mk_model(pkg, om), target=tr, minibatch=0)
+    t = pkg.isotarget(iso)
+    want = O.isotarget(O.TransformISA(permute=permute, whitening=whitening), om, *odata.features)
+    # the ISA map amplifies fp32 forward error by |inv(X[i,:])|; compare relative to the target scale
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(t, want, atol=2e-4 * scale)
+    # known answer: the selected columns form the identity (up to the row permutation)
+    ks = pkg.koopman(iso).astype(np.float64)
+    idx = O.indexmap(ks.T)
+    sel = t[:, idx]
+    assert np.allclose(np.sort(sel, axis=0)[-1], 1.0, atol=1e-4) and np.allclose(np.abs(sel).sum(axis=0), 1.0, atol=1e-3)
+    iso.close()
+
+
+def test_constant_chi_raises_domain_error(gpu_pkg):
+    pkg = gpu_pkg
+    om = _rand_model([6, 3, 1], seed=1)
+    for w in om.W:
+        w[...] = 0
+    xs = np.random.default_rng(0).normal(size=(6, 20))
+    ys = np.random.default_rng(1).normal(size=(6, 3, 20))
+    iso = pkg.Iso(pkg.SimulationData(xs, ys), model=_mk_model(pkg, om), minibatch=0)
+    with pytest.raises(pkg.DomainError) as ei:
+        pkg.isotarget(iso)
+    assert ei.value.status == pkg.capi.ECONSTANT_CHI
+    with pytest.raises(pkg.DomainError):
+        pkg.run(iso, 1)
+    iso.close()
+
+
+def test_singular_isa_raises_domain_error(gpu_pkg):
+    pkg = gpu_pkg
+    om = _rand_model([6, 3, 2], seed=1)
+    om.W[-1][...] = 0        # both outputs constant -> collapsed subspace
+    xs = np.random.default_rng(0).normal(size=(6, 20))
+    ys = np.random.default_rng(1).normal(size=(6, 3, 20))
+    iso = pkg.Iso(pkg.SimulationData(xs, ys), model=_mk_model(pkg, om), minibatch=0)
+    with pytest.raises(pkg.DomainError) as ei:
+        pkg.isotarget(iso)
+    assert ei.value.status == pkg.capi.ESINGULAR
+    iso.close()
+
+
+# ------------------------------------------------------------------ gradients ---------
+@pytest.mark.parametrize("widths,ln,act,B", [
+    ([50, 14, 5, 3], True, "sigmoid", 40),
+    ([50, 14, 5, 3], False, "sigmoid", 17),
+    ([231, 38, 6, 1], True, "sigmoid", 100),
+    ([33, 100, 20, 9, 2], True, "tanh", 64),
+    ([20, 4], True, "sigmoid", 16),
+    ([24, 9, 2], True, "swish", 33),
+])
+def test_batch_gradients(gpu_pkg, widths, ln, act, B):
+    pkg = gpu_pkg
+    om = _rand_model(widths, seed=B, ln=ln, act=act)
+    rng = np.random.default_rng(B)
+    N = 128
+    xs = rng.normal(size=(widths[0], N)) + 1.0
+    ys = rng.normal(size=(widths[0], 2, N)) + 1.0
+    nout = widths[-1]
+    tgt = np.asarray(rng.uniform(size=(nout, N)), np.float32)
+    tr = pkg.TransformShiftscale() if nout == 1 else pkg.TransformISA()
+    iso = pkg.Iso(pkg.SimulationData(xs, ys), model=_mk_model(pkg, om), target=tr, minibatch=0)
+    idx = rng.permutation(N)[:B]
+    g, l = pkg.batch_grads(iso, tgt, idx)
+    x32 = np.asarray(xs, np.float32).astype(np.float64)
+    t64 = tgt.astype(np.float64)
+    w = O.loss_weights(t64) if nout > 1 else np.ones(1)
+    lo, go, _ = O.batch_loss_and_grads(om, x32[:, idx], t64[:, idx], w)
+    gflat = np.concatenate([a.reshape(-1, order="F") for a in go])
+    assert abs(l - lo) <= 2e-5 * abs(lo)
+    scale = np.abs(gflat).max()
+    np.testing.assert_allclose(g, gflat, atol=3e-5 * scale, rtol=1e-4)
+    iso.close()
+
+
+# ------------------------------------------------------------------ training ----------
+@pytest.mark.parametrize("opt", ["adam", "nesterov"])
+@pytest.mark.parametrize("minibatch", [0, 32, 50])
+def test_train_batch_epoch(gpu_pkg, opt, minibatch):
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 20, 60, 130, 3, 1, seed=11)
+    rule = O.OptRule(opt, 1e-2, 1e-3)
+    popt = pkg.OptSpec(opt, 1e-2, 1e-3)
+    iso = pkg.Iso(data, model=_mk_model(pkg, om), opt=popt, minibatch=minibatch)
+    rng = np.random.default_rng(0)
+    st = O.setup(rule, om)
+    for ep in range(3):
+        tgt = np.asarray(rng.uniform(size=(1, 130)), np.float32)
+        perm = rng.permutation(130)
+        l = pkg.train_batch(iso, tgt, perm=perm)
+        lo = O.train_batch(om, odata.features[0], tgt.astype(np.float64), st, minibatch, perm=perm)
+        assert abs(l - lo) <= 1e-4 * abs(lo)
+    np.testing.assert_allclose(iso.model.get_params(), om.get_flat(), atol=2e-5, rtol=2e-4)
+    m, v, bt = iso.get_opt_state()
+    np.testing.assert_allclose(m, np.concatenate([a.reshape(-1, order="F") for a in st.m]), atol=1e-5, rtol=1e-3)
+    if opt == "adam":
+        assert bt[0] == pytest.approx(st.bt1) and bt[1] == pytest.approx(st.bt2)
+    iso.close()
+
+
+def test_nonfinite_loss_raises_and_keeps_weights(gpu_pkg):
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 10, 20, 40, 2, 1, seed=3)
+    iso = pkg.Iso(data, model=_mk_model(pkg, om), minibatch=0)
+    before = iso.model.get_params()
+    tgt = np.full((1, 40), np.nan, np.float32)
+    with pytest.raises(pkg.DomainError) as ei:
+        pkg.train_batch(iso, tgt, perm=np.arange(40))
+    assert ei.value.status == pkg.capi.ECOLLAPSED
+    np.testing.assert_array_equal(iso.model.get_params(), before)
+    iso.close()
+
+
+def test_run_full_batch_chi_within_1e5(gpu_pkg):
+    """north-star gate: chi within 1e-5 of the CPU oracle after 10 iterations at minibatch=0"""
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 22, 231, 256, 5, 1, seed=21)
+    iso = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(), minibatch=0)
+    oiso = O.Iso(odata, om, O.setup(O.AdamRegularized(), om), minibatch=0)
+    perms = np.stack([np.arange(256)] * 10)
+    pkg.run(iso, 10, 1, perms=perms)
+    O.run(oiso, 10, 1, perms=list(perms))
+    assert np.max(np.abs(pkg.chis(iso) - O.chis(oiso))) <= 1e-5
+    np.testing.assert_allclose(iso.losses, oiso.losses, rtol=1e-4)
+    iso.close()
+
+
+@pytest.mark.parametrize("every_iter", [False, True])
+@pytest.mark.parametrize("name", ["c1_shiftscale_nesterov", "c2small_shiftscale_adam", "c3small_isa_adam"])
+def test_run_matches_golden(gpu_pkg, name, every_iter):
+    pkg = gpu_pkg
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    kind = int(g["featurizer_kind"])
+    feat = {0: pkg.identity, 1: pkg.FeaturesAll(), 2: pkg.FeaturesPairs([tuple(p) for p in g["pairs"]])}[kind]
+    widths = [int(w) for w in g["widths"]]
+    model = pkg.densenet(widths, layernorm=True)
+    model.params = g["params0"].astype(np.float32)
+    opt = pkg.OptSpec(str(g["opt_kind"]), float(g["opt_lr"]), float(g["opt_reg"]))
+    iso = pkg.Iso(pkg.SimulationData(g["xs"], g["ys"], feat), model=model, opt=opt, minibatch=int(g["minibatch"]),
+                  featurize_every_iteration=every_iter)
+    t0 = pkg.isotarget(iso)
+    scale = max(1.0, np.abs(g["target0"]).max())
+    np.testing.assert_allclose(t0, g["target0"], atol=2e-4 * scale)
+    pkg.run(iso, int(g["n_iter"]), 1, perms=g["perms"])
+    np.testing.assert_allclose(iso.losses, g["losses"], rtol=2e-4)
+    np.testing.assert_allclose(pkg.chis(iso), g["chis"], atol=5e-5)
+    np.testing.assert_allclose(pkg.koopman(iso), g["koopman"], atol=5e-5)
+    iso.close()
+
+
+def test_engine_shuffle_is_seeded_and_valid(gpu_pkg):
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 10, 30, 90, 2, 1, seed=8)
+    a = pkg.Iso(data, model=_mk_model(pkg, om), minibatch=16, seed=7)
+    b = pkg.Iso(data, model=_mk_model(pkg, om), minibatch=16, seed=7)
+    c = pkg.Iso(data, model=_mk_model(pkg, om), minibatch=16, seed=8)
+    for i in (a, b, c):
+        pkg.run(i, 3)
+    assert a.losses == b.losses and a.losses != c.losses
+    assert all(np.isfinite(a.losses))
+    for i in (a, b, c):
+        i.close()
+
+
+def test_argument_errors(gpu_pkg):
+    pkg = gpu_pkg
+    xs = np.zeros((6, 10), np.float32)
+    ys = np.zeros((6, 2, 10), np.float32)
+    with pytest.raises(pkg.IskError):        # shiftscale needs nout == 1
+        pkg.Iso(pkg.SimulationData(xs, ys), model=pkg.densenet([6, 3, 2]), target=pkg.TransformShiftscale())
+    with pytest.raises(pkg.IskError):        # ISA needs nout > 1
+        pkg.Iso(pkg.SimulationData(xs, ys), model=pkg.densenet([6, 3, 1]), target=pkg.TransformISA())
+    iso = pkg.Iso(pkg.SimulationData(xs + 1, ys + 1), model=pkg.densenet([6, 3, 1]))
+    with pytest.raises(pkg.IskError):
+        iso.model(np.zeros((5, 3), np.float32))
+    with pytest.raises(pkg.IskError):        # no target yet
+        pkg.train_batch(iso, None)
+    iso.close()
