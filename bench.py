@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py -- ISOKANN train-step throughput on MI355X (BASELINE.json metric).
+
+One "step" = one run!(iso, 1, 1) iteration (src/iso.jl:72-94 of the reference) on synthetic
+data already resident in HBM: pairwise-distance featurization of xs and ys (per iteration,
+as the north-star defines the hot path), MLP forward over the N*K Koopman samples (+ N start
+points for ISA), K-mean, shift-scale / ISA target, one training epoch (weighted MSE fwd/bwd +
+WeightDecay+Adam) on xs.   value = Koopman samples (N*K, summed over ranks) per second.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W          (one rank per GPU, RCCL)
+
+Multi-GPU is WEAK scaling: every rank holds its own C3-sized shard (N=10000 starts, K=20) and a
+fixed per-rank minibatch, so the global batch is minibatch*N_gpus and the number of optimizer
+steps per epoch stays constant; one flat [gradient|loss] all-reduce per step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as ge  # noqa: E402
+
+
+def build_iso(pkg, wl, seed, device, args):
+    from isokann_jl_amd import synth
+    c = synth.WORKLOADS[wl]
+    xs, ys = synth.synthetic_coords(c["atoms"], c["N"], c["K"], seed=seed)
+    if c["feat"] == "all":
+        feat, F = pkg.FeaturesAll(), c["atoms"] * (c["atoms"] - 1) // 2
+    else:
+        feat, F = pkg.FeaturesPairs(synth.random_pairs(c["atoms"], c["feat"], seed=0)), c["feat"]
+    widths = pkg.pairnet_widths(F, nout=c["nout"])
+    model = pkg.densenet(widths, layernorm=True, seed=0)       # glorot init, identical on every rank
+    opt = pkg.AdamRegularized() if args.opt == "adam" else pkg.NesterovRegularized()
+    data = pkg.SimulationData(xs, ys, feat)
+    iso = pkg.Iso(data, opt=opt, model=model, minibatch=args.minibatch, device=device,
+                  featurize_every_iteration=not args.cached_features, seed=seed)
+    del xs, ys
+    return iso, c, widths
+
+
+def algorithmic_flops(widths, n, k, nb_rows):
+    """F_fwd = 2*sum(in*out) per sample"""
+    ffwd = 2 * sum(a * b for a, b in zip(widths[:-1], widths[1:]))
+    isa = 1 if widths[-1] > 1 else 0
+    fwd_launch = (n * k + isa * n) * ffwd                       # the dominant kernel (one launch)
+    step = fwd_launch + nb_rows * (3 * ffwd - 2 * widths[0] * widths[1])
+    return ffwd, fwd_launch, step
+
+
+def cpu_baseline(wl, args):
+    """the CPU oracle (a port of the reference semantics, NumPy/BLAS fp32) timed on a bounded
+    sample of the same workload on this host's cores"""
+    from oracle import isokann_oracle as O
+    from isokann_jl_amd import synth
+    c = synth.WORKLOADS[wl]
+    ns = min(c["N"], args.cpu_sample)
+    xs, ys = synth.synthetic_coords(c["atoms"], ns, c["K"], seed=1)
+    if c["feat"] == "all":
+        feat = O.FeaturesAll()
+        F = c["atoms"] * (c["atoms"] - 1) // 2
+    else:
+        feat = O.FeaturesPairs(synth.random_pairs(c["atoms"], c["feat"], seed=0))
+        F = c["feat"]
+    om = O.glorot_model(O.pairnet_widths(F, nout=c["nout"]), np.random.default_rng(0), dtype=np.float32)
+    rule = O.AdamRegularized() if args.opt == "adam" else O.NesterovRegularized()
+    st = O.setup(rule, om)
+    rng = np.random.default_rng(0)
+    mb = min(args.minibatch, ns) if args.minibatch else 0
+
+    def step():
+        data = O.SimulationData(xs, ys, feat, dtype=np.float32)          # featurization is part of the step
+        iso = O.Iso(data, om, st, minibatch=mb)
+        O.run(iso, 1, 1, rng=rng)
+
+    step()
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 2 or (time.perf_counter() - t0 < 10.0 and reps < 50):
+        step()
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": ns * c["K"] / dt, "unit": "Koopman-samples/s", "cores": int(cores), "kind": "port",
+            "sample": f"{ns} of {c['N']} start points x K={c['K']} (same featurizer/model/optimizer, fp32 NumPy+BLAS oracle, "
+                      f"{reps} timed steps of {dt:.2f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3"])
+    ap.add_argument("--minibatch", type=int, default=1000, help="per-rank minibatch (scripts/villin.jl:37 uses 1000); 0 = full batch")
+    ap.add_argument("--opt", default="adam", choices=["adam", "nesterov"])
+    ap.add_argument("--cached-features", action="store_true", help="featurize once at set_data (reference semantics) instead of every iteration")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1000)
+    ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--force-dp", action="store_true", help="use the data-parallel driver even with one rank (rehearsal)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    ge.build()
+    pkg = ge.load_package()
+    if pkg.capi.device_count() <= local_rank:
+        sys.exit("no HIP device for this rank: the product path has no CPU fallback")
+
+    dist = None
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    iso, c, widths = build_iso(pkg, args.workload, seed=rank, device=local_rank, args=args)
+    N, K = c["N"], c["K"]
+    bs = N if (args.minibatch == 0 or N < args.minibatch) else args.minibatch
+    nb_rows = (N // bs) * bs
+
+    if not use_dp:
+        def step():
+            pkg.run(iso, 1, 1)
+
+        def sync():
+            pkg.capi.check(iso._lib.isk_synchronize(iso._h))
+
+        def barrier():
+            pass
+    else:
+        import torch
+        from isokann_jl_amd import dp
+        comm = dp.Comm(device=torch.device("cuda", local_rank))
+        local = dp.HipLocal(iso)
+        rng = np.random.default_rng(1000 + rank)
+        gmb = 0 if args.minibatch == 0 else args.minibatch * world       # fixed per-rank batch
+
+        def step():
+            iso.losses.extend(dp.dp_run(local, comm, 1, 1, gmb, rng))
+
+        def sync():
+            torch.cuda.synchronize()
+
+        def barrier():
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync(); barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync(); barrier(); sync()
+    dt = time.perf_counter() - t0
+    if use_dp:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert all(np.isfinite(l) for l in iso.losses), "non-finite training loss"
+
+    # roofline of the dominant kernel (fused MLP forward), HIP events on the engine's stream, outside the timed region
+    roof = None
+    if rank == 0:
+        iso.timers(enable=True, reset=True)
+        for _ in range(args.profile_steps):
+            step()
+        sync()
+        tm = iso.timers(enable=False)
+        ffwd, fwd_flops, step_flops = algorithmic_flops(widths, N, K, nb_rows)
+        ms, cnt = tm["fwd_ys"]
+        if cnt:
+            avg = ms / cnt
+            ach = fwd_flops / (avg * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+                    "kernel": f"mlp_fwd_kernel<{(widths[1] + 15) // 16}>", "avg_ms": avg, "launches": cnt,
+                    "flops_per_launch": fwd_flops,
+                    "phases_ms": {k: (v[0] / v[1] if v[1] else None) for k, v in tm.items()}}
+    if use_dp:
+        dist.barrier()
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.workload, args)
+        value = world * N * K * args.steps / dt
+        line = {
+            "metric": "ISOKANN train-step Koopman-samples (N*K)/sec", "value": value, "unit": "Koopman-samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": c["label"], "N_per_gpu": N, "K": K, "features": widths[0], "widths": widths,
+                       "minibatch_per_gpu": args.minibatch, "optimizer": args.opt + "+weightdecay",
+                       "featurize": "cached" if args.cached_features else "every-iteration (fused pdist+LayerNorm kernel)",
+                       "parallelism": f"dp{world} over N" if world > 1 else "single GPU"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "final_loss": iso.losses[-1],
+        }
+        print(json.dumps(line), flush=True)
+    iso.close()
+    if use_dp:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -166,6 +166,13 @@ int  isk_dp_shiftscale_apply(isk_engine* e, float gmin, float gmax);   /* target
 int  isk_dp_get_ks_chi(isk_engine* e, float* ks, float* chi);   /* local (nout, N) slices for the ISA gather */
 int  isk_dp_isa_apply(isk_engine* e, const double* At, const int32_t* rowperm); /* target = (A' ks)[perm] */
 int  isk_dp_set_loss_weights(isk_engine* e, const float* w);    /* global 1/std(target) */
+/* per-row sum and sum of squares of the local target (for the global std, src/iso.jl:183) */
+int  isk_dp_target_moments(isk_engine* e, double* sum, double* sumsq);
+/* Host Float64 ISA solve on gathered arrays (no device work): ks, chi are (d, N) column-major.
+ * Outputs At (d*d, row-major: target = At * ks) and the fixperm row permutation.
+ * myisa + fixperm, src/isotarget.jl:81-98, 120-127. */
+int  isk_isa_solve(const float* ks, const float* chi, int64_t N, int32_t d, int32_t permute, int32_t whitening,
+                   double* At, int32_t* rowperm);
 /* device pointer + length of the flat gradient/loss buffer: [grads (nparams) | batch loss] */
 int  isk_dp_grad_buffer(isk_engine* e, void** buf_dev, int64_t* nfloats);
 /* local batch -> this rank's contribution to the gradient of (global batch loss / global_batch),

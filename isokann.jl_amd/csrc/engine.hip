@@ -1031,6 +1031,33 @@ extern "C" int isk_dp_set_loss_weights(isk_engine* e, const float* w) {
     return ISK_OK;
 }
 
+extern "C" int isk_dp_target_moments(isk_engine* e, double* sum, double* sumsq) {
+    CHK(need_data(e));
+    if (!e->have_target || !sum || !sumsq) return fail(ISK_ESTATE, "no target / null argument");
+    const int d = e->nout;
+    std::vector<float> t((size_t)e->N * d);
+    HIPCHK(hipMemcpyAsync(t.data(), e->d_target, t.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < d; ++i) { sum[i] = 0; sumsq[i] = 0; }
+    for (long long n = 0; n < e->N; ++n)
+        for (int i = 0; i < d; ++i) { const double v = t[n * d + i]; sum[i] += v; sumsq[i] += v * v; }
+    return ISK_OK;
+}
+
+extern "C" int isk_isa_solve(const float* ks, const float* chi, int64_t N, int32_t d, int32_t permute, int32_t whitening,
+                             double* At, int32_t* rowperm) {
+    if (!ks || !chi || !At || !rowperm || N < 1 || d < 2 || d > 8) return fail(ISK_EINVAL, "bad argument");
+    isk_engine tmp;
+    tmp.cfg.isa_permute = permute; tmp.cfg.isa_whitening = whitening;
+    std::vector<float> k(ks, ks + (size_t)N * d), c(chi, chi + (size_t)N * d);
+    std::vector<double> A;
+    std::vector<int> rp;
+    CHK(isa_solve_host(&tmp, k, c, N, d, A, rp, nullptr));
+    for (int i = 0; i < d * d; ++i) At[i] = A[i];
+    for (int i = 0; i < d; ++i) rowperm[i] = rp[i];
+    return ISK_OK;
+}
+
 extern "C" int isk_dp_grad_buffer(isk_engine* e, void** buf, int64_t* n) {
     if (!e || !buf || !n) return fail(ISK_EINVAL, "null argument");
     *buf = e->d_grad;

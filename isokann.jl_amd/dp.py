@@ -1,0 +1,213 @@
+"""Data-parallel ISOKANN iteration over N: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on MI355X; "gloo" for the CPU tests).
+
+The reference has no multi-device code at all; this is new.  The N
+axis shards naturally: every start point carries its own K replicas, so the K-mean
+(src/isotarget.jl:18) never crosses a device.  Per run!() iteration the exchange steps are
+
+  1-D target   all-reduce(max) of [-min, max] of the local Koopman values   (isotarget.jl:38)
+  ISA target   all-gather of the local (d, N_r) ks and chi slices; every rank then solves the
+               same tiny Float64 d x d problem (myisa + fixperm, isotarget.jl:81-127); the
+               loss weights 1/std(target, dims=2) (iso.jl:183) come from all-reduced moments
+  training     ONE all-reduce(sum) of the flat [gradient | batch loss] buffer per optimizer
+               step (villin: 246 698 floats, 0.99 MB) -- latency-bound on xGMI, so one flat
+               buffer, never per-array collectives
+
+`minibatch` keeps the reference's meaning on the GLOBAL data set: a global batch is the union of
+B/P columns from each rank's own shuffle of its shard; the gradient of the global batch mean is the
+all-reduced sum of the per-rank contributions (each already divided by the global batch size).
+At minibatch = 0 this is identical to the reference's single full batch.
+
+The local engine is duck-typed (HipLocal below; the gloo tests plug the CPU oracle in), so the
+collective logic is covered without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import capi
+
+
+def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """contiguous N-slab of rank `rank` (N is the slowest axis of xs (D,N) and ys (D,K,N), so a
+    slab is contiguous in memory); sizes differ by at most one"""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class Comm:
+    """torch.distributed plumbing; world == 1 works without an initialised process group"""
+
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.on else 1
+        self.rank = dist.get_rank() if self.on else 0
+        self.device = device if device is not None else torch.device("cpu")
+
+    def _t(self, a: np.ndarray):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def allreduce_np(self, a: np.ndarray, op: str = "sum") -> np.ndarray:
+        if not self.on:
+            return np.array(a, copy=True)
+        t = self._t(a)
+        self.dist.all_reduce(t, op={"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX}[op])
+        return t.cpu().numpy()
+
+    def allgather_cols(self, a: np.ndarray, counts: List[int]) -> np.ndarray:
+        """a: (d, n_r) column slice of this rank -> (d, sum n_r) in rank order"""
+        if not self.on:
+            return np.array(a, copy=True)
+        d, nmax = a.shape[0], max(counts)
+        pad = np.zeros((nmax, d), dtype=a.dtype)
+        pad[:a.shape[1]] = a.T
+        t = self._t(pad)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return np.concatenate([o.cpu().numpy()[:c] for o, c in zip(out, counts)], axis=0).T
+
+    def allreduce_tensor_(self, t):
+        if self.on:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t
+
+    def barrier(self):
+        if self.on:
+            self.dist.barrier()
+
+
+class _DevBuf:
+    """exposes engine-owned device memory to torch through __cuda_array_interface__"""
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class HipLocal:
+    """the C-ABI engine of one rank (an `Iso` built on the rank's shard)"""
+
+    def __init__(self, iso, use_torch_stream: bool = True):
+        import torch
+        self.iso, self.lib, self.h = iso, iso._lib, iso._h
+        self.n_local = len(iso.data)
+        self.nout = iso.nout
+        self.kind = "isa" if iso.target.__class__.__name__ == "TransformISA" else "shiftscale"
+        self.permute = getattr(iso.target, "permute", True)
+        self.whitening = getattr(iso.target, "whitening", False)
+        if use_torch_stream:
+            capi.check(self.lib.isk_set_stream(self.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ptr, n = C.c_void_p(), C.c_int64()
+        capi.check(self.lib.isk_dp_grad_buffer(self.h, C.byref(ptr), C.byref(n)))
+        self.grad_tensor = torch.as_tensor(_DevBuf(ptr.value, n.value), device=torch.device("cuda", torch.cuda.current_device()))
+
+    def koopman_local(self):
+        capi.check(self.lib.isk_dp_koopman_local(self.h))
+
+    def minmax_local(self):
+        mm = np.zeros(2, np.float32)
+        capi.check(self.lib.isk_dp_minmax_local(self.h, capi.ptr_f32(mm)))
+        return float(mm[0]), float(mm[1])
+
+    def shiftscale_apply(self, lo, hi):
+        capi.check(self.lib.isk_dp_shiftscale_apply(self.h, lo, hi))
+
+    def get_ks_chi(self):
+        ks = np.empty((self.nout, self.n_local), np.float32, order="F")
+        chi = np.empty((self.nout, self.n_local), np.float32, order="F")
+        capi.check(self.lib.isk_dp_get_ks_chi(self.h, capi.ptr_f32(ks), capi.ptr_f32(chi)))
+        return ks, chi
+
+    def isa_solve(self, ks_all, chi_all):
+        ks_all, chi_all = capi.f32(ks_all), capi.f32(chi_all)
+        d, n = ks_all.shape
+        At = np.zeros(d * d, np.float64)
+        rp = np.zeros(d, np.int32)
+        capi.check(self.lib.isk_isa_solve(capi.ptr_f32(ks_all), capi.ptr_f32(chi_all), n, d, int(self.permute),
+                                          int(self.whitening), capi.ptr_f64(At), capi.ptr_i32(rp)))
+        return At, rp
+
+    def isa_apply(self, At, rowperm):
+        capi.check(self.lib.isk_dp_isa_apply(self.h, capi.ptr_f64(At), capi.ptr_i32(rowperm)))
+
+    def target_moments(self):
+        s = np.zeros(self.nout, np.float64)
+        q = np.zeros(self.nout, np.float64)
+        capi.check(self.lib.isk_dp_target_moments(self.h, capi.ptr_f64(s), capi.ptr_f64(q)))
+        return s, q
+
+    def set_loss_weights(self, w):
+        w = np.ascontiguousarray(w, np.float32)
+        capi.check(self.lib.isk_dp_set_loss_weights(self.h, capi.ptr_f32(w)))
+
+    def local_grads(self, idx, global_batch):
+        idx = np.ascontiguousarray(idx, np.int32)
+        capi.check(self.lib.isk_dp_local_grads(self.h, capi.ptr_i32(idx), idx.size, int(global_batch)))
+
+    def apply(self) -> float:
+        loss = C.c_double(0)
+        capi.check(self.lib.isk_dp_apply(self.h, C.byref(loss)))
+        return float(loss.value)
+
+
+def dp_target(local, comm: Comm, counts: List[int]) -> None:
+    """isotarget(iso) across ranks; leaves target (+ loss weights) on every rank's device"""
+    local.koopman_local()
+    if local.kind == "shiftscale":
+        lo, hi = local.minmax_local()
+        g = comm.allreduce_np(np.array([-lo, hi], np.float32), "max")     # one collective for both
+        glo, ghi = -float(g[0]), float(g[1])
+        if not ghi > glo:                                                 # src/isotarget.jl:39 (NaN too)
+            raise capi.DomainError(capi.ECONSTANT_CHI, "Could not compute the shift-scale. chi function is constant")
+        local.shiftscale_apply(glo, ghi)
+        return
+    ks, chi = local.get_ks_chi()
+    both = comm.allgather_cols(np.concatenate([ks, chi], axis=0), counts)  # one gather for ks and chi
+    d = ks.shape[0]
+    At, rp = local.isa_solve(both[:d], both[d:])
+    local.isa_apply(At, rp)
+    s, q = local.target_moments()
+    tot = comm.allreduce_np(np.concatenate([s, q, [float(local.n_local)]]), "sum")
+    n = tot[-1]
+    var = (tot[d:2 * d] - tot[:d] ** 2 / n) / (n - 1)                     # corrected, src/iso.jl:183
+    local.set_loss_weights(1.0 / np.sqrt(var))
+
+
+def dp_train_epoch(local, comm: Comm, minibatch: int, counts: List[int], perm: np.ndarray) -> float:
+    """train_batch! (src/iso.jl:179-194) across ranks.  perm: this rank's shuffle of its own shard."""
+    n_global = int(sum(counts))
+    bs = n_global if (minibatch == 0 or n_global < minibatch) else minibatch      # src/iso.jl:180
+    if bs == n_global:
+        bl, nb = local.n_local, 1                       # full batch: every rank contributes its whole shard
+        gb = n_global
+    else:
+        bl = bs // comm.world
+        if bl < 1:
+            raise ValueError("global minibatch smaller than the number of ranks")
+        gb = bl * comm.world
+        nb = min(c // bl for c in counts)               # partial=false: the ragged tail is dropped
+    ls = 0.0
+    for b in range(nb):
+        local.local_grads(perm[b * bl:(b + 1) * bl], gb)
+        comm.allreduce_tensor_(local.grad_tensor)
+        ls += local.apply()                             # raises DomainError on a non-finite global loss
+    return ls / n_global                                # src/iso.jl:193
+
+
+def dp_run(local, comm: Comm, n: int, epochs: int, minibatch: int, rng: np.random.Generator,
+           perms: Optional[List[np.ndarray]] = None) -> List[float]:
+    """run!(iso, n, epochs) (src/iso.jl:72-94) across ranks; returns the per-epoch losses"""
+    counts = [int(c) for c in comm.allreduce_np(np.eye(comm.world, dtype=np.int64)[comm.rank] * local.n_local, "sum")]
+    losses, k = [], 0
+    for _ in range(n):
+        dp_target(local, comm, counts)
+        for _ in range(epochs):
+            perm = perms[k] if perms is not None else rng.permutation(local.n_local)
+            k += 1
+            losses.append(dp_train_epoch(local, comm, minibatch, counts, np.asarray(perm)))
+    return losses
