@@ -104,6 +104,7 @@ struct isk_engine {
     int* d_status = nullptr;
     float* d_mm = nullptr;
     int2* d_pairs = nullptr;
+    unsigned* d_packed = nullptr;
     double bt1 = 0.9, bt2 = 0.999;
     // data
     long long N = 0, K = 0, D = 0;
@@ -196,7 +197,7 @@ static MlpFwdArgs fwd_args(const isk_engine* e, const float* X, long long S, flo
     a.H1 = e->cfg.widths[1];
     a.nt1 = isk_pad16(a.H1) / 16;
     a.ntail = e->L - 1;
-    int sa = 0, sb = 0;
+    int sa = isk_pad16(e->cfg.widths[1]) + 4, sb = 0;    // layer-1 output always passes through scratch A
     for (int l = 1; l < e->L; ++l) {
         TailLayer& t = a.tail[l - 1];
         t.Wt = e->d_Wt[l]; t.bias = e->d_bias[l];
@@ -333,6 +334,12 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     if (!pairs.empty()) {
         ALLOC(e->d_pairs, pairs.size() * sizeof(int2));
         (void)hipMemcpy(e->d_pairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice);
+        if (cfg->n_atoms <= 65535) {
+            std::vector<unsigned> pk(pairs.size());
+            for (size_t i = 0; i < pairs.size(); ++i) pk[i] = (unsigned)pairs[i].x | ((unsigned)pairs[i].y << 16);
+            ALLOC(e->d_packed, pk.size() * sizeof(unsigned));
+            (void)hipMemcpy(e->d_packed, pk.data(), pk.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+        }
     }
 #undef ALLOC
     (void)hipMemset(e->d_theta, 0, pb); (void)hipMemset(e->d_grad, 0, pb);
@@ -353,7 +360,7 @@ extern "C" void isk_destroy(isk_engine* e) {
     free_data(e);
     free_dev(e->d_theta); free_dev(e->d_grad); free_dev(e->d_m); free_dev(e->d_v);
     free_dev(e->d_loss_acc); free_dev(e->d_status); free_dev(e->d_mm); free_dev(e->d_lossw);
-    free_dev(e->d_At); free_dev(e->d_rowperm); free_dev(e->d_pairs);
+    free_dev(e->d_At); free_dev(e->d_rowperm); free_dev(e->d_pairs); free_dev(e->d_packed);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_Wt[l]); free_dev(e->d_bias[l]); }
     drain_timers(e);
     for (auto& ep : e->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -436,7 +443,7 @@ extern "C" int isk_reset_opt_state(isk_engine* e) {
 // ---------------------------------------------------------------------------------------
 static void featurize_rows(isk_engine* e, const float* in, long long S, float* xhat) {
     FeatArgs a;
-    a.in = in; a.pairs = e->d_pairs; a.xhat = xhat; a.S = S; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
+    a.in = in; a.pairs = e->d_pairs; a.packed_pairs = e->d_packed; a.xhat = xhat; a.S = S; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
     isk_launch_featurize(a, e->stream);
 }
@@ -508,7 +515,7 @@ extern "C" int isk_features(isk_engine* e, const float* coords, int64_t D, int64
     HIPCHK(hipMalloc(&xh.p, (size_t)ncols * e->Fp * sizeof(float)));
     HIPCHK(hipMemcpyAsync(in.p, coords, (size_t)ncols * D * sizeof(float), hipMemcpyHostToDevice, e->stream));
     FeatArgs a;
-    a.in = (const float*)in.p; a.pairs = e->d_pairs; a.xhat = (float*)xh.p; a.S = ncols; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
+    a.in = (const float*)in.p; a.pairs = e->d_pairs; a.packed_pairs = e->d_packed; a.xhat = (float*)xh.p; a.S = ncols; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
     a.normalize = 0; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;   // raw features: the featurizer alone
     isk_launch_featurize(a, e->stream);
     HIPCHK(hipMemcpy2DAsync(out, (size_t)e->F * sizeof(float), xh.p, (size_t)e->Fp * sizeof(float), (size_t)e->F * sizeof(float),
@@ -526,7 +533,8 @@ static int forward_cols(isk_engine* e, const float* host_in, int64_t rowlen, int
     HIPCHK(hipMalloc(&o.p, (size_t)ncols * e->nout * sizeof(float)));
     HIPCHK(hipMemcpyAsync(in.p, host_in, (size_t)ncols * rowlen * sizeof(float), hipMemcpyHostToDevice, e->stream));
     FeatArgs a;
-    a.in = (const float*)in.p; a.pairs = is_coords ? e->d_pairs : nullptr; a.xhat = (float*)xh.p; a.S = ncols;
+    a.in = (const float*)in.p; a.pairs = is_coords ? e->d_pairs : nullptr; a.packed_pairs = is_coords ? e->d_packed : nullptr;
+    a.xhat = (float*)xh.p; a.S = ncols;
     a.D = (int)rowlen; a.F = e->F; a.Fp = e->Fp;
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
     isk_launch_featurize(a, e->stream);

@@ -16,6 +16,7 @@ static inline int isk_pad16(int x) { return (x + 15) & ~15; }
 struct FeatArgs {
     const float* in;        // [S][D]   (D = 3*n_atoms for pdist, = F for identity)
     const int2*  pairs;     // [F] 0-based atom pairs (pdist) or nullptr (identity)
+    const unsigned* packed_pairs;  // [F] a | b << 16 when n_atoms <= 65535, else nullptr
     float* xhat;            // [S][Fp]
     long long S;
     int D, F, Fp;

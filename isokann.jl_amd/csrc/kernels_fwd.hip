@@ -6,6 +6,7 @@
 //   LayerNorm/Dense  src/models.jl:87-92 (Flux.LayerNorm, Flux.Dense)
 //   K-mean           src/isotarget.jl:18 (expectation)
 //   shift-scale      src/isotarget.jl:36-42
+#include <cstdlib>
 #include "isk_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -110,14 +111,144 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeatArgs a) {
     }
 }
 
+// -------------------------------------------------------------------------------------
+// featurize, register-resident variant (the one that normally runs): persistent waves, one
+// sample per wave per trip, NO workgroup barrier.  Each lane keeps its <= NFL (packed 16-bit)
+// atom pairs and its NFL distances in registers across the whole sample loop; the sample's
+// coordinates are staged in a wave-private LDS region padded to xyzw so a pair costs two
+// ds_read_b128; mean / variance by wavefront shuffles; the standardised row goes out as
+// coalesced 256-B store instructions.
+// -------------------------------------------------------------------------------------
+template <int NFL, bool PDIST>
+__global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const unsigned* __restrict__ packed_pairs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int natoms = a.D / 3;
+    f32x4* cw = (f32x4*)smem + (size_t)wave * natoms;        // wave-private xyzw coordinates
+    unsigned pr[NFL];
+    if (PDIST) {
+#pragma unroll
+        for (int i = 0; i < NFL; ++i) {
+            const int f = lane + 64 * i;
+            pr[i] = (f < a.F) ? packed_pairs[f] : 0u;
+        }
+    }
+    const float invF = 1.0f / (float)a.F;
+    const long long nw = (long long)gridDim.x * 4;
+    for (long long s = (long long)blockIdx.x * 4 + wave; s < a.S; s += nw) {
+        const float* row = a.in + s * (long long)a.D;
+        float d[NFL];
+        if (PDIST) {
+            // coalesced row read, 8 loads in flight, scattered into the padded LDS image
+            for (int base = 0; base < a.D; base += 512) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = base + 64 * u + lane;
+                    v[u] = (i < a.D) ? row[i] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = base + 64 * u + lane;
+                    if (i < a.D) {
+                        const int at = i / 3;
+                        ((float*)cw)[4 * at + (i - 3 * at)] = v[u];
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes have landed
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < NFL; ++i) {
+                const f32x4 pa = cw[pr[i] & 0xffffu];
+                const f32x4 pb = cw[pr[i] >> 16];
+                const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+                d[i] = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
+            }
+            __builtin_amdgcn_wave_barrier();             // all reads issued before the next trip's writes
+        } else {
+#pragma unroll
+            for (int i = 0; i < NFL; ++i) {
+                const int f = lane + 64 * i;
+                d[i] = (f < a.F) ? row[f] : 0.f;
+            }
+        }
+        float mu = 0.f, rstd = 1.f;
+        if (a.normalize) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NFL; ++i) sum += (lane + 64 * i < a.F) ? d[i] : 0.f;
+            mu = wave_sum(sum) * invF;
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < NFL; ++i) {
+                const float t = d[i] - mu;
+                ss += (lane + 64 * i < a.F) ? t * t : 0.f;
+            }
+            const float var = wave_sum(ss) * invF;
+            if (a.ln_mode == ISK_LN_VAR_EPS2) rstd = 1.0f / sqrtf(var + a.eps * a.eps);
+            else if (a.ln_mode == ISK_LN_STD_EPS) rstd = 1.0f / (sqrtf(var) + a.eps);
+            else rstd = 1.0f / sqrtf(var + a.eps);
+        }
+        float* orow = a.xhat + s * (long long)a.Fp;
+#pragma unroll
+        for (int i = 0; i < NFL; ++i) {
+            const int f = lane + 64 * i;
+            if (f < a.Fp) orow[f] = (f < a.F) ? (d[i] - mu) * rstd : 0.f;
+        }
+    }
+}
+
+template <int NFL>
+static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream_t st) {
+    const bool pd = a.pairs != nullptr;
+    const size_t lds = pd ? (size_t)4 * (a.D / 3) * 16 : 0;
+    // waves per CU bounded by the wave-private LDS image (160 KiB) and by 16 (4 per SIMD)
+    int wg_per_cu = 4;
+    if (lds > 0) {
+        const int fit = (int)((150 * 1024) / lds);
+        if (fit < wg_per_cu) wg_per_cu = fit < 1 ? 1 : fit;
+    }
+    long long blocks = (a.S + 3) / 4;
+    const long long cap = (long long)ISK_NUM_CU * wg_per_cu;
+    if (blocks > cap) blocks = cap;
+    if (pd) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)featurize_reg_kernel<NFL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((featurize_reg_kernel<NFL, true>), dim3((unsigned)blocks), dim3(256), lds, st, a, packed);
+    } else {
+        hipLaunchKernelGGL((featurize_reg_kernel<NFL, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, packed);
+    }
+}
+
 void isk_launch_featurize(const FeatArgs& a, hipStream_t st) {
     if (a.S <= 0) return;
     const bool pd = a.pairs != nullptr;
+    const int need = (a.Fp + 63) / 64;
+    const bool reg_ok = need <= 32 && (!pd || (a.packed_pairs != nullptr && (size_t)4 * (a.D / 3) * 16 <= 150 * 1024));
+    if (reg_ok) {
+        if (need <= 1) launch_feat_reg<1>(a, a.packed_pairs, st);
+        else if (need <= 2) launch_feat_reg<2>(a, a.packed_pairs, st);
+        else if (need <= 4) launch_feat_reg<4>(a, a.packed_pairs, st);
+        else if (need <= 8) launch_feat_reg<8>(a, a.packed_pairs, st);
+        else if (need <= 12) launch_feat_reg<12>(a, a.packed_pairs, st);
+        else if (need <= 16) launch_feat_reg<16>(a, a.packed_pairs, st);
+        else if (need <= 20) launch_feat_reg<20>(a, a.packed_pairs, st);
+        else if (need <= 24) launch_feat_reg<24>(a, a.packed_pairs, st);
+        else if (need <= 28) launch_feat_reg<28>(a, a.packed_pairs, st);
+        else launch_feat_reg<32>(a, a.packed_pairs, st);
+        return;
+    }
+    // generic fallback (any F, any atom count): LDS stash variant
     const int Dp = pd ? ((a.D + 3) & ~3) : 0;
     const size_t lds = (size_t)4 * (Dp + a.Fp) * sizeof(float);
     long long blocks = (a.S + 3) / 4;
     const long long cap = (long long)ISK_NUM_CU * 8;
     if (blocks > cap) blocks = cap;
+    if (lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)featurize_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)featurize_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (pd) hipLaunchKernelGGL(featurize_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, a);
     else hipLaunchKernelGGL(featurize_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, st, a);
 }
@@ -235,13 +366,20 @@ __device__ __forceinline__ void layer1_gemm(const MlpFwdArgs& a, const float* x0
     const int nch = a.nchunks;
     Frags<NT> fa, fb;
     load_frags<NT, TWO>(fa, Wp, x0, x1, 0);
+    // Register double buffer.  The sched_barriers pin "issue the next chunk's loads, THEN run this
+    // chunk's MFMAs": without them hipcc sinks the loads below the MFMA block (to save registers)
+    // and waits vmcnt(0) right after issuing them, exposing the full memory latency every chunk.
     for (int c = 0; c < nch; c += 2) {
         const int c1 = (c + 1 < nch) ? c + 1 : nch - 1;
         load_frags<NT, TWO>(fb, Wp, x0, x1, c1);
+        __builtin_amdgcn_sched_barrier(0);
         mma_frags<NT, TWO>(fa, acc0, acc1);
+        __builtin_amdgcn_sched_barrier(0);
         const int c2 = (c + 2 < nch) ? c + 2 : nch - 1;
         load_frags<NT, TWO>(fa, Wp, x0, x1, c2);
+        __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < nch) mma_frags<NT, TWO>(fb, acc0, acc1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -251,26 +389,32 @@ __device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT],
                                           float* scrB, int lane) {
     const int li = lane & 15, lq = lane >> 4;
     int stride = a.stride_a;
-    if (a.ntail == 0) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int col = t * 16 + li;
-            const float bcol = a.bias1[col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long long grow = row_base + lq * 4 + r;
-                if (col < a.nout && grow < a.S) a.out[grow * a.nout + col] = act_apply(a.act1, acc[t][r] + bcol);
-            }
-        }
-        return;
-    }
+    // accumulator layout (row = 4*lq + r, col = 16*t + li) -> LDS rows; bias added on the way
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = t * 16 + li;
         const float bcol = a.bias1[col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) scrA[(lq * 4 + r) * stride + col] = act_apply(a.act1, acc[t][r] + bcol);
+        for (int r = 0; r < 4; ++r) scrA[(lq * 4 + r) * stride + col] = acc[t][r] + bcol;
     }
+    __builtin_amdgcn_wave_barrier();
+    const int H1p = NT * 16;
+    if (a.ntail == 0) {
+        for (int row = lq; row < 16; row += 4) {
+            const long long grow = row_base + row;
+            if (li < a.nout && grow < a.S) a.out[grow * a.nout + li] = act_apply(a.act1, scrA[row * stride + li]);
+        }
+        // nout > 16 with a single layer
+        for (int col = 16 + li; col < a.nout; col += 16)
+            for (int row = lq; row < 16; row += 4) {
+                const long long grow = row_base + row;
+                if (grow < a.S) a.out[grow * a.nout + col] = act_apply(a.act1, scrA[row * stride + col]);
+            }
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
+    for (int row = 0; row < 16; ++row)
+        for (int col = lane; col < H1p; col += WAVE) scrA[row * stride + col] = act_apply(a.act1, scrA[row * stride + col]);
     __builtin_amdgcn_wave_barrier();
     float* in = scrA;
     float* ob = scrB;
@@ -338,7 +482,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a, long long un
 template <int NT>
 static void launch_fwd_nt(const MlpFwdArgs& a, hipStream_t st) {
     const long long units = (a.S + 15) / 16;
-    const long long waves_max = (long long)ISK_NUM_CU * 4;
+    static const int wps = [] { const char* v = getenv("ISK_FWD_WAVES_PER_SIMD"); int n = v ? atoi(v) : 1; return n < 1 ? 1 : (n > 4 ? 4 : n); }();
+    const long long waves_max = (long long)ISK_NUM_CU * 4 * wps;
     long long upw = (units + waves_max - 1) / waves_max;     // units per wave
     if (upw < 1) upw = 1;
     const long long nwaves = (units + upw - 1) / upw;

@@ -40,12 +40,17 @@ __device__ __forceinline__ float t_dact(int act, float z, float a) {
 }
 
 // ------------------------------------------------------------------ train_fwd1 -------
-// grid (units, nt1); workgroup = 4 waves splitting the feature (K) axis; one 16x16 output tile.
-__global__ __launch_bounds__(256) void train_fwd1_kernel(const float* __restrict__ X, int Fp, int nch,
-                                                         const float* __restrict__ W1t, const float* __restrict__ bias1,
-                                                         int nt1, const int* __restrict__ perm, int B,
-                                                         float* __restrict__ z1) {
-    __shared__ float red[4][256];
+// grid (units, nt1); workgroup = FW1_WAVES waves splitting the feature (K) axis of one 16x16
+// output tile; every wave issues the loads of up to FW1_GROUP chunks before its MFMAs (the step
+// is latency-bound: B rows only), partial tiles are combined through LDS.
+#define FW1_WAVES 8
+#define FW1_GROUP 7
+__global__ __launch_bounds__(FW1_WAVES * 64) void train_fwd1_kernel(const float* __restrict__ X, int Fp, int nch,
+                                                                   const float* __restrict__ W1t,
+                                                                   const float* __restrict__ bias1, int nt1,
+                                                                   const int* __restrict__ perm, int B,
+                                                                   float* __restrict__ z1) {
+    __shared__ float red[FW1_WAVES][256];
     const int unit = blockIdx.x, t = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -54,29 +59,29 @@ __global__ __launch_bounds__(256) void train_fwd1_kernel(const float* __restrict
     const long long xr = perm ? perm[row] : row;
     const float* x = X + xr * (long long)Fp + lq * 4;
     const f32x4* Wp = (const f32x4*)W1t + lane;
-    const int cq = (nch + 3) / 4;
+    const int cq = (nch + FW1_WAVES - 1) / FW1_WAVES;
     const int c0 = wave * cq;
     int c1 = c0 + cq;
     if (c1 > nch) c1 = nch;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    int c = c0;
-#pragma unroll 2
-    for (; c + 1 < c1; c += 2) {
-        const f32x4 xa = *(const f32x4*)(x + c * 16);
-        const f32x4 wa = Wp[(long long)(c * nt1 + t) * 64];
-        const f32x4 xb = *(const f32x4*)(x + (c + 1) * 16);
-        const f32x4 wb = Wp[(long long)((c + 1) * nt1 + t) * 64];
+    for (int c = c0; c < c1; c += FW1_GROUP) {
+        f32x4 xa[FW1_GROUP], wa[FW1_GROUP];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], wa[j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[j], wb[j], acc1, 0, 0, 0);
+        for (int i = 0; i < FW1_GROUP; ++i) {
+            const int ci = (c + i < c1) ? c + i : c1 - 1;
+            xa[i] = *(const f32x4*)(x + ci * 16);
+            wa[i] = Wp[(long long)(ci * nt1 + t) * 64];
         }
-    }
-    if (c < c1) {
-        const f32x4 xa = *(const f32x4*)(x + c * 16);
-        const f32x4 wa = Wp[(long long)(c * nt1 + t) * 64];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], wa[j], acc0, 0, 0, 0);
+        for (int i = 0; i < FW1_GROUP; ++i) {
+            if (c + i < c1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i][j], wa[i][j], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i][j], wa[i][j], acc0, 0, 0, 0);
+                }
+            }
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][lane * 4 + r] = acc0[r] + acc1[r];
@@ -87,7 +92,9 @@ __global__ __launch_bounds__(256) void train_fwd1_kernel(const float* __restrict
         const float bcol = bias1[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v = red[0][lane * 4 + r] + red[1][lane * 4 + r] + red[2][lane * 4 + r] + red[3][lane * 4 + r];
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < FW1_WAVES; ++w) v += red[w][lane * 4 + r];
             z1[(long long)(unit * 16 + lq * 4 + r) * H1p + col] = v + bcol;
         }
     }
@@ -96,8 +103,8 @@ __global__ __launch_bounds__(256) void train_fwd1_kernel(const float* __restrict
 void isk_launch_train_fwd1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, hipStream_t st) {
     const int units = (B + 15) / 16;
     const int nt1 = isk_pad16(s.widths[1]) / 16;
-    hipLaunchKernelGGL(train_fwd1_kernel, dim3(units, nt1), dim3(256), 0, st, b.xhat_xs, b.Fp, b.Fp / 16, b.W1t, b.bias1,
-                       nt1, perm, B, b.a1);
+    hipLaunchKernelGGL(train_fwd1_kernel, dim3(units, nt1), dim3(FW1_WAVES * 64), 0, st, b.xhat_xs, b.Fp, b.Fp / 16, b.W1t,
+                       b.bias1, nt1, perm, B, b.a1);
 }
 
 // ------------------------------------------------------------------ train_tail -------
@@ -112,60 +119,87 @@ __host__ __device__ static inline long long part_size(const TrainShape& s) {
 int isk_train_tail_nblocks(int B) { return (B + 15) / 16; }
 long long isk_train_part_floats(const TrainShape& s, int maxB) { return part_size(s) * isk_train_tail_nblocks(maxB); }
 
+// LDS carve of the tail kernel: [A_0 | Z_0 | A_1 | Z_1 | ... | W_1 | W_2 | ...]; A_l, Z_l are 16 x widths[l+1]
+__host__ __device__ static inline int tail_off_act(const TrainShape& s, int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += 32 * s.widths[i + 1];
+    return o;
+}
+__host__ __device__ static inline int tail_off_w(const TrainShape& s, int l) {
+    int o = tail_off_act(s, s.nlayers);
+    for (int i = 1; i < l; ++i) o += s.widths[i + 1] * s.widths[i];
+    return o;
+}
+
 __global__ __launch_bounds__(256) void train_tail_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm, int B,
                                                          float inv_div) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float lred[4];
     const int L = s.nlayers;
-    const int tid = threadIdx.x, sidx = tid >> 4, t = tid & 15;
+    const int tid = threadIdx.x;
     const int unit = blockIdx.x;
-    const int row = unit * 16 + sidx;
-    const bool valid = row < B;
-    const int rowc = valid ? row : B - 1;
-    const long long prow = perm ? perm[rowc] : rowc;
-    // LDS carve: A[l], Z[l] for l = 0..L-1, each 16 x widths[l+1]
-    float* A[ISK_MAX_LAYERS];
-    float* Z[ISK_MAX_LAYERS];
-    {
-        float* p = sm;
-        for (int l = 0; l < L; ++l) { A[l] = p; p += 16 * s.widths[l + 1]; Z[l] = p; p += 16 * s.widths[l + 1]; }
-    }
     const int H1 = s.widths[1];
     const int H1p = (H1 + 15) & ~15;
-    const int act0 = (L == 1) ? s.lastact : s.act;
-    for (int o = t; o < H1; o += 16) {
-        const float z = b.a1[(long long)row * H1p + o];
-        Z[0][sidx * H1 + o] = z;
-        A[0][sidx * H1 + o] = t_act(act0, z);
+    // stage the tail weights (Flux layout W[o + k*N]) in LDS
+    for (int l = 1; l < L; ++l) {
+        float* Wl = sm + tail_off_w(s, l);
+        const float* Wg = b.theta + s.off_W[l];
+        const int n = s.widths[l + 1] * s.widths[l];
+        for (int e = tid; e < n; e += 256) Wl[e] = Wg[e];
+    }
+    {
+        float* A0 = sm;
+        float* Z0 = sm + 16 * H1;
+        const int act0 = (L == 1) ? s.lastact : s.act;
+        for (int e = tid; e < 16 * H1; e += 256) {
+            const int sidx = e / H1, o = e - sidx * H1;
+            const float z = b.a1[(long long)(unit * 16 + sidx) * H1p + o];
+            Z0[e] = z;
+            A0[e] = t_act(act0, z);
+        }
     }
     __syncthreads();
     for (int l = 1; l < L; ++l) {
         const int K = s.widths[l], N = s.widths[l + 1];
-        const float* W = b.theta + s.off_W[l];
+        const float* Ap = sm + tail_off_act(s, l - 1);
+        float* Al = sm + tail_off_act(s, l);
+        float* Zl = Al + 16 * N;
+        const float* Wl = sm + tail_off_w(s, l);
         const float* bias = b.theta + s.off_b[l];
         const int actl = (l == L - 1) ? s.lastact : s.act;
-        for (int o = t; o < N; o += 16) {
+        for (int p = tid; p < 16 * N; p += 256) {
+            const int sidx = p / N, o = p - sidx * N;
+            const float* arow = Ap + sidx * K;
             float z = bias[o];
-            for (int k = 0; k < K; ++k) z += W[o + (long long)k * N] * A[l - 1][sidx * K + k];
-            Z[l][sidx * N + o] = z;
-            A[l][sidx * N + o] = t_act(actl, z);
+#pragma unroll 4
+            for (int k = 0; k < K; ++k) z += Wl[o + k * N] * arow[k];
+            Zl[p] = z;
+            Al[p] = t_act(actl, z);
         }
         __syncthreads();
     }
-    // loss + delta of the last layer
+    // loss + delta of the last layer (overwrites Z_{L-1})
     const int nout = s.widths[L];
-    const int actL = s.lastact;
     float lsum = 0.f;
-    for (int o = t; o < nout; o += 16) {
-        const float w = b.lossw[o];
-        const float out = A[L - 1][sidx * nout + o];
-        const float r = (out - b.target[prow * nout + o]) * w;
-        float d = 0.f;
-        if (valid) {
-            lsum += r * r;
-            d = 2.f * r * w * inv_div * t_dact(actL, Z[L - 1][sidx * nout + o], out);
+    {
+        float* AL = sm + tail_off_act(s, L - 1);
+        float* ZL = AL + 16 * nout;
+        for (int p = tid; p < 16 * nout; p += 256) {
+            const int sidx = p / nout, o = p - sidx * nout;
+            const int row = unit * 16 + sidx;
+            const bool valid = row < B;
+            const int rowc = valid ? row : B - 1;
+            const long long prow = perm ? perm[rowc] : rowc;
+            const float w = b.lossw[o];
+            const float out = AL[p];
+            const float r = (out - b.target[prow * nout + o]) * w;
+            float d = 0.f;
+            if (valid) {
+                lsum += r * r;
+                d = 2.f * r * w * inv_div * t_dact(s.lastact, ZL[p], out);
+            }
+            ZL[p] = d;
         }
-        Z[L - 1][sidx * nout + o] = d;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, WAVE);
@@ -174,63 +208,72 @@ __global__ __launch_bounds__(256) void train_tail_kernel(TrainShape s, TrainBuff
     float* part = b.part + (long long)unit * part_size(s);
     if (tid == 0) part[0] = lred[0] + lred[1] + lred[2] + lred[3];
     // backward through the tail
-    long long poff = 1 + H1;
-    // offsets of each tail layer inside the partial vector
-    long long poffs[ISK_MAX_LAYERS];
-    for (int l = 1; l < L; ++l) { poffs[l] = poff; poff += (long long)s.widths[l + 1] * s.widths[l] + s.widths[l + 1]; }
     for (int l = L - 1; l >= 1; --l) {
         const int K = s.widths[l], N = s.widths[l + 1];
-        const float* W = b.theta + s.off_W[l];
-        float* pW = part + poffs[l];
+        float* Ap = sm + tail_off_act(s, l - 1);
+        float* Zp = Ap + 16 * K;
+        const float* Zl = sm + tail_off_act(s, l) + 16 * N;
+        const float* Wl = sm + tail_off_w(s, l);
+        long long poff = 1 + H1;
+        for (int i = 1; i < l; ++i) poff += (long long)s.widths[i + 1] * s.widths[i] + s.widths[i + 1];
+        float* pW = part + poff;
         float* pb = pW + (long long)N * K;
         for (int e = tid; e < N * K; e += 256) {
-            const int o = e % N, k = e / N;
+            const int k = e / N, o = e - k * N;
             float acc = 0.f;
-#pragma unroll 4
-            for (int q = 0; q < 16; ++q) acc += Z[l][q * N + o] * A[l - 1][q * K + k];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc += Zl[q * N + o] * Ap[q * K + k];
             pW[e] = acc;
         }
         for (int o = tid; o < N; o += 256) {
             float acc = 0.f;
-            for (int q = 0; q < 16; ++q) acc += Z[l][q * N + o];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc += Zl[q * N + o];
             pb[o] = acc;
         }
-        const int actp = s.act;      // layer l-1 is a hidden layer
-        for (int k = t; k < K; k += 16) {
+        for (int p = tid; p < 16 * K; p += 256) {
+            const int sidx = p / K, k = p - sidx * K;
+            const float* drow = Zl + sidx * N;
             float acc = 0.f;
-            for (int o = 0; o < N; ++o) acc += W[o + (long long)k * N] * Z[l][sidx * N + o];
-            const float zk = Z[l - 1][sidx * K + k];
-            const float ak = A[l - 1][sidx * K + k];
-            // Z[l-1][sidx][k] is read and written by this thread only
-            Z[l - 1][sidx * K + k] = acc * t_dact(actp, zk, ak);
+            for (int o = 0; o < N; ++o) acc += Wl[o + k * N] * drow[o];
+            Zp[p] = acc * t_dact(s.act, Zp[p], Ap[p]);      // read and written by this thread only
         }
         __syncthreads();
     }
     // delta1 -> global (zero padded), D partial
-    for (int o = t; o < H1p; o += 16)
-        b.delta1[(long long)row * H1p + o] = (o < H1) ? Z[0][sidx * H1 + o] : 0.f;
-    for (int o = tid; o < H1; o += 256) {
-        float acc = 0.f;
-        for (int q = 0; q < 16; ++q) acc += Z[0][q * H1 + o];
-        part[1 + o] = acc;
+    {
+        const float* Z0 = sm + 16 * H1;
+        for (int e = tid; e < 16 * H1p; e += 256) {
+            const int sidx = e / H1p, o = e - sidx * H1p;
+            b.delta1[(long long)(unit * 16 + sidx) * H1p + o] = (o < H1) ? Z0[sidx * H1 + o] : 0.f;
+        }
+        for (int o = tid; o < H1; o += 256) {
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc += Z0[q * H1 + o];
+            part[1 + o] = acc;
+        }
     }
 }
 
-static size_t tail_lds_bytes(const TrainShape& s) {
-    size_t n = 0;
-    for (int l = 0; l < s.nlayers; ++l) n += (size_t)2 * 16 * s.widths[l + 1];
-    return n * sizeof(float);
-}
+static size_t tail_lds_bytes(const TrainShape& s) { return (size_t)tail_off_w(s, s.nlayers) * sizeof(float); }
 
 void isk_launch_train_tail(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div,
                            hipStream_t st) {
     const int units = (B + 15) / 16;
-    hipLaunchKernelGGL(train_tail_kernel, dim3(units), dim3(256), tail_lds_bytes(s), st, s, b, perm, B, inv_div);
+    const size_t lds = tail_lds_bytes(s);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)train_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(train_tail_kernel, dim3(units), dim3(256), lds, st, s, b, perm, B, inv_div);
 }
 
 // ------------------------------------------------------------------ train_grad1 ------
-// grid = Fp/16 feature tiles; workgroup = nt1 waves (one per 16-wide output tile).
-// Each wave: Gt[f][o] = sum_n xhat[n][f] * delta1[n][o] over the whole batch (f32 MFMA).
+// grid = Fp/16 feature tiles; workgroup = NW waves that SPLIT THE BATCH ROWS (the step is
+// latency-bound, so every SIMD gets 4 waves of independent gathers); each wave accumulates all
+// NT output tiles:  Gt[f][o] = sum_n xhat[n][f] * delta1[n][o]  (f32 MFMA), the NW partial tiles are
+// combined through LDS, then waves 0..NT-1 run the LayerNorm-affine unfold of their tile.
+// Output-column mapping: tiles are loaded four at a time with one dwordx4 per row, so tile t,
+// lane column li holds o = 64*(t/4) + 4*li + t%4 for the first 4*(NT/4) tiles, 16*t + li after.
 __device__ __forceinline__ long long part_to_grad(const TrainShape& s, long long e) {
     if (e == 0) return s.nparams;                       // loss slot
     e -= 1;
@@ -246,32 +289,32 @@ __device__ __forceinline__ long long part_to_grad(const TrainShape& s, long long
     return -1;
 }
 
-__global__ __launch_bounds__(640) void train_grad1_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm, int B,
-                                                          int nparts) {
+template <int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm,
+                                                             int B, int nparts) {
+    constexpr int NB4 = NT / 4, NR = NT % 4;
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* red = sm;                               // [NW][NT][256]
+    float* Dsh = sm + NW * NT * 256;               // [NT*16]
+    float* red2 = Dsh + NT * 16;                   // [NT][16][2]
     const int H1 = s.widths[1], F = s.widths[0];
-    const int H1p = (H1 + 15) & ~15;
-    const int nt1 = H1p / 16;
-    float* Dsh = sm;                       // [H1p]
-    float* red = sm + H1p;                 // [nt1][16][2]
-    const int tid = threadIdx.x, lane = tid & 63, t = tid >> 6;
+    const int H1p = NT * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int ft = blockIdx.x;
     const long long PS = part_size(s);
     const bool ln = s.layernorm != 0;
-    // phase 0: D (needed by every workgroup when LayerNorm is present)
     if (ln) {
-        for (int o = tid; o < H1p; o += blockDim.x) {
+        for (int o = tid; o < H1p; o += NW * 64) {
             float acc = 0.f;
             if (o < H1)
                 for (int w = 0; w < nparts; ++w) acc += b.part[(long long)w * PS + 1 + o];
             Dsh[o] = acc;
         }
     }
-    // phase 0b: reduce the partial vectors of the small gradients (disjoint elements per thread)
     {
-        const long long gt = (long long)blockIdx.x * blockDim.x + tid;
-        const long long gn = (long long)gridDim.x * blockDim.x;
+        const long long gt = (long long)blockIdx.x * (NW * 64) + tid;
+        const long long gn = (long long)gridDim.x * (NW * 64);
         for (long long e = gt; e < PS; e += gn) {
             float acc = 0.f;
             for (int w = 0; w < nparts; ++w) acc += b.part[(long long)w * PS + e];
@@ -279,57 +322,81 @@ __global__ __launch_bounds__(640) void train_grad1_kernel(TrainShape s, TrainBuf
             if (gi >= 0) b.grad[gi] = acc;
         }
     }
-    // main loop over the batch
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const int Bpad = ((B + 15) / 16) * 16;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nchunks = (B + 15) / 16;
     const float* Xc = b.xhat_xs + ft * 16 + li;
-    const float* Dc = b.delta1 + t * 16 + li;
-    for (int n0 = 0; n0 < Bpad; n0 += 16) {
-        float av[4], bv[4];
+    for (int chunk = wave; chunk < nchunks; chunk += NW) {
+        const int r0 = chunk * 16 + 4 * lq;
+        float av[4];
+        f32x4 bq[4][NB4 > 0 ? NB4 : 1];
+        float br[4][NR > 0 ? NR : 1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int nr = n0 + 4 * j + lq;
-            const int nc = nr < B ? nr : B - 1;
-            const long long rr = perm ? perm[nc] : nc;
+            const int r = r0 + j;
+            const long long rr = (r < B) ? (perm ? perm[r] : r) : 0;    // rows >= B carry delta == 0
             av[j] = Xc[rr * (long long)b.Fp];
-            bv[j] = Dc[(long long)nr * H1p];
+            const float* drow = b.delta1 + (long long)r * H1p;
+#pragma unroll
+            for (int q = 0; q < NB4; ++q) bq[j][q] = *(const f32x4*)(drow + 64 * q + 4 * li);
+#pragma unroll
+            for (int u = 0; u < NR; ++u) br[j][u] = drow[64 * NB4 + 16 * u + li];
         }
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc1, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int q = 0; q < NB4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[4 * q + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bq[j][q][u], acc[4 * q + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < NR; ++u)
+                acc[4 * NB4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], br[j][u], acc[4 * NB4 + u], 0, 0, 0);
+        }
     }
-    __syncthreads();                       // Dsh visible
-    const int o = t * 16 + li;
-    const float* W1 = b.theta + s.off_W[0];
-    const float* g = ln ? b.theta + s.off_lns : nullptr;
-    const float* beta = ln ? b.theta + s.off_lnb : nullptr;
-    float* gW1 = b.grad + s.off_W[0];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int f = ft * 16 + lq * 4 + r;
-        const float G = acc0[r] + acc1[r];
-        float pg = 0.f, pb = 0.f;
-        if (o < H1 && f < F) {
-            if (ln) {
-                const float w = W1[o + (long long)f * H1];
-                const float Do = Dsh[o];
-                gW1[o + (long long)f * H1] = g[f] * G + beta[f] * Do;
-                pg = w * G;
-                pb = w * Do;
-            } else {
-                gW1[o + (long long)f * H1] = G;
-            }
+    for (int t = 0; t < NT; ++t)
+        *(f32x4*)(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
+    __syncthreads();
+    if (wave < NT) {
+        const int t = wave;
+        f32x4 G = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const f32x4 v = *(const f32x4*)(red + ((w * NT + t) * 64 + lane) * 4);
+            G += v;
         }
-        if (ln) {
+        const int o = (t < 4 * NB4) ? 64 * (t >> 2) + 4 * li + (t & 3) : 16 * t + li;
+        const float* W1 = b.theta + s.off_W[0];
+        const float* g = ln ? b.theta + s.off_lns : nullptr;
+        const float* beta = ln ? b.theta + s.off_lnb : nullptr;
+        float* gW1 = b.grad + s.off_W[0];
 #pragma unroll
-            for (int sft = 8; sft > 0; sft >>= 1) {
-                pg += __shfl_xor(pg, sft, WAVE);
-                pb += __shfl_xor(pb, sft, WAVE);
+        for (int r = 0; r < 4; ++r) {
+            const int f = ft * 16 + lq * 4 + r;
+            float pg = 0.f, pb = 0.f;
+            if (o < H1 && f < F) {
+                if (ln) {
+                    const float w = W1[o + (long long)f * H1];
+                    const float Do = Dsh[o];
+                    gW1[o + (long long)f * H1] = g[f] * G[r] + beta[f] * Do;
+                    pg = w * G[r];
+                    pb = w * Do;
+                } else {
+                    gW1[o + (long long)f * H1] = G[r];
+                }
             }
-            if (li == 0) {
-                red[(t * 16 + lq * 4 + r) * 2 + 0] = pg;
-                red[(t * 16 + lq * 4 + r) * 2 + 1] = pb;
+            if (ln) {
+#pragma unroll
+                for (int sft = 8; sft > 0; sft >>= 1) {
+                    pg += __shfl_xor(pg, sft, WAVE);
+                    pb += __shfl_xor(pb, sft, WAVE);
+                }
+                if (li == 0) {
+                    red2[(t * 16 + lq * 4 + r) * 2 + 0] = pg;
+                    red2[(t * 16 + lq * 4 + r) * 2 + 1] = pb;
+                }
             }
         }
     }
@@ -339,7 +406,7 @@ __global__ __launch_bounds__(640) void train_grad1_kernel(TrainShape s, TrainBuf
             const int f = ft * 16 + tid;
             if (f < F) {
                 float sg = 0.f, sb = 0.f;
-                for (int w = 0; w < nt1; ++w) { sg += red[(w * 16 + tid) * 2]; sb += red[(w * 16 + tid) * 2 + 1]; }
+                for (int w = 0; w < NT; ++w) { sg += red2[(w * 16 + tid) * 2]; sb += red2[(w * 16 + tid) * 2 + 1]; }
                 b.grad[s.off_lns + f] = sg;
                 b.grad[s.off_lnb + f] = sb;
             }
@@ -347,12 +414,29 @@ __global__ __launch_bounds__(640) void train_grad1_kernel(TrainShape s, TrainBuf
     }
 }
 
-void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int, hipStream_t st) {
-    const int H1p = isk_pad16(s.widths[1]);
-    const int nt1 = H1p / 16;
+template <int NT, int NW>
+static void launch_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, hipStream_t st) {
     const int nparts = (B + 15) / 16;
-    const size_t lds = (size_t)(H1p + nt1 * 16 * 2) * sizeof(float);
-    hipLaunchKernelGGL(train_grad1_kernel, dim3(b.Fp / 16), dim3(64 * nt1), lds, st, s, b, perm, B, nparts);
+    const size_t lds = (size_t)(NW * NT * 256 + NT * 16 + NT * 32) * sizeof(float);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)train_grad1_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((train_grad1_kernel<NT, NW>), dim3(b.Fp / 16), dim3(NW * 64), lds, st, s, b, perm, B, nparts);
+}
+
+void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int, hipStream_t st) {
+    const int nt1 = isk_pad16(s.widths[1]) / 16;
+    switch (nt1) {
+        case 1: launch_grad1<1, 16>(s, b, perm, B, st); break;
+        case 2: launch_grad1<2, 16>(s, b, perm, B, st); break;
+        case 3: launch_grad1<3, 16>(s, b, perm, B, st); break;
+        case 4: launch_grad1<4, 16>(s, b, perm, B, st); break;
+        case 5: launch_grad1<5, 16>(s, b, perm, B, st); break;
+        case 6: launch_grad1<6, 16>(s, b, perm, B, st); break;
+        case 7: launch_grad1<7, 16>(s, b, perm, B, st); break;
+        case 8: launch_grad1<8, 16>(s, b, perm, B, st); break;
+        case 9: launch_grad1<9, 16>(s, b, perm, B, st); break;
+        default: launch_grad1<10, 8>(s, b, perm, B, st); break;
+    }
 }
 
 // ------------------------------------------------------------------ opt_step ---------
