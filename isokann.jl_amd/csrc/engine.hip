@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -96,6 +97,11 @@ struct isk_engine {
     long long off_W[ISK_MAX_LAYERS], off_b[ISK_MAX_LAYERS];
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // side stream: the (weight-independent) ys featurization of the NEXT iteration runs here,
+    // concurrently with the latency-bound training kernels of the current one
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fwd_done = nullptr, ev_ys_ready = nullptr;
+    bool ys_ahead = false;       // a side-stream featurization of ys is in flight / complete
     // parameters
     float *d_theta = nullptr, *d_grad = nullptr, *d_m = nullptr, *d_v = nullptr;
     float* d_Wt[ISK_MAX_LAYERS] = {nullptr};
@@ -109,7 +115,8 @@ struct isk_engine {
     // data
     long long N = 0, K = 0, D = 0;
     float *d_in_xs = nullptr, *d_in_ys = nullptr;   // raw coords / raw features
-    float* d_xhat = nullptr;                         // [(N*K + N)][Fp]  ys rows first, then xs rows
+    float* d_xhat = nullptr;                         // CURRENT [(N*K + N)][Fp] buffer: ys rows first, then xs rows
+    float* d_xhat_alt = nullptr;                     // the other buffer of the pair (per-iteration featurize mode)
     float* d_out = nullptr;                          // [(N*K + N)][nout]
     float *d_ks = nullptr, *d_target = nullptr, *d_lossw = nullptr;
     bool have_target = false, have_ks = false;
@@ -129,9 +136,11 @@ struct isk_engine {
 static void free_dev(void* p) { if (p) (void)hipFree(p); }
 
 static void free_data(isk_engine* e) {
-    free_dev(e->d_in_xs); free_dev(e->d_in_ys); free_dev(e->d_xhat); free_dev(e->d_out); free_dev(e->d_ks);
+    if (e->side) (void)hipStreamSynchronize(e->side);
+    e->ys_ahead = false;
+    free_dev(e->d_in_xs); free_dev(e->d_in_ys); free_dev(e->d_xhat); free_dev(e->d_xhat_alt); free_dev(e->d_out); free_dev(e->d_ks);
     free_dev(e->d_target); free_dev(e->d_z1); free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm);
-    e->d_in_xs = e->d_in_ys = e->d_xhat = e->d_out = e->d_ks = e->d_target = e->d_z1 = e->d_delta1 = e->d_part = nullptr;
+    e->d_in_xs = e->d_in_ys = e->d_xhat = e->d_xhat_alt = e->d_out = e->d_ks = e->d_target = e->d_z1 = e->d_delta1 = e->d_part = nullptr;
     e->d_perm = nullptr;
     e->N = e->K = e->D = 0;
     e->have_target = e->have_ks = false;
@@ -160,17 +169,17 @@ static void shuffle_perm(isk_engine* e, std::vector<int32_t>& p) {
 
 // ---- timers ---------------------------------------------------------------------------
 struct ScopedTimer {
-    isk_engine* e; EventPair ep; bool on;
-    ScopedTimer(isk_engine* e_, int id) : e(e_), on(e_->timers_on) {
+    isk_engine* e; EventPair ep; bool on; hipStream_t st;
+    ScopedTimer(isk_engine* e_, int id, hipStream_t s = nullptr) : e(e_), on(e_->timers_on), st(s ? s : e_->stream) {
         if (!on) return;
         if (!e->ev_free.empty()) { ep = e->ev_free.back(); e->ev_free.pop_back(); }
         else { (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b); }
         ep.id = id;
-        (void)hipEventRecord(ep.a, e->stream);
+        (void)hipEventRecord(ep.a, st);
     }
     ~ScopedTimer() {
         if (!on) return;
-        (void)hipEventRecord(ep.b, e->stream);
+        (void)hipEventRecord(ep.b, st);
         e->ev_live.push_back(ep);
     }
 };
@@ -205,6 +214,8 @@ static MlpFwdArgs fwd_args(const isk_engine* e, const float* X, long long S, flo
         t.ntiles = isk_pad16(e->cfg.widths[l + 1]) / 16;
         t.act = act_of_layer(e, l);
         t.width = e->cfg.widths[l + 1];
+        t.lds_off = a.tailw_floats;
+        a.tailw_floats += t.kchunks * t.ntiles * 256;
     }
     // scratch A holds the outputs of layers 0,2,4,..; scratch B of layers 1,3,..
     for (int l = 0; l < e->L - 1; ++l) {
@@ -322,6 +333,12 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     hipError_t se = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete e; return fail(ISK_EHIP, hipGetErrorString(se)); }
     e->own_stream = true;
+    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_fwd_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_ys_ready, hipEventDisableTiming) != hipSuccess) {
+        isk_destroy(e);
+        return fail(ISK_EHIP, "side stream / event creation failed");
+    }
     const size_t pb = (size_t)(e->nparams + 2) * sizeof(float);
     ALLOC(e->d_theta, pb); ALLOC(e->d_grad, pb); ALLOC(e->d_m, pb); ALLOC(e->d_v, pb);
     ALLOC(e->d_loss_acc, 2 * sizeof(double)); ALLOC(e->d_status, sizeof(int)); ALLOC(e->d_mm, 2 * sizeof(float));
@@ -347,6 +364,11 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     (void)hipMemset(e->d_loss_acc, 0, 2 * sizeof(double)); (void)hipMemset(e->d_status, 0, sizeof(int));
     std::vector<float> ones(nout, 1.0f);
     (void)hipMemcpy(e->d_lossw, ones.data(), nout * sizeof(float), hipMemcpyHostToDevice);
+    {
+        const MlpFwdArgs fa = fwd_args(e, nullptr, 0, nullptr);
+        const size_t lds = ((size_t)fa.tailw_floats + (size_t)4 * 16 * (fa.stride_a + fa.stride_b)) * sizeof(float);
+        if (lds > 150 * 1024) { isk_destroy(e); return fail(ISK_EUNSUPPORTED, "tail layers too wide for the LDS-resident fused forward kernel"); }
+    }
     launch_fold(e);
     (void)hipStreamSynchronize(e->stream);
     *out = e;
@@ -357,6 +379,7 @@ extern "C" void isk_destroy(isk_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->side) (void)hipStreamSynchronize(e->side);
     free_data(e);
     free_dev(e->d_theta); free_dev(e->d_grad); free_dev(e->d_m); free_dev(e->d_v);
     free_dev(e->d_loss_acc); free_dev(e->d_status); free_dev(e->d_mm); free_dev(e->d_lossw);
@@ -364,6 +387,9 @@ extern "C" void isk_destroy(isk_engine* e) {
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_Wt[l]); free_dev(e->d_bias[l]); }
     drain_timers(e);
     for (auto& ep : e->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    if (e->ev_fwd_done) (void)hipEventDestroy(e->ev_fwd_done);
+    if (e->ev_ys_ready) (void)hipEventDestroy(e->ev_ys_ready);
+    if (e->side) (void)hipStreamDestroy(e->side);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -441,17 +467,47 @@ extern "C" int isk_reset_opt_state(isk_engine* e) {
 // ---------------------------------------------------------------------------------------
 // data
 // ---------------------------------------------------------------------------------------
-static void featurize_rows(isk_engine* e, const float* in, long long S, float* xhat) {
+static void featurize_rows(isk_engine* e, const float* in, long long S, float* xhat, hipStream_t st = nullptr) {
     FeatArgs a;
     a.in = in; a.pairs = e->d_pairs; a.packed_pairs = e->d_packed; a.xhat = xhat; a.S = S; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
-    isk_launch_featurize(a, e->stream);
+    isk_launch_featurize(a, st ? st : e->stream);
 }
 
+// per-iteration featurization.  ys (the 95 % share) may already have been produced on the side
+// stream, into the other buffer of the pair, while the previous iteration's MFMA-bound forward was
+// running; then the main stream only waits for it and swaps buffers.
 static void featurize_resident(isk_engine* e) {
+    if (e->ys_ahead) {
+        (void)hipStreamWaitEvent(e->stream, e->ev_ys_ready, 0);
+        std::swap(e->d_xhat, e->d_xhat_alt);
+        e->ys_ahead = false;
+    } else {
+        ScopedTimer t(e, ISK_T_FEATURIZE);
+        featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat);
+    }
     ScopedTimer t(e, ISK_T_FEATURIZE);
-    featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat);
     featurize_rows(e, e->d_in_xs, e->N, e->d_xhat + (long long)e->N * e->K * e->Fp);
+}
+
+// Called right after this iteration's forward has been enqueued on the main stream: featurize ys for
+// the NEXT iteration on the side stream into the other buffer.  The featurizer is HBM-bound, the
+// forward f32-MFMA-bound, so the two share the chip.  `ev_main_point` (recorded before the forward)
+// orders the write after every earlier reader of that buffer.
+static void featurize_ys_ahead(isk_engine* e) {
+    // Measured on MI355X (round 1): co-running the HBM-bound featurizer with the MFMA-bound forward
+    // slows the forward from 0.83 to 1.5 ms (the featurizer's streaming evicts the L2-resident
+    // weights and saturates the memory queues), a net loss against running them back to back.
+    // Kept behind ISK_OVERLAP_FEATURIZE=1 for further tuning.
+    static const bool on = [] { const char* v = getenv("ISK_OVERLAP_FEATURIZE"); return v && atoi(v) != 0; }();
+    if (!on || !e->d_xhat_alt) return;
+    (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
+    {
+        ScopedTimer t(e, ISK_T_FEATURIZE, e->side);
+        featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat_alt, e->side);
+    }
+    (void)hipEventRecord(e->ev_ys_ready, e->side);
+    e->ys_ahead = true;
 }
 
 static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_t D, int64_t K, int64_t N, hipMemcpyKind kind) {
@@ -469,6 +525,7 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
     HIPCHK(hipMalloc((void**)&e->d_in_xs, (size_t)N * D * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_in_ys, (size_t)N * K * D * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_xhat, (size_t)S * e->Fp * sizeof(float)));
+    if (e->cfg.featurize_every_iteration) HIPCHK(hipMalloc((void**)&e->d_xhat_alt, (size_t)S * e->Fp * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_out, (size_t)S * e->nout * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_ks, (size_t)N * e->nout * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_target, (size_t)N * e->nout * sizeof(float)));
@@ -573,7 +630,7 @@ static int need_data(isk_engine* e) {
 }
 
 // which: 1 = ys rows, 2 = xs rows, 3 = both (single launch over the contiguous slab)
-static int forward_resident(isk_engine* e, int which) {
+static int forward_resident(isk_engine* e, int which, bool ahead = false) {
     const long long nys = e->N * e->K;
     const float* X = e->d_xhat;
     float* out = e->d_out;
@@ -581,9 +638,13 @@ static int forward_resident(isk_engine* e, int which) {
     int tid = ISK_T_FWD_YS;
     if (which == 1) S = nys;
     if (which == 2) { X += nys * e->Fp; out += nys * e->nout; S = e->N; tid = ISK_T_FWD_XS; }
-    ScopedTimer t(e, tid);
-    MlpFwdArgs f = fwd_args(e, X, S, out);
-    if (isk_launch_mlp_fwd(f, e->stream) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
+    if (ahead) (void)hipEventRecord(e->ev_fwd_done, e->stream);
+    {
+        ScopedTimer t(e, tid);
+        MlpFwdArgs f = fwd_args(e, X, S, out);
+        if (isk_launch_mlp_fwd(f, e->stream) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
+    }
+    if (ahead) featurize_ys_ahead(e);
     return ISK_OK;
 }
 
@@ -812,10 +873,10 @@ static int check_status(isk_engine* e) {
 }
 
 // computes the target on the device-resident data; leaves target + loss weights on the device
-static int compute_target(isk_engine* e, bool check) {
+static int compute_target(isk_engine* e, bool check, bool ahead = false) {
     const int d = e->nout;
     if (e->cfg.target_kind == ISK_TARGET_SHIFTSCALE) {
-        CHK(forward_resident(e, 1));
+        CHK(forward_resident(e, 1, ahead));
         ScopedTimer t(e, ISK_T_TARGET);
         launch_kmean(e);
         isk_launch_minmax(e->d_ks, e->N, e->d_mm, e->stream);
@@ -825,7 +886,7 @@ static int compute_target(isk_engine* e, bool check) {
         return ISK_OK;
     }
     // ISA: chi = model(xs), ks = E[model(ys)] in one launch over the contiguous slab
-    CHK(forward_resident(e, 3));
+    CHK(forward_resident(e, 3, ahead));
     ScopedTimer t(e, ISK_T_TARGET);
     launch_kmean(e);
     std::vector<float> ks((size_t)e->N * d), chi((size_t)e->N * d);
@@ -953,7 +1014,7 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
     for (int it = 0; it < n; ++it) {
         if (e->cfg.featurize_every_iteration) featurize_resident(e);
         // the constant-chi check needs the device status word; it is read together with the loss
-        CHK(compute_target(e, false));
+        CHK(compute_target(e, false, e->cfg.featurize_every_iteration != 0));
         for (int ep = 0; ep < epochs; ++ep) {
             double l = 0;
             const int32_t* p = perms ? perms + k * e->N : nullptr;
@@ -981,7 +1042,7 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
 extern "C" int isk_dp_koopman_local(isk_engine* e) {
     CHK(need_data(e));
     if (e->cfg.featurize_every_iteration) featurize_resident(e);
-    CHK(forward_resident(e, e->cfg.target_kind == ISK_TARGET_ISA ? 3 : 1));
+    CHK(forward_resident(e, e->cfg.target_kind == ISK_TARGET_ISA ? 3 : 1, e->cfg.featurize_every_iteration != 0));
     ScopedTimer t(e, ISK_T_TARGET);
     launch_kmean(e);
     return ISK_OK;

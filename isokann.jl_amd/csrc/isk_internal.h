@@ -35,6 +35,7 @@ struct TailLayer {
     const float* Wt;        // fragment-linear, [kchunks][ntiles][64][4]
     const float* bias;      // [ntiles*16], zero padded
     int kchunks, ntiles, act, width;
+    int lds_off;            // float offset of this layer's weights inside the workgroup's LDS copy
 };
 struct MlpFwdArgs {
     const float* X;         // [S][Fp] standardised features (row-major, zero padded)
@@ -48,6 +49,7 @@ struct MlpFwdArgs {
     TailLayer tail[ISK_MAX_LAYERS];
     float* out;             // [S][nout]
     int nout;
+    int tailw_floats;       // total floats of tail weights staged in LDS
     int stride_a, stride_b; // floats per row of the two per-wave LDS ping-pong buffers (padded width + 4)
 };
 int  isk_launch_mlp_fwd(const MlpFwdArgs& a, hipStream_t st);   // returns 0 or ISK_EUNSUPPORTED

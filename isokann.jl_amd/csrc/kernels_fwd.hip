@@ -260,62 +260,83 @@ void isk_launch_featurize(const FeatArgs& a, hipStream_t st) {
 // standardised rows directly.
 // =====================================================================================
 __global__ __launch_bounds__(256) void fold_kernel(FoldArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];     // [16][Np + 1]
     const int layer = blockIdx.y;
     if (layer >= a.nlayers) return;
     const int K = a.widths[layer], N = a.widths[layer + 1];
     const int Kp = (K + 15) & ~15, Np = (N + 15) & ~15;
-    const int nt = Np / 16;
+    const int nt = Np / 16, nchunks = Kp / 16;
     const float* W = a.theta + a.off_W[layer];
     const float* b = a.theta + a.off_b[layer];
     const bool ln = (layer == 0 && a.off_lns >= 0);
     const float* g = ln ? a.theta + a.off_lns : nullptr;
     const float* beta = ln ? a.theta + a.off_lnb : nullptr;
-    const long long total = (long long)Kp * Np;
-    float* Wt = a.Wt[layer];
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int j = e & 3;
-        const int lane = (e >> 2) & 63;
-        const long long ct = e >> 8;
-        const int t = (int)(ct % nt);
-        const int c = (int)(ct / nt);
-        const int o = t * 16 + (lane & 15);
-        const int k = c * 16 + 4 * (lane >> 4) + j;
-        float v = 0.f;
-        if (o < N && k < K) {
-            v = W[o + (long long)k * N];
-            if (ln) v *= g[k];
-        }
-        Wt[e] = v;
-    }
-    // bias: one wave per output row, waves strided over the whole grid.x
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    for (int o = gw; o < Np; o += gridDim.x * 4) {
-        float v = 0.f;
-        if (o < N) {
-            if (ln) {
-                float s = 0.f;
-                for (int k = lane; k < K; k += WAVE) s += W[o + (long long)k * N] * beta[k];
-                s = wave_sum(s);
-                v = b[o] + s;
-            } else {
-                v = b[o];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < nchunks) {
+        // one 16-feature chunk: coalesced read of W[:, 16c .. 16c+15] (Flux layout: o fastest),
+        // LDS transpose, coalesced write of the chunk's nt fragment-linear KiB
+        const int c = blockIdx.x;
+        const int ld = Np + 1;
+        const int nel = 16 * N;
+        const float* Wc = W + (long long)c * 16 * N;
+        for (int e0 = 0; e0 < nel; e0 += 256 * 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * 256 + tid;
+                const int kl = e / N;
+                v[u] = (e < nel && c * 16 + kl < K) ? Wc[e] * (ln ? g[c * 16 + kl] : 1.f) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * 256 + tid;
+                if (e < nel) { const int kl = e / N; tile[kl * ld + (e - kl * N)] = v[u]; }
             }
         }
-        if (lane == 0) a.bias[layer][o] = v;
+        __syncthreads();
+        float* Wt = a.Wt[layer] + (long long)c * nt * 256;
+        for (int idx = tid; idx < nt * 256; idx += 256) {
+            const int j = idx & 3, lane = (idx >> 2) & 63, t = idx >> 8;
+            const int o = t * 16 + (lane & 15), kl = 4 * (lane >> 4) + j;
+            Wt[idx] = (o < N) ? tile[kl * ld + o] : 0.f;
+        }
+        return;
     }
+    // bias blocks: one wave per output row
+    const int lane = tid & 63;
+    const int o = ((int)blockIdx.x - nchunks) * 4 + (tid >> 6);
+    if (o >= Np) return;
+    float v = 0.f;
+    if (o < N) {
+        v = b[o];
+        if (ln) {
+            float sacc = 0.f;
+            for (int k0 = 0; k0 < K; k0 += 64 * 8) {
+                float wv[8], bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * 64 + lane;
+                    wv[u] = (k < K) ? W[o + (long long)k * N] : 0.f;
+                    bv[u] = (k < K) ? beta[k] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sacc += wv[u] * bv[u];
+            }
+            v += wave_sum(sacc);
+        }
+    }
+    if (lane == 0) a.bias[layer][o] = v;
 }
 
 void isk_launch_fold(const FoldArgs& a, hipStream_t st) {
-    int maxel = 0;
+    int bx = 1, maxNp = 16;
     for (int l = 0; l < a.nlayers; ++l) {
-        int e = isk_pad16(a.widths[l]) * isk_pad16(a.widths[l + 1]);
-        if (e > maxel) maxel = e;
+        const int Kp = isk_pad16(a.widths[l]), Np = isk_pad16(a.widths[l + 1]);
+        bx = bx > (Kp / 16 + Np / 4) ? bx : (Kp / 16 + Np / 4);
+        maxNp = maxNp > Np ? maxNp : Np;
     }
-    int bx = (maxel + 255) / 256;
-    if (bx > 1024) bx = 1024;
-    if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(fold_kernel, dim3(bx, a.nlayers), dim3(256), 0, st, a);
+    const size_t lds = (size_t)16 * (maxNp + 1) * sizeof(float);
+    hipLaunchKernelGGL(fold_kernel, dim3(bx, a.nlayers), dim3(256), lds, st, a);
 }
 
 // =====================================================================================
@@ -333,69 +354,99 @@ void isk_launch_fold(const FoldArgs& a, hipStream_t st) {
 // Bound: f32 MFMA (2*Fp*H1p flop per sample vs 4*Fp bytes).
 // =====================================================================================
 template <int NT>
-struct Frags {
+struct WFrags {
     f32x4 w[NT];
+};
+struct XFrags {
     f32x4 x0, x1;
 };
 
-template <int NT, bool TWO>
-__device__ __forceinline__ void load_frags(Frags<NT>& f, const f32x4* __restrict__ Wp, const float* __restrict__ x0,
-                                           const float* __restrict__ x1, int c) {
-    f.x0 = *(const f32x4*)(x0 + c * 16);
-    if (TWO) f.x1 = *(const f32x4*)(x1 + c * 16);
+template <int NT>
+__device__ __forceinline__ void load_w(WFrags<NT>& f, const f32x4* __restrict__ Wp, int c) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) f.w[t] = Wp[(long long)(c * NT + t) * 64];
 }
+template <bool TWO>
+__device__ __forceinline__ void load_x(XFrags& f, const float* __restrict__ x0, const float* __restrict__ x1, int c) {
+    f.x0 = *(const f32x4*)(x0 + c * 16);
+    if (TWO) f.x1 = *(const f32x4*)(x1 + c * 16);
+}
 
 template <int NT, bool TWO>
-__device__ __forceinline__ void mma_frags(const Frags<NT>& f, f32x4 (&acc0)[NT], f32x4 (&acc1)[NT]) {
+__device__ __forceinline__ void mma_frags(const XFrags& x, const WFrags<NT>& f, f32x4 (&acc0)[NT], f32x4 (&acc1)[NT]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x0[j], f.w[t][j], acc0[t], 0, 0, 0);
-            if (TWO) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x1[j], f.w[t][j], acc1[t], 0, 0, 0);
+            acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x0[j], f.w[t][j], acc0[t], 0, 0, 0);
+            if (TWO) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x1[j], f.w[t][j], acc1[t], 0, 0, 0);
         }
     }
 }
 
+// Layer-1 GEMM of one pass.  Two prefetch distances: the sample fragments come from HBM and are
+// fetched XPF chunks ahead (8 VGPRs per chunk in flight), the weight fragments are L2-resident and
+// double-buffered (one chunk ahead, 4*NT VGPRs each).  The sched_barriers pin "issue the loads,
+// THEN run this chunk's MFMAs": without them hipcc sinks the loads below the MFMA block (to save
+// registers) and waits vmcnt(0) right after issuing them, exposing the memory latency every chunk.
 template <int NT, bool TWO>
 __device__ __forceinline__ void layer1_gemm(const MlpFwdArgs& a, const float* x0, const float* x1, int lane,
                                             f32x4 (&acc0)[NT], f32x4 (&acc1)[NT]) {
+    constexpr int XPF = 5;                        // sample fragments: 5 chunks ahead, ring of 6
+    constexpr int WPF = 2;                        // weight fragments: 2 chunks ahead, ring of 3
+    constexpr int UNR = 6;                        // lcm(XPF + 1, WPF + 1): ring slots are compile-time
     const f32x4* Wp = (const f32x4*)a.W1t + lane;
     const int nch = a.nchunks;
-    Frags<NT> fa, fb;
-    load_frags<NT, TWO>(fa, Wp, x0, x1, 0);
-    // Register double buffer.  The sched_barriers pin "issue the next chunk's loads, THEN run this
-    // chunk's MFMAs": without them hipcc sinks the loads below the MFMA block (to save registers)
-    // and waits vmcnt(0) right after issuing them, exposing the full memory latency every chunk.
-    for (int c = 0; c < nch; c += 2) {
-        const int c1 = (c + 1 < nch) ? c + 1 : nch - 1;
-        load_frags<NT, TWO>(fb, Wp, x0, x1, c1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_frags<NT, TWO>(fa, acc0, acc1);
-        __builtin_amdgcn_sched_barrier(0);
-        const int c2 = (c + 2 < nch) ? c + 2 : nch - 1;
-        load_frags<NT, TWO>(fa, Wp, x0, x1, c2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nch) mma_frags<NT, TWO>(fb, acc0, acc1);
-        __builtin_amdgcn_sched_barrier(0);
+    const int last = nch - 1;
+    XFrags xr[XPF + 1];
+    WFrags<NT> w[WPF + 1];
+#pragma unroll
+    for (int i = 0; i < XPF; ++i) load_x<TWO>(xr[i], x0, x1, i < last ? i : last);
+#pragma unroll
+    for (int i = 0; i < WPF; ++i) load_w<NT>(w[i], Wp, i < last ? i : last);
+    for (int c = 0; c < nch; c += UNR) {
+#pragma unroll
+        for (int s = 0; s < UNR; ++s) {
+            const int cc = c + s;
+            load_x<TWO>(xr[(s + XPF) % (XPF + 1)], x0, x1, cc + XPF < last ? cc + XPF : last);
+            load_w<NT>(w[(s + WPF) % (WPF + 1)], Wp, cc + WPF < last ? cc + WPF : last);
+            __builtin_amdgcn_sched_barrier(0);
+            if (cc < nch) mma_frags<NT, TWO>(xr[s % (XPF + 1)], w[s % (WPF + 1)], acc0, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
 // epilogue + tail layers for one 16-row unit whose layer-1 pre-activations sit in acc[NT]
 template <int NT>
 __device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT], long long row_base, float* scrA,
-                                          float* scrB, int lane) {
+                                          float* scrB, const float* tailw, int lane) {
     const int li = lane & 15, lq = lane >> 4;
     int stride = a.stride_a;
-    // accumulator layout (row = 4*lq + r, col = 16*t + li) -> LDS rows; bias added on the way
+    const bool fast_sig = (a.act1 == ISK_ACT_SIGMOID) && a.ntail > 0;    // wave-uniform
+    // accumulator layout (row = 4*lq + r, col = 16*t + li) -> LDS rows; bias (and, on the common
+    // sigmoid path, the activation) applied on the way, in registers
+    if (fast_sig) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int col = t * 16 + li;
-        const float bcol = a.bias1[col];
+        for (int t = 0; t < NT; ++t) {
+            const int col = t * 16 + li;
+            const float bcol = a.bias1[col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) scrA[(lq * 4 + r) * stride + col] = acc[t][r] + bcol;
+            for (int r = 0; r < 4; ++r) {
+                const float z = acc[t][r] + bcol;
+                const float e = __expf(-fabsf(z));
+                const float q = __builtin_amdgcn_rcpf(1.0f + e);
+                scrA[(lq * 4 + r) * stride + col] = z >= 0.f ? q : e * q;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = t * 16 + li;
+            const float bcol = a.bias1[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scrA[(lq * 4 + r) * stride + col] = acc[t][r] + bcol;
+        }
     }
     __builtin_amdgcn_wave_barrier();
     const int H1p = NT * 16;
@@ -413,16 +464,18 @@ __device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT],
         __builtin_amdgcn_wave_barrier();
         return;
     }
-    for (int row = 0; row < 16; ++row)
-        for (int col = lane; col < H1p; col += WAVE) scrA[row * stride + col] = act_apply(a.act1, scrA[row * stride + col]);
-    __builtin_amdgcn_wave_barrier();
+    if (!fast_sig) {
+        for (int row = 0; row < 16; ++row)
+            for (int col = lane; col < H1p; col += WAVE) scrA[row * stride + col] = act_apply(a.act1, scrA[row * stride + col]);
+        __builtin_amdgcn_wave_barrier();
+    }
     float* in = scrA;
     float* ob = scrB;
     int ostride = a.stride_b;
     for (int l = 0; l < a.ntail; ++l) {
         const TailLayer L = a.tail[l];
         const bool last = (l == a.ntail - 1);
-        const f32x4* Wp = (const f32x4*)L.Wt + lane;
+        const f32x4* Wp = (const f32x4*)(tailw + L.lds_off) + lane;     // staged once per workgroup
         for (int t2 = 0; t2 < L.ntiles; ++t2) {
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             for (int c = 0; c < L.kchunks; ++c) {
@@ -455,8 +508,17 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a, long long un
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    float* scrA = smem + (size_t)wave * 16 * (a.stride_a + a.stride_b);
+    float* scrA = smem + a.tailw_floats + (size_t)wave * 16 * (a.stride_a + a.stride_b);
     float* scrB = scrA + 16 * a.stride_a;
+    // stage the (small) fragment-linear tail weights in LDS once: the per-unit tail then never waits on L2
+    for (int l = 0; l < a.ntail; ++l) {
+        const int n4 = a.tail[l].kchunks * a.tail[l].ntiles * 64;
+        const f32x4* src = (const f32x4*)a.tail[l].Wt;
+        f32x4* dst = (f32x4*)(smem + a.tail[l].lds_off);
+        for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(3);                 // MFMA waves win issue arbitration over co-resident streaming kernels
     const long long gw = (long long)blockIdx.x * 4 + wave;
     long long u = gw * units_per_wave;
     long long uend = u + units_per_wave;
@@ -474,8 +536,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a, long long un
         for (int t = 0; t < NT; ++t) { acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         if (two) layer1_gemm<NT, true>(a, x0, x1, lane, acc0, acc1);
         else layer1_gemm<NT, false>(a, x0, x1, lane, acc0, acc1);
-        unit_tail<NT>(a, acc0, u * 16, scrA, scrB, lane);
-        if (two) unit_tail<NT>(a, acc1, (u + 1) * 16, scrA, scrB, lane);
+        unit_tail<NT>(a, acc0, u * 16, scrA, scrB, smem, lane);
+        if (two) unit_tail<NT>(a, acc1, (u + 1) * 16, scrA, scrB, smem, lane);
     }
 }
 
@@ -488,7 +550,7 @@ static void launch_fwd_nt(const MlpFwdArgs& a, hipStream_t st) {
     if (upw < 1) upw = 1;
     const long long nwaves = (units + upw - 1) / upw;
     const long long blocks = (nwaves + 3) / 4;
-    const size_t lds = (size_t)4 * 16 * (a.stride_a + a.stride_b) * sizeof(float);
+    const size_t lds = ((size_t)a.tailw_floats + (size_t)4 * 16 * (a.stride_a + a.stride_b)) * sizeof(float);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(mlp_fwd_kernel<NT>, dim3((unsigned)blocks), dim3(256), lds, st, a, units, upw);

@@ -44,14 +44,18 @@ __device__ __forceinline__ float t_dact(int act, float z, float a) {
 // output tile; every wave issues the loads of up to FW1_GROUP chunks before its MFMAs (the step
 // is latency-bound: B rows only), partial tiles are combined through LDS.
 #define FW1_WAVES 8
-#define FW1_GROUP 7
+#define FW1_GROUP 14
 __global__ __launch_bounds__(FW1_WAVES * 64) void train_fwd1_kernel(const float* __restrict__ X, int Fp, int nch,
                                                                    const float* __restrict__ W1t,
                                                                    const float* __restrict__ bias1, int nt1,
                                                                    const int* __restrict__ perm, int B,
                                                                    float* __restrict__ z1) {
     __shared__ float red[FW1_WAVES][256];
-    const int unit = blockIdx.x, t = blockIdx.y;
+    // blocks are dealt round-robin over the 8 XCDs (b % 8 shares an XCD): give every XCD whole units,
+    // so a unit's gathered xhat rows are fetched into ONE L2 and re-read there by its nt1 tile blocks
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int unit = xcd + 8 * (slot / nt1), t = slot % nt1;
+    if (unit * 16 >= B) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
     int row = unit * 16 + li;
@@ -59,6 +63,7 @@ __global__ __launch_bounds__(FW1_WAVES * 64) void train_fwd1_kernel(const float*
     const long long xr = perm ? perm[row] : row;
     const float* x = X + xr * (long long)Fp + lq * 4;
     const f32x4* Wp = (const f32x4*)W1t + lane;
+    const float bcol = bias1[t * 16 + li];               // issued early, consumed by wave 0 at the end
     const int cq = (nch + FW1_WAVES - 1) / FW1_WAVES;
     const int c0 = wave * cq;
     int c1 = c0 + cq;
@@ -89,7 +94,6 @@ __global__ __launch_bounds__(FW1_WAVES * 64) void train_fwd1_kernel(const float*
     if (wave == 0) {
         const int H1p = nt1 * 16;
         const int col = t * 16 + li;
-        const float bcol = bias1[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = 0.f;
@@ -103,13 +107,15 @@ __global__ __launch_bounds__(FW1_WAVES * 64) void train_fwd1_kernel(const float*
 void isk_launch_train_fwd1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, hipStream_t st) {
     const int units = (B + 15) / 16;
     const int nt1 = isk_pad16(s.widths[1]) / 16;
-    hipLaunchKernelGGL(train_fwd1_kernel, dim3(units, nt1), dim3(FW1_WAVES * 64), 0, st, b.xhat_xs, b.Fp, b.Fp / 16, b.W1t,
+    const int upx = (units + 7) / 8;                      // units per XCD group
+    hipLaunchKernelGGL(train_fwd1_kernel, dim3(8 * upx * nt1), dim3(FW1_WAVES * 64), 0, st, b.xhat_xs, b.Fp, b.Fp / 16, b.W1t,
                        b.bias1, nt1, perm, B, b.a1);
 }
 
 // ------------------------------------------------------------------ train_tail -------
 // partial vector layout (per workgroup):
-//   [0] loss, [1 .. 1+H1) D = sum_s delta1[s][.], then for l = 1..L-1: dW_l (Flux order), db_l
+//   [0] loss, [1 .. 1+H1) unused (D = sum_s delta1[s][.] is rebuilt inside train_grad1), then for
+//   l = 1..L-1: dW_l (Flux order), db_l
 __host__ __device__ static inline long long part_size(const TrainShape& s) {
     long long n = 1 + s.widths[1];
     for (int l = 1; l < s.nlayers; ++l) n += (long long)s.widths[l + 1] * s.widths[l] + s.widths[l + 1];
@@ -131,31 +137,47 @@ __host__ __device__ static inline int tail_off_w(const TrainShape& s, int l) {
     return o;
 }
 
-__global__ __launch_bounds__(256) void train_tail_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm, int B,
-                                                         float inv_div) {
+#define TAIL_THREADS 1024
+__global__ __launch_bounds__(TAIL_THREADS) void train_tail_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm,
+                                                                  int B, float inv_div) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ float lred[4];
+    __shared__ float lred[TAIL_THREADS / 64];
+    constexpr int NTH = TAIL_THREADS;
     const int L = s.nlayers;
     const int tid = threadIdx.x;
     const int unit = blockIdx.x;
     const int H1 = s.widths[1];
     const int H1p = (H1 + 15) & ~15;
-    // stage the tail weights (Flux layout W[o + k*N]) in LDS
+    // stage the tail weights (Flux layout W[o + k*N]) in LDS; 16 waves keep the loads in flight
     for (int l = 1; l < L; ++l) {
         float* Wl = sm + tail_off_w(s, l);
         const float* Wg = b.theta + s.off_W[l];
         const int n = s.widths[l + 1] * s.widths[l];
-        for (int e = tid; e < n; e += 256) Wl[e] = Wg[e];
+        for (int e0 = 0; e0 < n; e0 += NTH * 2) {
+            float v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int e = e0 + u * NTH + tid; v[u] = (e < n) ? Wg[e] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int e = e0 + u * NTH + tid; if (e < n) Wl[e] = v[u]; }
+        }
     }
     {
         float* A0 = sm;
         float* Z0 = sm + 16 * H1;
         const int act0 = (L == 1) ? s.lastact : s.act;
-        for (int e = tid; e < 16 * H1; e += 256) {
-            const int sidx = e / H1, o = e - sidx * H1;
-            const float z = b.a1[(long long)(unit * 16 + sidx) * H1p + o];
-            Z0[e] = z;
-            A0[e] = t_act(act0, z);
+        for (int e0 = 0; e0 < 16 * H1; e0 += NTH * 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * NTH + tid;
+                const int sidx = e / H1, o = e - sidx * H1;
+                v[u] = (e < 16 * H1) ? b.a1[(long long)(unit * 16 + sidx) * H1p + o] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * NTH + tid;
+                if (e < 16 * H1) { Z0[e] = v[u]; A0[e] = t_act(act0, v[u]); }
+            }
         }
     }
     __syncthreads();
@@ -167,14 +189,23 @@ __global__ __launch_bounds__(256) void train_tail_kernel(TrainShape s, TrainBuff
         const float* Wl = sm + tail_off_w(s, l);
         const float* bias = b.theta + s.off_b[l];
         const int actl = (l == L - 1) ? s.lastact : s.act;
-        for (int p = tid; p < 16 * N; p += 256) {
+        // each (sample, output) dot product is split over 4 adjacent lanes along k
+        for (int p4 = tid; p4 < 16 * N * 4; p4 += NTH) {
+            const int p = p4 >> 2, ks = p4 & 3;
             const int sidx = p / N, o = p - sidx * N;
             const float* arow = Ap + sidx * K;
-            float z = bias[o];
-#pragma unroll 4
-            for (int k = 0; k < K; ++k) z += Wl[o + k * N] * arow[k];
-            Zl[p] = z;
-            Al[p] = t_act(actl, z);
+            float z0 = 0.f, z1 = 0.f;
+            int k = ks;
+            for (; k + 4 < K; k += 8) { z0 += Wl[o + k * N] * arow[k]; z1 += Wl[o + (k + 4) * N] * arow[k + 4]; }
+            if (k < K) z0 += Wl[o + k * N] * arow[k];
+            float z = z0 + z1;
+            z += __shfl_xor(z, 1, WAVE);
+            z += __shfl_xor(z, 2, WAVE);
+            if (ks == 0) {
+                z += bias[o];
+                Zl[p] = z;
+                Al[p] = t_act(actl, z);
+            }
         }
         __syncthreads();
     }
@@ -184,7 +215,7 @@ __global__ __launch_bounds__(256) void train_tail_kernel(TrainShape s, TrainBuff
     {
         float* AL = sm + tail_off_act(s, L - 1);
         float* ZL = AL + 16 * nout;
-        for (int p = tid; p < 16 * nout; p += 256) {
+        for (int p = tid; p < 16 * nout; p += NTH) {
             const int sidx = p / nout, o = p - sidx * nout;
             const int row = unit * 16 + sidx;
             const bool valid = row < B;
@@ -206,7 +237,12 @@ __global__ __launch_bounds__(256) void train_tail_kernel(TrainShape s, TrainBuff
     if ((tid & 63) == 0) lred[tid >> 6] = lsum;
     __syncthreads();
     float* part = b.part + (long long)unit * part_size(s);
-    if (tid == 0) part[0] = lred[0] + lred[1] + lred[2] + lred[3];
+    if (tid == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NTH / 64; ++w) t += lred[w];
+        part[0] = t;
+    }
     // backward through the tail
     for (int l = L - 1; l >= 1; --l) {
         const int K = s.widths[l], N = s.widths[l + 1];
@@ -218,40 +254,36 @@ __global__ __launch_bounds__(256) void train_tail_kernel(TrainShape s, TrainBuff
         for (int i = 1; i < l; ++i) poff += (long long)s.widths[i + 1] * s.widths[i] + s.widths[i + 1];
         float* pW = part + poff;
         float* pb = pW + (long long)N * K;
-        for (int e = tid; e < N * K; e += 256) {
+        for (int e = tid; e < N * K; e += NTH) {
             const int k = e / N, o = e - k * N;
             float acc = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc += Zl[q * N + o] * Ap[q * K + k];
             pW[e] = acc;
         }
-        for (int o = tid; o < N; o += 256) {
+        for (int o = tid; o < N; o += NTH) {
             float acc = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc += Zl[q * N + o];
             pb[o] = acc;
         }
-        for (int p = tid; p < 16 * K; p += 256) {
+        for (int p = tid; p < 16 * K; p += NTH) {
             const int sidx = p / K, k = p - sidx * K;
             const float* drow = Zl + sidx * N;
-            float acc = 0.f;
-            for (int o = 0; o < N; ++o) acc += Wl[o + k * N] * drow[o];
-            Zp[p] = acc * t_dact(s.act, Zp[p], Ap[p]);      // read and written by this thread only
+            float a0 = 0.f, a1 = 0.f;
+            int o = 0;
+            for (; o + 1 < N; o += 2) { a0 += Wl[o + k * N] * drow[o]; a1 += Wl[o + 1 + k * N] * drow[o + 1]; }
+            if (o < N) a0 += Wl[o + k * N] * drow[o];
+            Zp[p] = (a0 + a1) * t_dact(s.act, Zp[p], Ap[p]);      // read and written by this thread only
         }
         __syncthreads();
     }
-    // delta1 -> global (zero padded), D partial
+    // delta1 -> global (zero padded)
     {
         const float* Z0 = sm + 16 * H1;
-        for (int e = tid; e < 16 * H1p; e += 256) {
+        for (int e = tid; e < 16 * H1p; e += NTH) {
             const int sidx = e / H1p, o = e - sidx * H1p;
             b.delta1[(long long)(unit * 16 + sidx) * H1p + o] = (o < H1) ? Z0[sidx * H1 + o] : 0.f;
-        }
-        for (int o = tid; o < H1; o += 256) {
-            float acc = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc += Z0[q * H1 + o];
-            part[1 + o] = acc;
         }
     }
 }
@@ -264,7 +296,7 @@ void isk_launch_train_tail(const TrainShape& s, const TrainBuffers& b, const int
     const size_t lds = tail_lds_bytes(s);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)train_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(train_tail_kernel, dim3(units), dim3(256), lds, st, s, b, perm, B, inv_div);
+    hipLaunchKernelGGL(train_tail_kernel, dim3(units), dim3(TAIL_THREADS), lds, st, s, b, perm, B, inv_div);
 }
 
 // ------------------------------------------------------------------ train_grad1 ------
@@ -293,9 +325,11 @@ template <int NT, int NW>
 __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm,
                                                              int B, int nparts) {
     constexpr int NB4 = NT / 4, NR = NT % 4;
+    constexpr int CB = 4;                          // chunks per batch: their row indices are fetched together
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* red = sm;                               // [NW][NT][256]
-    float* Dsh = sm + NW * NT * 256;               // [NT*16]
+    float* Dred = sm + NW * NT * 256;              // [NW][NT][16]
+    float* Dsh = Dred + NW * NT * 16;              // [NT*16] in tile order
     float* red2 = Dsh + NT * 16;                   // [NT][16][2]
     const int H1 = s.widths[1], F = s.widths[0];
     const int H1p = NT * 16;
@@ -304,60 +338,95 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
     const int ft = blockIdx.x;
     const long long PS = part_size(s);
     const bool ln = s.layernorm != 0;
-    if (ln) {
-        for (int o = tid; o < H1p; o += NW * 64) {
-            float acc = 0.f;
-            if (o < H1)
-                for (int w = 0; w < nparts; ++w) acc += b.part[(long long)w * PS + 1 + o];
-            Dsh[o] = acc;
-        }
-    }
+    // small-gradient partial vectors: one element per 16-lane group, lanes split the partials
     {
-        const long long gt = (long long)blockIdx.x * (NW * 64) + tid;
-        const long long gn = (long long)gridDim.x * (NW * 64);
-        for (long long e = gt; e < PS; e += gn) {
+        const long long ngroups = (long long)gridDim.x * (NW * 4);
+        const long long grp = (long long)blockIdx.x * (NW * 4) + (tid >> 4);
+        for (long long e = grp; e < PS; e += ngroups) {
+            if (e >= 1 && e < 1 + H1) continue;     // D is rebuilt below
             float acc = 0.f;
-            for (int w = 0; w < nparts; ++w) acc += b.part[(long long)w * PS + e];
+            for (int w0 = li; w0 < nparts; w0 += 64) {       // 4 independent loads per lane in flight
+                float pv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int w = w0 + 16 * u; pv[u] = (w < nparts) ? b.part[(long long)w * PS + e] : 0.f; }
+                acc += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+            }
+#pragma unroll
+            for (int sft = 8; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft, WAVE);
             const long long gi = part_to_grad(s, e);
-            if (gi >= 0) b.grad[gi] = acc;
+            if (li == 0 && gi >= 0) b.grad[gi] = acc;
         }
     }
     f32x4 acc[NT];
+    float dsum[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) { acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dsum[t] = 0.f; }
     const int nchunks = (B + 15) / 16;
     const float* Xc = b.xhat_xs + ft * 16 + li;
-    for (int chunk = wave; chunk < nchunks; chunk += NW) {
-        const int r0 = chunk * 16 + 4 * lq;
-        float av[4];
-        f32x4 bq[4][NB4 > 0 ? NB4 : 1];
-        float br[4][NR > 0 ? NR : 1];
+    for (int c0 = wave; c0 < nchunks; c0 += NW * CB) {
+        long long rr[CB][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = r0 + j;
-            const long long rr = (r < B) ? (perm ? perm[r] : r) : 0;    // rows >= B carry delta == 0
-            av[j] = Xc[rr * (long long)b.Fp];
-            const float* drow = b.delta1 + (long long)r * H1p;
+        for (int cb = 0; cb < CB; ++cb) {
+            const int chunk = c0 + cb * NW;
 #pragma unroll
-            for (int q = 0; q < NB4; ++q) bq[j][q] = *(const f32x4*)(drow + 64 * q + 4 * li);
-#pragma unroll
-            for (int u = 0; u < NR; ++u) br[j][u] = drow[64 * NB4 + 16 * u + li];
+            for (int j = 0; j < 4; ++j) {
+                const int r = chunk * 16 + 4 * lq + j;
+                rr[cb][j] = (r < B) ? (perm ? perm[r] : r) : 0;      // rows >= B carry delta == 0
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int cb = 0; cb < CB; ++cb) {
+            const int chunk = c0 + cb * NW;
+            if (chunk < nchunks) {                                    // wave-uniform
+                const int r0 = chunk * 16 + 4 * lq;
+                float av[4];
+                f32x4 bq[4][NB4 > 0 ? NB4 : 1];
+                float br[4][NR > 0 ? NR : 1];
 #pragma unroll
-            for (int q = 0; q < NB4; ++q)
+                for (int j = 0; j < 4; ++j) {
+                    av[j] = Xc[rr[cb][j] * (long long)b.Fp];
+                    const float* drow = b.delta1 + (long long)(r0 + j) * H1p;
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    acc[4 * q + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bq[j][q][u], acc[4 * q + u], 0, 0, 0);
+                    for (int q = 0; q < NB4; ++q) bq[j][q] = *(const f32x4*)(drow + 64 * q + 4 * li);
 #pragma unroll
-            for (int u = 0; u < NR; ++u)
-                acc[4 * NB4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], br[j][u], acc[4 * NB4 + u], 0, 0, 0);
+                    for (int u = 0; u < NR; ++u) br[j][u] = drow[64 * NB4 + 16 * u + li];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int q = 0; q < NB4; ++q)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            acc[4 * q + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bq[j][q][u], acc[4 * q + u], 0, 0, 0);
+                            dsum[4 * q + u] += bq[j][q][u];
+                        }
+#pragma unroll
+                    for (int u = 0; u < NR; ++u) {
+                        acc[4 * NB4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], br[j][u], acc[4 * NB4 + u], 0, 0, 0);
+                        dsum[4 * NB4 + u] += br[j][u];
+                    }
+                }
+            }
         }
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
         *(f32x4*)(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
+        float d = dsum[t];
+        d += __shfl_xor(d, 16, WAVE);
+        d += __shfl_xor(d, 32, WAVE);
+        if (lq == 0) Dred[(wave * NT + t) * 16 + li] = d;
+    }
+    __syncthreads();
+    if (tid < NT * 16) {                                               // D in tile order: Dsh[t*16 + li]
+        float d = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) d += Dred[w * NT * 16 + tid];
+        Dsh[tid] = d;
+        const int t = tid >> 4, l2 = tid & 15;
+        const int o = (t < 4 * NB4) ? 64 * (t >> 2) + 4 * l2 + (t & 3) : 16 * t + l2;
+        if (ft == 0 && o < H1) b.grad[s.off_b[0] + o] = d;             // db1 == D
+    }
     __syncthreads();
     if (wave < NT) {
         const int t = wave;
@@ -372,6 +441,7 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
         const float* g = ln ? b.theta + s.off_lns : nullptr;
         const float* beta = ln ? b.theta + s.off_lnb : nullptr;
         float* gW1 = b.grad + s.off_W[0];
+        const float Do = Dsh[t * 16 + li];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int f = ft * 16 + lq * 4 + r;
@@ -379,7 +449,6 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
             if (o < H1 && f < F) {
                 if (ln) {
                     const float w = W1[o + (long long)f * H1];
-                    const float Do = Dsh[o];
                     gW1[o + (long long)f * H1] = g[f] * G[r] + beta[f] * Do;
                     pg = w * G[r];
                     pb = w * Do;
@@ -417,7 +486,7 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
 template <int NT, int NW>
 static void launch_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, hipStream_t st) {
     const int nparts = (B + 15) / 16;
-    const size_t lds = (size_t)(NW * NT * 256 + NT * 16 + NT * 32) * sizeof(float);
+    const size_t lds = (size_t)(NW * NT * 256 + NW * NT * 16 + NT * 16 + NT * 32) * sizeof(float);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)train_grad1_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((train_grad1_kernel<NT, NW>), dim3(b.Fp / 16), dim3(NW * 64), lds, st, s, b, perm, B, nparts);
