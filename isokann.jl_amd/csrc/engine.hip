@@ -125,6 +125,7 @@ struct isk_engine {
     int* d_perm = nullptr;
     float* d_At = nullptr;
     int* d_rowperm = nullptr;
+    double* d_isa_work = nullptr;
     uint64_t rng[4];
     // timers
     bool timers_on = false;
@@ -139,7 +140,8 @@ static void free_data(isk_engine* e) {
     if (e->side) (void)hipStreamSynchronize(e->side);
     e->ys_ahead = false;
     free_dev(e->d_in_xs); free_dev(e->d_in_ys); free_dev(e->d_xhat); free_dev(e->d_xhat_alt); free_dev(e->d_out); free_dev(e->d_ks);
-    free_dev(e->d_target); free_dev(e->d_z1); free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm);
+    free_dev(e->d_target); free_dev(e->d_z1); free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm); free_dev(e->d_isa_work);
+    e->d_isa_work = nullptr;
     e->d_in_xs = e->d_in_ys = e->d_xhat = e->d_xhat_alt = e->d_out = e->d_ks = e->d_target = e->d_z1 = e->d_delta1 = e->d_part = nullptr;
     e->d_perm = nullptr;
     e->N = e->K = e->D = 0;
@@ -534,6 +536,7 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
     const TrainShape ts = train_shape(e);
     HIPCHK(hipMalloc((void**)&e->d_part, (size_t)isk_train_part_floats(ts, (int)N) * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_perm, (size_t)N * sizeof(int)));
+    if (e->cfg.target_kind == ISK_TARGET_ISA) HIPCHK(hipMalloc((void**)&e->d_isa_work, (size_t)2 * N * e->nout * sizeof(double)));
     HIPCHK(hipMemcpyAsync(e->d_in_xs, xs, (size_t)N * D * sizeof(float), kind, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_in_ys, ys, (size_t)N * K * D * sizeof(float), kind, e->stream));
     featurize_resident(e);
@@ -715,6 +718,8 @@ static bool invert_host(std::vector<double>& A, int d) {
         for (int j = 0; j < d; ++j) M[i * 2 * d + j] = A[i * d + j];
         M[i * 2 * d + d + i] = 1.0;
     }
+    // multiplier against the unscaled pivot row (as LU does): exactly dependent rows cancel to exact
+    // zeros and are reported singular, like Julia's inv()
     for (int c = 0; c < d; ++c) {
         int p = c;
         for (int r = c + 1; r < d; ++r)
@@ -723,14 +728,17 @@ static bool invert_host(std::vector<double>& A, int d) {
         if (!(std::fabs(pv) > 0.0) || !std::isfinite(pv)) return false;
         if (p != c)
             for (int j = 0; j < 2 * d; ++j) std::swap(M[p * 2 * d + j], M[c * 2 * d + j]);
-        const double inv = 1.0 / pv;
-        for (int j = 0; j < 2 * d; ++j) M[c * 2 * d + j] *= inv;
         for (int r = 0; r < d; ++r) {
             if (r == c) continue;
-            const double f = M[r * 2 * d + c];
+            const double f = M[r * 2 * d + c] / pv;
             if (f == 0.0) continue;
             for (int j = 0; j < 2 * d; ++j) M[r * 2 * d + j] -= f * M[c * 2 * d + j];
+            M[r * 2 * d + c] = 0.0;
         }
+    }
+    for (int c = 0; c < d; ++c) {
+        const double inv = 1.0 / M[c * 2 * d + c];
+        for (int j = 0; j < 2 * d; ++j) M[c * 2 * d + j] *= inv;
     }
     for (int i = 0; i < d; ++i)
         for (int j = 0; j < d; ++j) {
@@ -865,10 +873,9 @@ static int check_status(isk_engine* e) {
     int st = 0;
     HIPCHK(hipMemcpyAsync(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (st & 1) {
-        HIPCHK(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
-        return fail(ISK_ECONSTANT_CHI, isk_status_string(ISK_ECONSTANT_CHI));
-    }
+    if (st) HIPCHK(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
+    if (st & 1) return fail(ISK_ECONSTANT_CHI, isk_status_string(ISK_ECONSTANT_CHI));
+    if (st & 2) return fail(ISK_ESINGULAR, isk_status_string(ISK_ESINGULAR));
     return ISK_OK;
 }
 
@@ -885,23 +892,20 @@ static int compute_target(isk_engine* e, bool check, bool ahead = false) {
         if (check) CHK(check_status(e));
         return ISK_OK;
     }
-    // ISA: chi = model(xs), ks = E[model(ys)] in one launch over the contiguous slab
+    // ISA: chi = model(xs), ks = E[model(ys)] in one launch over the contiguous slab, then the
+    // Float64 simplex solve, fixperm and the loss weights in a single-workgroup kernel: the
+    // iteration never leaves the device (the reference pulls chi and ks to the host here,
+    // src/isotarget.jl:101,103)
     CHK(forward_resident(e, 3, ahead));
     ScopedTimer t(e, ISK_T_TARGET);
     launch_kmean(e);
-    std::vector<float> ks((size_t)e->N * d), chi((size_t)e->N * d);
-    HIPCHK(hipMemcpyAsync(ks.data(), e->d_ks, ks.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(chi.data(), e->d_out + e->N * e->K * d, chi.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    std::vector<double> At, tgt;
-    std::vector<int> rp;
-    CHK(isa_solve_host(e, ks, chi, e->N, d, At, rp, &tgt));
-    std::vector<float> tf(tgt.begin(), tgt.end()), w;      // T(target): back to Float32
-    loss_weights_host(tf, e->N, d, w);
-    HIPCHK(hipMemcpyAsync(e->d_target, tf.data(), tf.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->d_lossw, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));               // tf / w are stack-owned
+    IsaArgs ia;
+    ia.ks = e->d_ks; ia.chi = e->d_out + e->N * e->K * d; ia.work = e->d_isa_work; ia.target = e->d_target;
+    ia.lossw = e->d_lossw; ia.status = e->d_status; ia.N = e->N; ia.d = d;
+    ia.permute = e->cfg.isa_permute; ia.whitening = e->cfg.isa_whitening;
+    isk_launch_isa(ia, e->stream);
     e->have_target = true;
+    if (check) CHK(check_status(e));
     return ISK_OK;
 }
 
@@ -1019,19 +1023,15 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
             double l = 0;
             const int32_t* p = perms ? perms + k * e->N : nullptr;
             int r = train_epoch(e, -1, p, &l);
-            if (e->cfg.target_kind == ISK_TARGET_SHIFTSCALE) {
-                int st = 0;
-                HIPCHK(hipMemcpy(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
-                if (st & 1) {
-                    HIPCHK(hipMemset(e->d_status, 0, sizeof(int)));
-                    return fail(ISK_ECONSTANT_CHI, isk_status_string(ISK_ECONSTANT_CHI));
-                }
+            {   // the target's DomainError (constant chi / singular simplex) outranks the loss check
+                const int sr = check_status(e);
+                if (sr != ISK_OK) return sr;
             }
             if (r != ISK_OK) return r;
             if (losses) losses[k] = l;
             ++k;
         }
-        if (epochs == 0 && e->cfg.target_kind == ISK_TARGET_SHIFTSCALE) CHK(check_status(e));
+        if (epochs == 0) CHK(check_status(e));
     }
     return ISK_OK;
 }

@@ -80,6 +80,18 @@ void isk_launch_shiftscale(const float* ks, const float* mm, float* target, long
 void isk_launch_isa_apply(const float* ks, const float* At /*[d*d] device, row-major At[a][b]*/, const int* rowperm,
                           float* target, long long N, int d, hipStream_t st);
 
+// device-side Float64 inner simplex algorithm + fixperm + loss weights (single workgroup)
+struct IsaArgs {
+    const float* ks;        // [N][d]
+    const float* chi;       // [N][d]
+    double* work;           // [2*N*d] Float64 scratch
+    float* target;          // [N][d]
+    float* lossw;           // [d]
+    int* status;            // bit 1 (value 2): singular / non-finite
+    long long N; int d, permute, whitening;
+};
+void isk_launch_isa(const IsaArgs& a, hipStream_t st);
+
 // ---------------------------------------------------------------- training --------
 struct TrainShape {
     int nlayers;
