@@ -473,6 +473,7 @@ static void featurize_rows(isk_engine* e, const float* in, long long S, float* x
     FeatArgs a;
     a.in = in; a.pairs = e->d_pairs; a.packed_pairs = e->d_packed; a.xhat = xhat; a.S = S; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
+    a.background = (st != nullptr);
     isk_launch_featurize(a, st ? st : e->stream);
 }
 
@@ -501,8 +502,8 @@ static void featurize_ys_ahead(isk_engine* e) {
     // slows the forward from 0.83 to 1.5 ms (the featurizer's streaming evicts the L2-resident
     // weights and saturates the memory queues), a net loss against running them back to back.
     // Kept behind ISK_OVERLAP_FEATURIZE=1 for further tuning.
-    static const bool on = [] { const char* v = getenv("ISK_OVERLAP_FEATURIZE"); return v && atoi(v) != 0; }();
-    if (!on || !e->d_xhat_alt) return;
+    static const int mode = [] { const char* v = getenv("ISK_OVERLAP_FEATURIZE"); return v ? atoi(v) : 0; }();
+    if (mode != 1 || !e->d_xhat_alt) return;
     (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
     {
         ScopedTimer t(e, ISK_T_FEATURIZE, e->side);
@@ -577,6 +578,7 @@ extern "C" int isk_features(isk_engine* e, const float* coords, int64_t D, int64
     FeatArgs a;
     a.in = (const float*)in.p; a.pairs = e->d_pairs; a.packed_pairs = e->d_packed; a.xhat = (float*)xh.p; a.S = ncols; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
     a.normalize = 0; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;   // raw features: the featurizer alone
+    a.background = 0;
     isk_launch_featurize(a, e->stream);
     HIPCHK(hipMemcpy2DAsync(out, (size_t)e->F * sizeof(float), xh.p, (size_t)e->Fp * sizeof(float), (size_t)e->F * sizeof(float),
                             (size_t)ncols, hipMemcpyDeviceToHost, e->stream));
@@ -597,6 +599,7 @@ static int forward_cols(isk_engine* e, const float* host_in, int64_t rowlen, int
     a.xhat = (float*)xh.p; a.S = ncols;
     a.D = (int)rowlen; a.F = e->F; a.Fp = e->Fp;
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
+    a.background = 0;
     isk_launch_featurize(a, e->stream);
     MlpFwdArgs f = fwd_args(e, (const float*)xh.p, ncols, (float*)o.p);
     if (isk_launch_mlp_fwd(f, e->stream) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
@@ -1019,6 +1022,16 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
         if (e->cfg.featurize_every_iteration) featurize_resident(e);
         // the constant-chi check needs the device status word; it is read together with the loss
         CHK(compute_target(e, false, e->cfg.featurize_every_iteration != 0));
+        {   // experimental: ISK_OVERLAP_FEATURIZE=2 runs the next ys featurization beside the training kernels
+            static const int mode = [] { const char* v = getenv("ISK_OVERLAP_FEATURIZE"); return v ? atoi(v) : 0; }();
+            if (mode == 2 && e->cfg.featurize_every_iteration && e->d_xhat_alt) {
+                (void)hipEventRecord(e->ev_fwd_done, e->stream);
+                (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
+                { ScopedTimer t(e, ISK_T_FEATURIZE, e->side); featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat_alt, e->side); }
+                (void)hipEventRecord(e->ev_ys_ready, e->side);
+                e->ys_ahead = true;
+            }
+        }
         for (int ep = 0; ep < epochs; ++ep) {
             double l = 0;
             const int32_t* p = perms ? perms + k * e->N : nullptr;

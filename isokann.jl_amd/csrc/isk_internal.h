@@ -23,6 +23,7 @@ struct FeatArgs {
     int normalize;          // 1: (x-mu)*rstd, Flux normalise over the feature axis
     int ln_mode;            // isk_ln_mode
     float eps;
+    int background;         // launched on the side stream next to other kernels: may be throttled
 };
 void isk_launch_featurize(const FeatArgs& a, hipStream_t st);
 

@@ -10,11 +10,17 @@
 // The LayerNorm standardisation has no trainable parameters, so it is hoisted out of the loop
 // (xhat is cached); its affine part (g, beta) is folded into layer 1 on the way in and unfolded
 // on the way back, which removes the dL/d(a0) GEMM entirely: only G (one GEMM) is needed.
+#include <cstdlib>
 #include "isk_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define WAVE 64
 
+__device__ __forceinline__ float wave_sum_t(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
 __device__ __forceinline__ float t_sigmoid(float z) {
     float e = __expf(-fabsf(z));
     float r = 1.0f / (1.0f + e);
@@ -44,7 +50,7 @@ __device__ __forceinline__ float t_dact(int act, float z, float a) {
 // output tile; every wave issues the loads of up to FW1_GROUP chunks before its MFMAs (the step
 // is latency-bound: B rows only), partial tiles are combined through LDS.
 #define FW1_WAVES 8
-#define FW1_GROUP 14
+#define FW1_GROUP 7
 __global__ __launch_bounds__(FW1_WAVES * 64) void train_fwd1_kernel(const float* __restrict__ X, int Fp, int nch,
                                                                    const float* __restrict__ W1t,
                                                                    const float* __restrict__ bias1, int nt1,
@@ -330,7 +336,6 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
     float* red = sm;                               // [NW][NT][256]
     float* Dred = sm + NW * NT * 256;              // [NW][NT][16]
     float* Dsh = Dred + NW * NT * 16;              // [NT*16] in tile order
-    float* red2 = Dsh + NT * 16;                   // [NT][16][2]
     const int H1 = s.widths[1], F = s.widths[0];
     const int H1p = NT * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -428,57 +433,42 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
         if (ft == 0 && o < H1) b.grad[s.off_b[0] + o] = d;             // db1 == D
     }
     __syncthreads();
-    if (wave < NT) {
-        const int t = wave;
-        f32x4 G = {0.f, 0.f, 0.f, 0.f};
+    // Epilogue, coalesced: wave w owns feature row f = 16*ft + w (NW >= 16 waves cover the tile; with
+    // NW == 8 each wave takes two rows) and its lanes walk the outputs o, so the W1 reads and the dW1
+    // writes are contiguous in Flux's (out, in) layout.  G[f][o] is re-assembled from the NW partial
+    // accumulator tiles in LDS: C layout row = 4*lq + r is the feature, col = li the output slot.
+    const float* W1 = b.theta + s.off_W[0];
+    const float* g = ln ? b.theta + s.off_lns : nullptr;
+    const float* beta = ln ? b.theta + s.off_lnb : nullptr;
+    float* gW1 = b.grad + s.off_W[0];
+    for (int fl = wave; fl < 16; fl += NW) {
+        const int f = ft * 16 + fl;
+        if (f >= F) continue;                                   // wave-uniform
+        const int flq = fl >> 2, fr = fl & 3;
+        const float gf = ln ? g[f] : 1.f, bf = ln ? beta[f] : 0.f;
+        float pg = 0.f, pb = 0.f;
+        for (int o = lane; o < H1; o += WAVE) {
+            int t, l2;
+            if (o < 64 * NB4) { t = 4 * (o >> 6) + (o & 3); l2 = (o & 63) >> 2; }
+            else { t = 4 * NB4 + ((o - 64 * NB4) >> 4); l2 = o & 15; }
+            const int slot = ((t * 64) + flq * 16 + l2) * 4 + fr;
+            float G = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const f32x4 v = *(const f32x4*)(red + ((w * NT + t) * 64 + lane) * 4);
-            G += v;
-        }
-        const int o = (t < 4 * NB4) ? 64 * (t >> 2) + 4 * li + (t & 3) : 16 * t + li;
-        const float* W1 = b.theta + s.off_W[0];
-        const float* g = ln ? b.theta + s.off_lns : nullptr;
-        const float* beta = ln ? b.theta + s.off_lnb : nullptr;
-        float* gW1 = b.grad + s.off_W[0];
-        const float Do = Dsh[t * 16 + li];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = ft * 16 + lq * 4 + r;
-            float pg = 0.f, pb = 0.f;
-            if (o < H1 && f < F) {
-                if (ln) {
-                    const float w = W1[o + (long long)f * H1];
-                    gW1[o + (long long)f * H1] = g[f] * G[r] + beta[f] * Do;
-                    pg = w * G[r];
-                    pb = w * Do;
-                } else {
-                    gW1[o + (long long)f * H1] = G[r];
-                }
-            }
+            for (int w = 0; w < NW; ++w) G += red[w * NT * 256 + slot];
             if (ln) {
-#pragma unroll
-                for (int sft = 8; sft > 0; sft >>= 1) {
-                    pg += __shfl_xor(pg, sft, WAVE);
-                    pb += __shfl_xor(pb, sft, WAVE);
-                }
-                if (li == 0) {
-                    red2[(t * 16 + lq * 4 + r) * 2 + 0] = pg;
-                    red2[(t * 16 + lq * 4 + r) * 2 + 1] = pb;
-                }
+                const float w1 = W1[o + (long long)f * H1];
+                const float Do = Dsh[t * 16 + l2];
+                gW1[o + (long long)f * H1] = gf * G + bf * Do;
+                pg += w1 * G;
+                pb += w1 * Do;
+            } else {
+                gW1[o + (long long)f * H1] = G;
             }
         }
-    }
-    if (ln) {
-        __syncthreads();
-        if (tid < 16) {
-            const int f = ft * 16 + tid;
-            if (f < F) {
-                float sg = 0.f, sb = 0.f;
-                for (int w = 0; w < NT; ++w) { sg += red2[(w * 16 + tid) * 2]; sb += red2[(w * 16 + tid) * 2 + 1]; }
-                b.grad[s.off_lns + f] = sg;
-                b.grad[s.off_lnb + f] = sb;
-            }
+        if (ln) {
+            pg = wave_sum_t(pg);
+            pb = wave_sum_t(pb);
+            if (lane == 0) { b.grad[s.off_lns + f] = pg; b.grad[s.off_lnb + f] = pb; }
         }
     }
 }
@@ -486,7 +476,7 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
 template <int NT, int NW>
 static void launch_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, hipStream_t st) {
     const int nparts = (B + 15) / 16;
-    const size_t lds = (size_t)(NW * NT * 256 + NW * NT * 16 + NT * 16 + NT * 32) * sizeof(float);
+    const size_t lds = (size_t)(NW * NT * 256 + NW * NT * 16 + NT * 16) * sizeof(float);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)train_grad1_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((train_grad1_kernel<NT, NW>), dim3(b.Fp / 16), dim3(NW * 64), lds, st, s, b, perm, B, nparts);
@@ -494,18 +484,13 @@ static void launch_grad1(const TrainShape& s, const TrainBuffers& b, const int* 
 
 void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int, hipStream_t st) {
     const int nt1 = isk_pad16(s.widths[1]) / 16;
+    static const int nw8 = [] { const char* v = getenv("ISK_GRAD1_NW8"); return v ? atoi(v) : 0; }();
+#define G1CASE(NT_) case NT_: if (nw8) launch_grad1<NT_, 8>(s, b, perm, B, st); else launch_grad1<NT_, 16>(s, b, perm, B, st); break;
     switch (nt1) {
-        case 1: launch_grad1<1, 16>(s, b, perm, B, st); break;
-        case 2: launch_grad1<2, 16>(s, b, perm, B, st); break;
-        case 3: launch_grad1<3, 16>(s, b, perm, B, st); break;
-        case 4: launch_grad1<4, 16>(s, b, perm, B, st); break;
-        case 5: launch_grad1<5, 16>(s, b, perm, B, st); break;
-        case 6: launch_grad1<6, 16>(s, b, perm, B, st); break;
-        case 7: launch_grad1<7, 16>(s, b, perm, B, st); break;
-        case 8: launch_grad1<8, 16>(s, b, perm, B, st); break;
-        case 9: launch_grad1<9, 16>(s, b, perm, B, st); break;
+        G1CASE(1) G1CASE(2) G1CASE(3) G1CASE(4) G1CASE(5) G1CASE(6) G1CASE(7) G1CASE(8) G1CASE(9)
         default: launch_grad1<10, 8>(s, b, perm, B, st); break;
     }
+#undef G1CASE
 }
 
 // ------------------------------------------------------------------ opt_step ---------
