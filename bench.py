@@ -127,7 +127,12 @@ def main():
 
     dist = None
     use_dp = world > 1 or args.force_dp
+    real_stdout = None
     if use_dp:
+        # RCCL prints a version banner on stdout; the driver wants exactly one JSON line there
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -217,7 +222,10 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
             "final_loss": iso.losses[-1],
         }
-        print(json.dumps(line), flush=True)
+        if real_stdout is not None:
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        else:
+            print(json.dumps(line), flush=True)
     iso.close()
     if use_dp:
         dist.destroy_process_group()

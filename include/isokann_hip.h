@@ -166,6 +166,14 @@ int  isk_dp_shiftscale_apply(isk_engine* e, float gmin, float gmax);   /* target
 int  isk_dp_get_ks_chi(isk_engine* e, float* ks, float* chi);   /* local (nout, N) slices for the ISA gather */
 int  isk_dp_isa_apply(isk_engine* e, const double* At, const int32_t* rowperm); /* target = (A' ks)[perm] */
 int  isk_dp_set_loss_weights(isk_engine* e, const float* w);    /* global 1/std(target) */
+/* Device-resident ISA for data-parallel runs: the host all-gathers the local slices (device pointers
+ * from isk_dp_ks_chi_dev, `nfloats` each) into ks_all/chi_all ([n_global][d], rank order) and every
+ * rank runs the same Float64 solve on them, writing the target rows [first, first+N_local) of its own
+ * shard and the global loss weights.  No host synchronisation; isk_dp_check_target reports the
+ * DomainError status (one sync), normally folded into isk_dp_epoch_end by the caller. */
+int  isk_dp_ks_chi_dev(isk_engine* e, void** ks_dev, void** chi_dev, int64_t* nfloats);
+int  isk_dp_isa_dev(isk_engine* e, const float* ks_all_dev, const float* chi_all_dev, int64_t n_global, int64_t first);
+int  isk_dp_check_target(isk_engine* e);
 /* per-row sum and sum of squares of the local target (for the global std, src/iso.jl:183) */
 int  isk_dp_target_moments(isk_engine* e, double* sum, double* sumsq);
 /* Host Float64 ISA solve on gathered arrays (no device work): ks, chi are (d, N) column-major.
@@ -175,12 +183,20 @@ int  isk_isa_solve(const float* ks, const float* chi, int64_t N, int32_t d, int3
                    double* At, int32_t* rowperm);
 /* device pointer + length of the flat gradient/loss buffer: [grads (nparams) | batch loss] */
 int  isk_dp_grad_buffer(isk_engine* e, void** buf_dev, int64_t* nfloats);
-/* local batch -> this rank's contribution to the gradient of (global batch loss / global_batch),
- * written into the buffer together with the local batch loss; nothing is updated */
-int  isk_dp_local_grads(isk_engine* e, const int32_t* idx, int32_t nidx, int64_t global_batch);
-/* after the host all-reduced (sum) the buffer: one optimizer step from it; *batch_loss = the
- * all-reduced batch loss.  A non-finite loss skips the update and returns ISK_ECOLLAPSED. */
-int  isk_dp_apply(isk_engine* e, double* batch_loss);
+/* Epoch protocol (no host synchronisation inside the step loop):
+ *   isk_dp_epoch_begin(perm, n)   upload this rank's shuffle of its shard, zero the loss accumulator
+ *   per optimizer step:
+ *     isk_dp_local_grads(first, nidx, global_batch)   rows perm[first .. first+nidx): this rank's
+ *         contribution to the gradient of (global batch loss / global_batch) + its batch loss -> buffer
+ *     <host all-reduces (sum) the buffer on the engine's stream>
+ *     isk_dp_apply()              optimizer step from the reduced buffer; a non-finite reduced loss
+ *                                 skips this and every later update of the epoch
+ *   isk_dp_epoch_end(&loss_sum)   one synchronisation: sum of the reduced batch losses, or
+ *                                 ISK_ECOLLAPSED */
+int  isk_dp_epoch_begin(isk_engine* e, const int32_t* perm, int32_t n);
+int  isk_dp_local_grads(isk_engine* e, int32_t first, int32_t nidx, int64_t global_batch);
+int  isk_dp_apply(isk_engine* e);
+int  isk_dp_epoch_end(isk_engine* e, double* loss_sum);
 
 /* ---- instrumentation -------------------------------------------------------------- */
 typedef enum { ISK_T_FEATURIZE = 0, ISK_T_FWD_YS = 1, ISK_T_FWD_XS = 2, ISK_T_TARGET = 3,

@@ -98,11 +98,16 @@ PROTOTYPES = {
     "isk_dp_get_ks_chi": (C.c_int, [_H, _f32p, _f32p]),
     "isk_dp_isa_apply": (C.c_int, [_H, _f64p, _i32p]),
     "isk_dp_set_loss_weights": (C.c_int, [_H, _f32p]),
+    "isk_dp_ks_chi_dev": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i64p]),
+    "isk_dp_isa_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "isk_dp_check_target": (C.c_int, [_H]),
     "isk_dp_target_moments": (C.c_int, [_H, _f64p, _f64p]),
     "isk_isa_solve": (C.c_int, [_f32p, _f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _f64p, _i32p]),
     "isk_dp_grad_buffer": (C.c_int, [_H, C.POINTER(C.c_void_p), _i64p]),
-    "isk_dp_local_grads": (C.c_int, [_H, _i32p, C.c_int32, C.c_int64]),
-    "isk_dp_apply": (C.c_int, [_H, _f64p]),
+    "isk_dp_epoch_begin": (C.c_int, [_H, _i32p, C.c_int32]),
+    "isk_dp_local_grads": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int64]),
+    "isk_dp_apply": (C.c_int, [_H]),
+    "isk_dp_epoch_end": (C.c_int, [_H, _f64p]),
     "isk_timers_enable": (C.c_int, [_H, C.c_int32]),
     "isk_timers_read": (C.c_int, [_H, _f64p, _i64p]),
     "isk_timers_reset": (C.c_int, [_H]),

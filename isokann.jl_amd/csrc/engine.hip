@@ -126,7 +126,10 @@ struct isk_engine {
     float* d_At = nullptr;
     int* d_rowperm = nullptr;
     double* d_isa_work = nullptr;
+    double* d_isa_work_dp = nullptr;
+    long long isa_work_dp_rows = 0;
     uint64_t rng[4];
+    int dp_perm_len = 0;
     // timers
     bool timers_on = false;
     std::vector<EventPair> ev_live, ev_free;
@@ -385,7 +388,7 @@ extern "C" void isk_destroy(isk_engine* e) {
     free_data(e);
     free_dev(e->d_theta); free_dev(e->d_grad); free_dev(e->d_m); free_dev(e->d_v);
     free_dev(e->d_loss_acc); free_dev(e->d_status); free_dev(e->d_mm); free_dev(e->d_lossw);
-    free_dev(e->d_At); free_dev(e->d_rowperm); free_dev(e->d_pairs); free_dev(e->d_packed);
+    free_dev(e->d_At); free_dev(e->d_rowperm); free_dev(e->d_pairs); free_dev(e->d_packed); free_dev(e->d_isa_work_dp);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_Wt[l]); free_dev(e->d_bias[l]); }
     drain_timers(e);
     for (auto& ep : e->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -906,6 +909,7 @@ static int compute_target(isk_engine* e, bool check, bool ahead = false) {
     ia.ks = e->d_ks; ia.chi = e->d_out + e->N * e->K * d; ia.work = e->d_isa_work; ia.target = e->d_target;
     ia.lossw = e->d_lossw; ia.status = e->d_status; ia.N = e->N; ia.d = d;
     ia.permute = e->cfg.isa_permute; ia.whitening = e->cfg.isa_whitening;
+    ia.out_first = 0; ia.out_count = e->N;
     isk_launch_isa(ia, e->stream);
     e->have_target = true;
     if (check) CHK(check_status(e));
@@ -1106,6 +1110,42 @@ extern "C" int isk_dp_isa_apply(isk_engine* e, const double* At, const int32_t* 
     return ISK_OK;
 }
 
+extern "C" int isk_dp_ks_chi_dev(isk_engine* e, void** ks_dev, void** chi_dev, int64_t* nfloats) {
+    CHK(need_data(e));
+    if (!e->have_ks || !ks_dev || !chi_dev || !nfloats) return fail(ISK_ESTATE, "call isk_dp_koopman_local first / null argument");
+    *ks_dev = e->d_ks;
+    *chi_dev = e->d_out + e->N * e->K * e->nout;
+    *nfloats = e->N * e->nout;
+    return ISK_OK;
+}
+
+extern "C" int isk_dp_isa_dev(isk_engine* e, const float* ks_all_dev, const float* chi_all_dev, int64_t n_global, int64_t first) {
+    CHK(need_data(e));
+    if (e->cfg.target_kind != ISK_TARGET_ISA) return fail(ISK_EINVAL, "engine is not configured for TransformISA");
+    if (!ks_all_dev || !chi_all_dev || n_global < e->N || first < 0 || first + e->N > n_global) return fail(ISK_EINVAL, "bad gathered arrays");
+    const int d = e->nout;
+    if (e->isa_work_dp_rows < n_global) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        free_dev(e->d_isa_work_dp);
+        e->d_isa_work_dp = nullptr;
+        HIPCHK(hipMalloc((void**)&e->d_isa_work_dp, (size_t)2 * n_global * d * sizeof(double)));
+        e->isa_work_dp_rows = n_global;
+    }
+    IsaArgs ia;
+    ia.ks = ks_all_dev; ia.chi = chi_all_dev; ia.work = e->d_isa_work_dp; ia.target = e->d_target;
+    ia.lossw = e->d_lossw; ia.status = e->d_status; ia.N = n_global; ia.d = d;
+    ia.permute = e->cfg.isa_permute; ia.whitening = e->cfg.isa_whitening;
+    ia.out_first = first; ia.out_count = e->N;
+    isk_launch_isa(ia, e->stream);
+    e->have_target = true;
+    return ISK_OK;
+}
+
+extern "C" int isk_dp_check_target(isk_engine* e) {
+    CHK(need_data(e));
+    return check_status(e);
+}
+
 extern "C" int isk_dp_set_loss_weights(isk_engine* e, const float* w) {
     if (!e || !w) return fail(ISK_EINVAL, "null argument");
     HIPCHK(hipMemcpyAsync(e->d_lossw, w, (size_t)e->nout * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -1147,27 +1187,41 @@ extern "C" int isk_dp_grad_buffer(isk_engine* e, void** buf, int64_t* n) {
     return ISK_OK;
 }
 
-extern "C" int isk_dp_local_grads(isk_engine* e, const int32_t* idx, int32_t nidx, int64_t global_batch) {
+extern "C" int isk_dp_epoch_begin(isk_engine* e, const int32_t* perm, int32_t n) {
     CHK(need_data(e));
     if (!e->have_target) return fail(ISK_ESTATE, "no target");
-    if (!idx || nidx < 1 || nidx > e->N || global_batch < nidx) return fail(ISK_EINVAL, "bad batch");
-    for (int i = 0; i < nidx; ++i)
-        if (idx[i] < 0 || idx[i] >= e->N) return fail(ISK_EINVAL, "batch index out of range");
-    HIPCHK(hipMemcpyAsync(e->d_perm, idx, (size_t)nidx * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));                 // idx is caller-owned
-    launch_grads(e, e->d_perm, nidx, 1.0f / (float)global_batch);
+    if (!perm || n < 1 || n > e->N) return fail(ISK_EINVAL, "bad permutation");
+    for (int i = 0; i < n; ++i)
+        if (perm[i] < 0 || perm[i] >= e->N) return fail(ISK_EINVAL, "permutation entry out of range");
+    HIPCHK(hipMemcpyAsync(e->d_perm, perm, (size_t)n * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(e->d_loss_acc, 0, 2 * sizeof(double), e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));                 // perm is caller-owned
+    e->dp_perm_len = n;
     return ISK_OK;
 }
 
-extern "C" int isk_dp_apply(isk_engine* e, double* batch_loss) {
-    CHK(need_data(e));
-    HIPCHK(hipMemsetAsync(e->d_loss_acc, 0, 2 * sizeof(double), e->stream));
+extern "C" int isk_dp_local_grads(isk_engine* e, int32_t first, int32_t nidx, int64_t global_batch) {
+    if (!e || e->N == 0) return fail(ISK_ESTATE, "no data");
+    if (first < 0 || nidx < 1 || first + nidx > e->dp_perm_len || global_batch < nidx) return fail(ISK_EINVAL, "bad batch");
+    launch_grads(e, e->d_perm + first, nidx, 1.0f / (float)global_batch);
+    return ISK_OK;
+}
+
+extern "C" int isk_dp_apply(isk_engine* e) {
+    if (!e || e->N == 0) return fail(ISK_ESTATE, "no data");
     launch_opt(e, 1.0f);
+    return ISK_OK;
+}
+
+extern "C" int isk_dp_epoch_end(isk_engine* e, double* loss_sum) {
+    CHK(need_data(e));
     double acc[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(acc, e->d_loss_acc, sizeof(acc), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    e->dp_perm_len = 0;
     if (acc[1] != 0.0) return fail(ISK_ECOLLAPSED, isk_status_string(ISK_ECOLLAPSED));
-    if (batch_loss) *batch_loss = acc[0];
+    if (loss_sum) *loss_sum = acc[0];
     return ISK_OK;
 }
 

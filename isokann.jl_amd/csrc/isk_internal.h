@@ -90,6 +90,7 @@ struct IsaArgs {
     float* lossw;           // [d]
     int* status;            // bit 1 (value 2): singular / non-finite
     long long N; int d, permute, whitening;
+    long long out_first, out_count;   // rows [out_first, out_first + out_count) of the target are written (data-parallel: the local shard)
 };
 void isk_launch_isa(const IsaArgs& a, hipStream_t st);
 

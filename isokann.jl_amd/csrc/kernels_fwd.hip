@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(ISA_T) void isa_kernel(IsaArgs a) {
 #pragma unroll
                         for (int k = 0; k < D; ++k) v = (rp[i] == k) ? tv[r][k] : v;
                         const float vf = (float)v;                 // T(target): back to Float32
-                        a.target[n * D + i] = vf;
+                        if (n >= a.out_first && n < a.out_first + a.out_count) a.target[(n - a.out_first) * D + i] = vf;
                         const double c = (double)vf - sh0[i];
                         mom[i] += c;
                         mom[D + i] += c * c;

@@ -132,6 +132,32 @@ class HipLocal:
                                           int(self.whitening), capi.ptr_f64(At), capi.ptr_i32(rp)))
         return At, rp
 
+    def isa_device(self, comm, counts) -> bool:
+        """device-resident path: all-gather the local ks / chi slices with RCCL and run the Float64
+        ISA kernel on the gathered arrays on every rank (no host round trip).  Needs equal shards."""
+        if len(set(counts)) != 1:
+            return False
+        torch = comm.torch
+        ks_p, chi_p, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        capi.check(self.lib.isk_dp_ks_chi_dev(self.h, C.byref(ks_p), C.byref(chi_p), C.byref(n)))
+        dev = self.grad_tensor.device
+        ks_t = torch.as_tensor(_DevBuf(ks_p.value, n.value), device=dev)
+        chi_t = torch.as_tensor(_DevBuf(chi_p.value, n.value), device=dev)
+        if comm.on:
+            gks = torch.empty(n.value * comm.world, dtype=torch.float32, device=dev)
+            gchi = torch.empty_like(gks)
+            comm.dist.all_gather_into_tensor(gks, ks_t)
+            comm.dist.all_gather_into_tensor(gchi, chi_t)
+        else:
+            gks, gchi = ks_t, chi_t
+        self._keep = (gks, gchi)          # alive until the kernel has run
+        capi.check(self.lib.isk_dp_isa_dev(self.h, C.c_void_p(gks.data_ptr()), C.c_void_p(gchi.data_ptr()),
+                                           int(sum(counts)), int(sum(counts[:comm.rank]))))
+        return True
+
+    def check_target(self):
+        capi.check(self.lib.isk_dp_check_target(self.h))
+
     def isa_apply(self, At, rowperm):
         capi.check(self.lib.isk_dp_isa_apply(self.h, capi.ptr_f64(At), capi.ptr_i32(rowperm)))
 
@@ -145,13 +171,19 @@ class HipLocal:
         w = np.ascontiguousarray(w, np.float32)
         capi.check(self.lib.isk_dp_set_loss_weights(self.h, capi.ptr_f32(w)))
 
-    def local_grads(self, idx, global_batch):
-        idx = np.ascontiguousarray(idx, np.int32)
-        capi.check(self.lib.isk_dp_local_grads(self.h, capi.ptr_i32(idx), idx.size, int(global_batch)))
+    def epoch_begin(self, perm):
+        perm = np.ascontiguousarray(perm, np.int32)
+        capi.check(self.lib.isk_dp_epoch_begin(self.h, capi.ptr_i32(perm), perm.size))
 
-    def apply(self) -> float:
+    def local_grads(self, first, nidx, global_batch):
+        capi.check(self.lib.isk_dp_local_grads(self.h, int(first), int(nidx), int(global_batch)))
+
+    def apply(self):
+        capi.check(self.lib.isk_dp_apply(self.h))
+
+    def epoch_end(self) -> float:
         loss = C.c_double(0)
-        capi.check(self.lib.isk_dp_apply(self.h, C.byref(loss)))
+        capi.check(self.lib.isk_dp_epoch_end(self.h, C.byref(loss)))
         return float(loss.value)
 
 
@@ -165,6 +197,8 @@ def dp_target(local, comm: Comm, counts: List[int]) -> None:
         if not ghi > glo:                                                 # src/isotarget.jl:39 (NaN too)
             raise capi.DomainError(capi.ECONSTANT_CHI, "Could not compute the shift-scale. chi function is constant")
         local.shiftscale_apply(glo, ghi)
+        return
+    if hasattr(local, "isa_device") and local.isa_device(comm, counts):
         return
     ks, chi = local.get_ks_chi()
     both = comm.allgather_cols(np.concatenate([ks, chi], axis=0), counts)  # one gather for ks and chi
@@ -191,12 +225,12 @@ def dp_train_epoch(local, comm: Comm, minibatch: int, counts: List[int], perm: n
             raise ValueError("global minibatch smaller than the number of ranks")
         gb = bl * comm.world
         nb = min(c // bl for c in counts)               # partial=false: the ragged tail is dropped
-    ls = 0.0
-    for b in range(nb):
-        local.local_grads(perm[b * bl:(b + 1) * bl], gb)
+    local.epoch_begin(perm[:nb * bl])
+    for b in range(nb):                                 # enqueue only: no host synchronisation per step
+        local.local_grads(b * bl, bl, gb)
         comm.allreduce_tensor_(local.grad_tensor)
-        ls += local.apply()                             # raises DomainError on a non-finite global loss
-    return ls / n_global                                # src/iso.jl:193
+        local.apply()
+    return local.epoch_end() / n_global                 # one sync; DomainError on a non-finite global loss; src/iso.jl:193
 
 
 def dp_run(local, comm: Comm, n: int, epochs: int, minibatch: int, rng: np.random.Generator,
@@ -210,4 +244,6 @@ def dp_run(local, comm: Comm, n: int, epochs: int, minibatch: int, rng: np.rando
             perm = perms[k] if perms is not None else rng.permutation(local.n_local)
             k += 1
             losses.append(dp_train_epoch(local, comm, minibatch, counts, np.asarray(perm)))
+            if hasattr(local, "check_target"):
+                local.check_target()                    # deferred DomainError of the device-resident target
     return losses

@@ -69,8 +69,17 @@ class OracleLocal:
     def set_loss_weights(self, w):
         self.w = np.asarray(w, np.float64)
 
-    def local_grads(self, idx, gb):
+    def epoch_begin(self, perm):
+        self.perm, self.lsum, self.dead = np.asarray(perm), 0.0, False
+
+    def epoch_end(self):
+        if self.dead:
+            raise self.O.DomainError("collapsed")
+        return self.lsum
+
+    def local_grads(self, first, nidx, gb):
         O = self.O
+        idx = self.perm[first:first + nidx]
         out, cache = O.forward_cache(self.m, self.xs[:, idx])
         r = (out - self.target[:, idx]) * self.w[:, None]
         grads = O.backward(self.m, cache, 2 * r * self.w[:, None] / gb)
@@ -80,15 +89,16 @@ class OracleLocal:
 
     def apply(self):
         l = float(self.grad_tensor[self.P])
-        if not np.isfinite(l):
-            raise self.O.DomainError("collapsed")
+        if self.dead or not np.isfinite(l):
+            self.dead = True
+            return
+        self.lsum += l
         flat = self.grad_tensor[:self.P].numpy()
         grads, off = [], 0
         for a in self.m.arrays():
             grads.append(flat[off:off + a.size].reshape(a.shape, order="F"))
             off += a.size
         self.O.update(self.st, self.m, grads)
-        return l
 
 
 def _case(nout, n=53):

@@ -328,3 +328,28 @@ def test_argument_errors(gpu_pkg):
     with pytest.raises(pkg.IskError):        # no target yet
         pkg.train_batch(iso, None)
     iso.close()
+
+
+@pytest.mark.parametrize("nout,minibatch", [(1, 32), (3, 0), (3, 48)])
+def test_dp_driver_single_rank_matches_run(gpu_pkg, nout, minibatch):
+    """the data-parallel driver (dp.py + isk_dp_* entry points) with one rank and no process group
+    must reproduce isk_run on the same injected shuffles"""
+    import importlib
+    import torch
+    pkg = gpu_pkg
+    dp = importlib.import_module("isokann_jl_amd.dp")
+    data, odata, om = _coords_case(pkg, 16, 40, 144, 3, nout, seed=30 + nout)
+    rng = np.random.default_rng(5)
+    perms = [rng.permutation(144) for _ in range(3)]
+    a = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(1e-2, 1e-3), minibatch=minibatch)
+    b = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(1e-2, 1e-3), minibatch=minibatch)
+    pkg.run(a, 3, 1, perms=np.stack(perms))
+    torch.cuda.set_device(0)
+    local = dp.HipLocal(b)
+    losses = dp.dp_run(local, dp.Comm(device=torch.device("cuda", 0)), 3, 1, minibatch, rng, perms=perms)
+    np.testing.assert_allclose(losses, a.losses, rtol=2e-5)
+    # ISA on the host (gathered path) vs the device kernel: same algorithm, Float64 both
+    np.testing.assert_allclose(b.model.get_params(), a.model.get_params(), atol=2e-6, rtol=2e-4)
+    np.testing.assert_allclose(pkg.chis(b), pkg.chis(a), atol=1e-5)
+    a.close()
+    b.close()
