@@ -196,10 +196,18 @@ def main():
         tm = iso.timers(enable=False)
         ffwd, fwd_flops, step_flops = algorithmic_flops(widths, N, K, nb_rows)
         ms, cnt = tm["fwd_ys"]
+        traffic = None
+        try:        # HBM bytes per launch of this kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            if args.workload == "c3" and not args.cached_features:
+                traffic = pm["mlp_fwd_traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         if cnt:
             avg = ms / cnt
             ach = fwd_flops / (avg * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+            roof = {"bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": (N * K + (N if widths[-1] > 1 else 0)) * ((widths[0] + 15) // 16 * 16) * 4,
                     "kernel": f"mlp_fwd_kernel<{(widths[1] + 15) // 16}>", "avg_ms": avg, "launches": cnt,
                     "flops_per_launch": fwd_flops,
                     "phases_ms": {k: (v[0] / v[1] if v[1] else None) for k, v in tm.items()}}
