@@ -1,0 +1,88 @@
+"""Full-size (BASELINE.json configs C2 and C3) GPU tests through size-independent properties:
+the oracle cannot finish these sizes in seconds, so the checks are invariants of the path plus
+oracle spot checks on a sub-sample of columns."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import isokann_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _workload(pkg, name, **kw):
+    synth = importlib.import_module("isokann_jl_amd.synth")
+    c = synth.WORKLOADS[name]
+    xs, ys = synth.synthetic_coords(c["atoms"], c["N"], c["K"], seed=0)
+    if c["feat"] == "all":
+        feat, ofeat, F = pkg.FeaturesAll(), O.FeaturesAll(), c["atoms"] * (c["atoms"] - 1) // 2
+    else:
+        pairs = synth.random_pairs(c["atoms"], c["feat"], seed=0)
+        feat, ofeat, F = pkg.FeaturesPairs(pairs), O.FeaturesPairs(pairs), c["feat"]
+    widths = pkg.pairnet_widths(F, nout=c["nout"])
+    model = pkg.densenet(widths, layernorm=True, seed=3)
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, feat), opt=pkg.AdamRegularized(), model=model, **kw)
+    om = O.glorot_model(widths, np.random.default_rng(0))
+    om.set_flat(model.params.astype(np.float64))
+    return iso, om, ofeat, xs, ys, c
+
+
+def test_synthetic_generators_agree_with_oracle_copy(gpu_pkg):
+    synth = importlib.import_module("isokann_jl_amd.synth")
+    assert synth.random_pairs(50, 100, seed=4) == O.random_pairs(50, 100, seed=4)
+
+
+def test_c3_full_size_properties(gpu_pkg):
+    pkg = gpu_pkg
+    iso, om, ofeat, xs, ys, c = _workload(pkg, "c3", minibatch=1000, featurize_every_iteration=True)
+    N, K, d = c["N"], c["K"], c["nout"]
+    # (1) spot check vs the oracle on a sample of columns: chi, koopman
+    idx = np.random.default_rng(1).choice(N, size=64, replace=False)
+    chi = pkg.chis(iso)
+    ks = pkg.koopman(iso)
+    fx = ofeat(np.asarray(xs[:, idx], np.float64))
+    fy = ofeat(np.asarray(ys[:, :, idx], np.float64))
+    np.testing.assert_allclose(chi[:, idx], om(fx), atol=2e-5)
+    np.testing.assert_allclose(ks[:, idx], O.expectation(om, fy), atol=2e-5)
+    # (2) koopman is the K-mean of the model over the propagated samples (linearity of expectation)
+    sub = pkg.chicoords(iso, ys[:, :, idx])                      # (d, K, 64) through featurize + forward
+    np.testing.assert_allclose(sub.mean(axis=1), ks[:, idx], atol=2e-6)
+    # (3) ISA target: the selected columns are the identity, every other column is an affine image of ks
+    t = pkg.isotarget(iso)
+    sel = O.indexmap(ks.T.astype(np.float64))
+    scale = np.abs(t).max()
+    assert np.allclose(np.sort(t[:, sel], axis=0)[-1], 1.0, atol=1e-4 * scale)
+    assert np.allclose(np.abs(t[:, sel]).sum(axis=0), 1.0, atol=1e-3 * scale)
+    A = np.linalg.lstsq(ks.T.astype(np.float64), t.T.astype(np.float64), rcond=None)[0]
+    assert np.abs(ks.T @ A - t.T).max() < 1e-4 * scale          # target is linear in ks (A' * ks)
+    # (4) training: losses finite and decreasing over a few iterations; parameters move; chi stays finite
+    p0 = iso.model.get_params()
+    pkg.run(iso, 6)
+    assert np.all(np.isfinite(iso.losses)) and iso.losses[-1] < iso.losses[0]
+    assert np.abs(iso.model.get_params() - p0).max() > 0
+    assert np.all(np.isfinite(pkg.chis(iso)))
+    # (5) idempotence of the per-iteration featurization: cached and per-iteration engines agree
+    iso2, *_ = _workload(pkg, "c3", minibatch=1000, featurize_every_iteration=False)
+    pkg.run(iso2, 6)
+    np.testing.assert_allclose(iso2.losses, iso.losses, rtol=1e-6)
+    iso.close()
+    iso2.close()
+
+
+def test_c2_full_size_matches_oracle_end_to_end(gpu_pkg):
+    """C2 (ADP, 231 features, N=1000, K=10) is small enough for the oracle: full run parity"""
+    pkg = gpu_pkg
+    iso, om, ofeat, xs, ys, c = _workload(pkg, "c2", minibatch=100)
+    N = c["N"]
+    rng = np.random.default_rng(2)
+    perms = np.stack([rng.permutation(N) for _ in range(5)])
+    odata = O.SimulationData(np.asarray(xs, np.float64), np.asarray(ys, np.float64), ofeat)
+    oiso = O.Iso(odata, om, O.setup(O.AdamRegularized(), om), minibatch=100)
+    t = pkg.isotarget(iso)
+    assert t.min() == 0.0 and t.max() == 1.0
+    pkg.run(iso, 5, 1, perms=perms)
+    O.run(oiso, 5, 1, perms=list(perms))
+    np.testing.assert_allclose(iso.losses, oiso.losses, rtol=2e-4)
+    np.testing.assert_allclose(pkg.chis(iso), O.chis(oiso), atol=2e-5)
+    iso.close()
