@@ -540,7 +540,7 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
     const TrainShape ts = train_shape(e);
     HIPCHK(hipMalloc((void**)&e->d_part, (size_t)isk_train_part_floats(ts, (int)N) * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_perm, (size_t)N * sizeof(int)));
-    if (e->cfg.target_kind == ISK_TARGET_ISA) HIPCHK(hipMalloc((void**)&e->d_isa_work, (size_t)2 * N * e->nout * sizeof(double)));
+    if (e->cfg.target_kind == ISK_TARGET_ISA) HIPCHK(hipMalloc((void**)&e->d_isa_work, (size_t)isk_isa_work_doubles(N, e->nout) * sizeof(double)));
     HIPCHK(hipMemcpyAsync(e->d_in_xs, xs, (size_t)N * D * sizeof(float), kind, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_in_ys, ys, (size_t)N * K * D * sizeof(float), kind, e->stream));
     featurize_resident(e);
@@ -1128,7 +1128,7 @@ extern "C" int isk_dp_isa_dev(isk_engine* e, const float* ks_all_dev, const floa
         HIPCHK(hipStreamSynchronize(e->stream));
         free_dev(e->d_isa_work_dp);
         e->d_isa_work_dp = nullptr;
-        HIPCHK(hipMalloc((void**)&e->d_isa_work_dp, (size_t)2 * n_global * d * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&e->d_isa_work_dp, (size_t)isk_isa_work_doubles(n_global, d) * sizeof(double)));
         e->isa_work_dp_rows = n_global;
     }
     IsaArgs ia;

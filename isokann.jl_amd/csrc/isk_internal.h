@@ -85,7 +85,7 @@ void isk_launch_isa_apply(const float* ks, const float* At /*[d*d] device, row-m
 struct IsaArgs {
     const float* ks;        // [N][d]
     const float* chi;       // [N][d]
-    double* work;           // [2*N*d] Float64 scratch
+    double* work;           // isk_isa_work_doubles(N, d) Float64 scratch
     float* target;          // [N][d]
     float* lossw;           // [d]
     int* status;            // bit 1 (value 2): singular / non-finite
@@ -93,6 +93,7 @@ struct IsaArgs {
     long long out_first, out_count;   // rows [out_first, out_first + out_count) of the target are written (data-parallel: the local shard)
 };
 void isk_launch_isa(const IsaArgs& a, hipStream_t st);
+long long isk_isa_work_doubles(long long N, int d);
 
 // ---------------------------------------------------------------- training --------
 struct TrainShape {

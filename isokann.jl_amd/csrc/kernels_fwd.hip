@@ -679,398 +679,3 @@ void isk_launch_isa_apply(const float* ks, const float* At, const int* rowperm, 
     hipLaunchKernelGGL(isa_apply_kernel, dim3((unsigned)b), dim3(256), 0, st, ks, At, rowperm, target, N, d);
 }
 
-// =====================================================================================
-// Device-side inner simplex algorithm (TransformISA, src/isotarget.jl:74-127 of the reference):
-// one 1024-thread workgroup, Float64 throughout as the reference's host solve.  Keeps the whole
-// iteration on the device: no chi/ks download, no target upload, no host synchronisation.
-//   X = Float64(ks')                       N x d
-//   ind = PCCAPlus.indexmap(X or X*C^-1/2)  d passes: max-norm row, translate / normalise+project
-//   A = inv(X[ind, :]);  T = A' * ks
-//   fixperm: argmin over the d! row permutations (lexicographic, first minimiser) of sum |T[p] - chi|
-//   loss weights 1 ./ std(target, dims=2) (corrected) from the Float32-rounded target
-// status bit 1 (value 2) is raised for a singular / non-finite simplex (DomainError in the reference).
-// =====================================================================================
-#define ISA_T 1024
-#define ISA_MAXD 8
-#define ISA_R 4           // rows per thread per trip: their loads are issued together (latency-bound kernel)
-
-// sum M per-thread doubles over the workgroup; result valid in every thread
-template <int M>
-__device__ __forceinline__ void block_sum_multi(double (&v)[M], double* sh /* [M][ISA_T/64] */) {
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v[m] += __shfl_xor(v[m], o, WAVE);
-    }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int m = 0; m < M; ++m) sh[m * (ISA_T / 64) + (threadIdx.x >> 6)] = v[m];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        double t = 0;
-#pragma unroll
-        for (int i = 0; i < ISA_T / 64; ++i) t += sh[m * (ISA_T / 64) + i];
-        v[m] = t;
-    }
-}
-
-// workgroup argmax of (value, first index); result broadcast through shd[0] / shi[0]
-__device__ __forceinline__ void block_argmax(double bv, long long bi, double* shd, long long* shi) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(bv, o, WAVE);
-        const long long oi = __shfl_xor(bi, o, WAVE);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { shd[threadIdx.x >> 6] = bv; shi[threadIdx.x >> 6] = bi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < ISA_T / 64; ++i)
-            if (shd[i] > bv || (shd[i] == bv && shi[i] < bi)) { bv = shd[i]; bi = shi[i]; }
-        shd[0] = bv;
-        shi[0] = bi;
-    }
-    __syncthreads();
-}
-
-template <int D>
-__global__ __launch_bounds__(ISA_T) void isa_kernel(IsaArgs a) {
-    __shared__ double shd[ISA_MAXD * ISA_MAXD * (ISA_T / 64)];
-    __shared__ long long shi[ISA_T / 64];
-    __shared__ double Am[D * D];                   // inverse of ks[ind, :]
-    __shared__ double Wm[D * D];                   // whitening matrix
-    __shared__ double vrow[D];
-    __shared__ double Cst[D * D];
-    __shared__ int ind[D], rperm[D];
-    __shared__ int bad;
-    const int tid = threadIdx.x;
-    const long long N = a.N;
-    double* X = a.work;                 // [N][D] working copy for indexmap
-    double* T = a.work + N * D;         // [N][D] target before the permutation
-    if (tid == 0) bad = 0;
-    __syncthreads();
-    // ---- pass 0: X = Float64(ks'), finiteness, (whitening moments | first norms) ----
-    double bv = -1.0;
-    long long bi = 0x7fffffffffffffffLL;
-    {
-        int nf = 0;
-        double cm[D * D];
-#pragma unroll
-        for (int i = 0; i < D * D; ++i) cm[i] = 0;
-        for (long long n0 = tid; n0 < N; n0 += (long long)ISA_T * ISA_R) {
-            float kv[ISA_R][D];
-#pragma unroll
-            for (int r = 0; r < ISA_R; ++r) {
-                const long long n = n0 + (long long)r * ISA_T;
-#pragma unroll
-                for (int k = 0; k < D; ++k) kv[r][k] = (n < N) ? a.ks[n * D + k] : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < ISA_R; ++r) {
-                const long long n = n0 + (long long)r * ISA_T;
-                if (n < N) {
-                    double s = 0;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        nf |= !isfinite(kv[r][k]);
-                        const double x = (double)kv[r][k];
-                        X[n * D + k] = x;
-                        s += x * x;
-                    }
-                    if (a.whitening) {
-#pragma unroll
-                        for (int i = 0; i < D; ++i)
-#pragma unroll
-                            for (int j = 0; j < D; ++j) cm[i * D + j] += (double)kv[r][i] * (double)kv[r][j];
-                    }
-                    s = sqrt(s);
-                    if (s > bv) { bv = s; bi = n; }
-                }
-            }
-        }
-        if (nf) atomicOr(&bad, 1);
-        if (a.whitening) {
-            block_sum_multi<D * D>(cm, shd);
-            if (tid == 0) {
-                // cyclic Jacobi: C = V diag(ev) V'  ->  Wm = V diag(ev^-1/2) V'
-                double V[D * D], Aj[D * D];
-                for (int i = 0; i < D * D; ++i) { Aj[i] = cm[i] / (double)N; V[i] = 0; }
-                for (int i = 0; i < D; ++i) V[i * D + i] = 1;
-                for (int sweep = 0; sweep < 100; ++sweep) {
-                    double off = 0;
-                    for (int i = 0; i < D; ++i)
-                        for (int j = i + 1; j < D; ++j) off += Aj[i * D + j] * Aj[i * D + j];
-                    if (off < 1e-300) break;
-                    for (int p = 0; p < D; ++p)
-                        for (int q = p + 1; q < D; ++q) {
-                            if (fabs(Aj[p * D + q]) < 1e-300) continue;
-                            const double th = (Aj[q * D + q] - Aj[p * D + p]) / (2 * Aj[p * D + q]);
-                            const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1));
-                            const double c = 1 / sqrt(t * t + 1), sn = t * c;
-                            for (int k = 0; k < D; ++k) {
-                                const double akp = Aj[k * D + p], akq = Aj[k * D + q];
-                                Aj[k * D + p] = c * akp - sn * akq; Aj[k * D + q] = sn * akp + c * akq;
-                            }
-                            for (int k = 0; k < D; ++k) {
-                                const double apk = Aj[p * D + k], aqk = Aj[q * D + k];
-                                Aj[p * D + k] = c * apk - sn * aqk; Aj[q * D + k] = sn * apk + c * aqk;
-                            }
-                            for (int k = 0; k < D; ++k) {
-                                const double vkp = V[k * D + p], vkq = V[k * D + q];
-                                V[k * D + p] = c * vkp - sn * vkq; V[k * D + q] = sn * vkp + c * vkq;
-                            }
-                        }
-                }
-                for (int i = 0; i < D; ++i)
-                    if (!(Aj[i * D + i] > 0)) bad = 1;
-                for (int i = 0; i < D; ++i)
-                    for (int j = 0; j < D; ++j) {
-                        double sacc = 0;
-                        for (int k = 0; k < D; ++k) sacc += V[i * D + k] * V[j * D + k] / sqrt(Aj[k * D + k]);
-                        Wm[i * D + j] = sacc;
-                    }
-            }
-            __syncthreads();
-            // X <- X * Wm, norms of the whitened rows
-            bv = -1.0;
-            bi = 0x7fffffffffffffffLL;
-            for (long long n0 = tid; n0 < N; n0 += (long long)ISA_T * ISA_R) {
-                double xv[ISA_R][D];
-#pragma unroll
-                for (int r = 0; r < ISA_R; ++r) {
-                    const long long n = n0 + (long long)r * ISA_T;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) xv[r][k] = (n < N) ? X[n * D + k] : 0.0;
-                }
-#pragma unroll
-                for (int r = 0; r < ISA_R; ++r) {
-                    const long long n = n0 + (long long)r * ISA_T;
-                    if (n < N) {
-                        double s = 0;
-#pragma unroll
-                        for (int j = 0; j < D; ++j) {
-                            double y = 0;
-#pragma unroll
-                            for (int k = 0; k < D; ++k) y += xv[r][k] * Wm[k * D + j];
-                            X[n * D + j] = y;
-                            s += y * y;
-                        }
-                        s = sqrt(s);
-                        if (s > bv) { bv = s; bi = n; }
-                    }
-                }
-            }
-        }
-    }
-    // ---- indexmap: each update pass also produces the norms / argmax of the next step ----
-    for (int j = 0; j < D; ++j) {
-        block_argmax(bv, bi, shd, shi);
-        const double rn = shd[0];
-        const long long bsel = shi[0];
-        if (tid == 0) ind[j] = (int)bsel;
-        if (tid < D) vrow[tid] = X[bsel * D + tid] * ((j == 0) ? 1.0 : 1.0 / rn);
-        __syncthreads();
-        if (j == D - 1) break;
-        const double inv = (j == 0) ? 1.0 : 1.0 / rn;
-        double vr[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k) vr[k] = vrow[k];
-        bv = -1.0;
-        bi = 0x7fffffffffffffffLL;
-        for (long long n0 = tid; n0 < N; n0 += (long long)ISA_T * ISA_R) {
-            double xv[ISA_R][D];
-#pragma unroll
-            for (int r = 0; r < ISA_R; ++r) {
-                const long long n = n0 + (long long)r * ISA_T;
-#pragma unroll
-                for (int k = 0; k < D; ++k) xv[r][k] = (n < N) ? X[n * D + k] : 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < ISA_R; ++r) {
-                const long long n = n0 + (long long)r * ISA_T;
-                if (n < N) {
-                    double s = 0;
-                    if (j == 0) {
-#pragma unroll
-                        for (int k = 0; k < D; ++k) { xv[r][k] -= vr[k]; }
-                    } else {
-                        double dot = 0;
-#pragma unroll
-                        for (int k = 0; k < D; ++k) { xv[r][k] *= inv; dot += xv[r][k] * vr[k]; }
-#pragma unroll
-                        for (int k = 0; k < D; ++k) xv[r][k] -= dot * vr[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < D; ++k) { X[n * D + k] = xv[r][k]; s += xv[r][k] * xv[r][k]; }
-                    s = sqrt(s);
-                    if (s > bv) { bv = s; bi = n; }
-                }
-            }
-        }
-    }
-    // ---- A = inv(Float64(ks)[ind, :]) : Gauss-Jordan with partial pivoting ----
-    if (tid == 0) {
-        double M[D * 2 * D];
-        for (int i = 0; i < D; ++i)
-            for (int j = 0; j < D; ++j) { M[i * 2 * D + j] = (double)a.ks[(long long)ind[i] * D + j]; M[i * 2 * D + D + j] = (i == j) ? 1.0 : 0.0; }
-        // elimination with the multiplier taken against the UNSCALED pivot row (as LU does), so exactly
-        // dependent rows cancel to exact zeros and are reported singular like Julia's inv()
-        for (int c = 0; c < D && !bad; ++c) {
-            int p = c;
-            for (int r = c + 1; r < D; ++r)
-                if (fabs(M[r * 2 * D + c]) > fabs(M[p * 2 * D + c])) p = r;
-            const double pv = M[p * 2 * D + c];
-            if (!(fabs(pv) > 0.0) || !isfinite(pv)) { bad = 1; break; }
-            if (p != c)
-                for (int j = 0; j < 2 * D; ++j) { const double t = M[p * 2 * D + j]; M[p * 2 * D + j] = M[c * 2 * D + j]; M[c * 2 * D + j] = t; }
-            for (int r = 0; r < D; ++r) {
-                if (r == c) continue;
-                const double f = M[r * 2 * D + c] / pv;
-                if (f == 0.0) continue;
-                for (int j = 0; j < 2 * D; ++j) M[r * 2 * D + j] -= f * M[c * 2 * D + j];
-                M[r * 2 * D + c] = 0.0;
-            }
-        }
-        for (int c = 0; c < D && !bad; ++c) {
-            const double inv = 1.0 / M[c * 2 * D + c];
-            for (int j = 0; j < 2 * D; ++j) M[c * 2 * D + j] *= inv;
-        }
-        for (int i = 0; i < D; ++i)
-            for (int j = 0; j < D; ++j) {
-                Am[i * D + j] = M[i * 2 * D + D + j];
-                if (!isfinite(Am[i * D + j])) bad = 1;
-            }
-    }
-    __syncthreads();
-    if (bad) {
-        if (tid == 0) atomicOr(a.status, 2);
-        return;
-    }
-    // ---- T = A' * ks, and the fixperm cost matrix in the same pass ----
-    {
-        double Al[D * D];
-#pragma unroll
-        for (int i = 0; i < D * D; ++i) Al[i] = Am[i];
-        double cst[D * D];
-#pragma unroll
-        for (int i = 0; i < D * D; ++i) cst[i] = 0;
-        for (long long n0 = tid; n0 < N; n0 += (long long)ISA_T * ISA_R) {
-            float kv[ISA_R][D], cv[ISA_R][D];
-#pragma unroll
-            for (int r = 0; r < ISA_R; ++r) {
-                const long long n = n0 + (long long)r * ISA_T;
-#pragma unroll
-                for (int k = 0; k < D; ++k) { kv[r][k] = (n < N) ? a.ks[n * D + k] : 0.f; cv[r][k] = (n < N) ? a.chi[n * D + k] : 0.f; }
-            }
-#pragma unroll
-            for (int r = 0; r < ISA_R; ++r) {
-                const long long n = n0 + (long long)r * ISA_T;
-                if (n < N) {
-                    double tq[D];
-#pragma unroll
-                    for (int q = 0; q < D; ++q) {
-                        double sacc = 0;
-#pragma unroll
-                        for (int b = 0; b < D; ++b) sacc += Al[b * D + q] * (double)kv[r][b];
-                        tq[q] = sacc;
-                        T[n * D + q] = sacc;
-                    }
-                    if (a.permute) {
-#pragma unroll
-                        for (int q = 0; q < D; ++q)
-#pragma unroll
-                            for (int i = 0; i < D; ++i) cst[q * D + i] += fabs(tq[q] - (double)cv[r][i]);
-                    }
-                }
-            }
-        }
-        if (tid < D) rperm[tid] = tid;
-        if (a.permute) {
-            block_sum_multi<D * D>(cst, shd);
-            if (tid == 0) {
-                for (int i = 0; i < D * D; ++i) Cst[i] = cst[i];
-                int p[D], best[D];
-                for (int i = 0; i < D; ++i) p[i] = i;
-                double bc = 0;
-                bool first = true;
-                while (true) {
-                    double c = 0;
-                    for (int i = 0; i < D; ++i) c += Cst[p[i] * D + i];
-                    if (first || c < bc) { bc = c; first = false; for (int i = 0; i < D; ++i) best[i] = p[i]; }
-                    int i = D - 2;                      // next lexicographic permutation
-                    while (i >= 0 && p[i] >= p[i + 1]) --i;
-                    if (i < 0) break;
-                    int j = D - 1;
-                    while (p[j] <= p[i]) --j;
-                    { const int t = p[i]; p[i] = p[j]; p[j] = t; }
-                    for (int l = i + 1, r = D - 1; l < r; ++l, --r) { const int t = p[l]; p[l] = p[r]; p[r] = t; }
-                }
-                for (int i = 0; i < D; ++i) rperm[i] = best[i];
-            }
-        }
-        __syncthreads();
-    }
-    // ---- target (Float32) and the moments of the loss weights, one pass ----
-    {
-        int rp[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) rp[i] = rperm[i];
-        double mom[2 * D];
-#pragma unroll
-        for (int i = 0; i < 2 * D; ++i) mom[i] = 0;
-        // shift by the first row's value: keeps sum(t^2) - sum(t)^2/N well conditioned in Float64
-        double sh0[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) sh0[i] = (double)(float)T[rp[i]];
-        for (long long n0 = tid; n0 < N; n0 += (long long)ISA_T * ISA_R) {
-            double tv[ISA_R][D];
-#pragma unroll
-            for (int r = 0; r < ISA_R; ++r) {
-                const long long n = n0 + (long long)r * ISA_T;
-#pragma unroll
-                for (int k = 0; k < D; ++k) tv[r][k] = (n < N) ? T[n * D + k] : 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < ISA_R; ++r) {
-                const long long n = n0 + (long long)r * ISA_T;
-                if (n < N) {
-#pragma unroll
-                    for (int i = 0; i < D; ++i) {
-                        double v = 0;
-#pragma unroll
-                        for (int k = 0; k < D; ++k) v = (rp[i] == k) ? tv[r][k] : v;
-                        const float vf = (float)v;                 // T(target): back to Float32
-                        if (n >= a.out_first && n < a.out_first + a.out_count) a.target[(n - a.out_first) * D + i] = vf;
-                        const double c = (double)vf - sh0[i];
-                        mom[i] += c;
-                        mom[D + i] += c * c;
-                    }
-                }
-            }
-        }
-        block_sum_multi<2 * D>(mom, shd);
-        if (tid < D) {
-            double s1 = 0, s2 = 0;
-#pragma unroll
-            for (int i = 0; i < D; ++i) { s1 = (tid == i) ? mom[i] : s1; s2 = (tid == i) ? mom[D + i] : s2; }
-            const double var = (s2 - s1 * s1 / (double)N) / (double)(N - 1);
-            a.lossw[tid] = (float)(1.0 / sqrt(var));
-        }
-    }
-}
-
-void isk_launch_isa(const IsaArgs& a, hipStream_t st) {
-    switch (a.d) {
-        case 2: hipLaunchKernelGGL(isa_kernel<2>, dim3(1), dim3(ISA_T), 0, st, a); break;
-        case 3: hipLaunchKernelGGL(isa_kernel<3>, dim3(1), dim3(ISA_T), 0, st, a); break;
-        case 4: hipLaunchKernelGGL(isa_kernel<4>, dim3(1), dim3(ISA_T), 0, st, a); break;
-        case 5: hipLaunchKernelGGL(isa_kernel<5>, dim3(1), dim3(ISA_T), 0, st, a); break;
-        case 6: hipLaunchKernelGGL(isa_kernel<6>, dim3(1), dim3(ISA_T), 0, st, a); break;
-        case 7: hipLaunchKernelGGL(isa_kernel<7>, dim3(1), dim3(ISA_T), 0, st, a); break;
-        default: hipLaunchKernelGGL(isa_kernel<8>, dim3(1), dim3(ISA_T), 0, st, a); break;
-    }
-}
