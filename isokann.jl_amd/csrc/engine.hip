@@ -130,6 +130,7 @@ struct isk_engine {
     long long isa_work_dp_rows = 0;
     uint64_t rng[4];
     int dp_perm_len = 0;
+    int last_nslab = 1;
     // timers
     bool timers_on = false;
     std::vector<EventPair> ev_live, ev_free;
@@ -345,7 +346,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
         return fail(ISK_EHIP, "side stream / event creation failed");
     }
     const size_t pb = (size_t)(e->nparams + 2) * sizeof(float);
-    ALLOC(e->d_theta, pb); ALLOC(e->d_grad, pb); ALLOC(e->d_m, pb); ALLOC(e->d_v, pb);
+    ALLOC(e->d_theta, pb); ALLOC(e->d_grad, pb * ISK_MAX_SLABS); ALLOC(e->d_m, pb); ALLOC(e->d_v, pb);
     ALLOC(e->d_loss_acc, 2 * sizeof(double)); ALLOC(e->d_status, sizeof(int)); ALLOC(e->d_mm, 2 * sizeof(float));
     ALLOC(e->d_lossw, (size_t)nout * sizeof(float));
     ALLOC(e->d_At, (size_t)nout * nout * sizeof(float)); ALLOC(e->d_rowperm, (size_t)nout * sizeof(int));
@@ -364,7 +365,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
         }
     }
 #undef ALLOC
-    (void)hipMemset(e->d_theta, 0, pb); (void)hipMemset(e->d_grad, 0, pb);
+    (void)hipMemset(e->d_theta, 0, pb); (void)hipMemset(e->d_grad, 0, pb * ISK_MAX_SLABS);
     (void)hipMemset(e->d_m, 0, pb); (void)hipMemset(e->d_v, 0, pb);
     (void)hipMemset(e->d_loss_acc, 0, 2 * sizeof(double)); (void)hipMemset(e->d_status, 0, sizeof(int));
     std::vector<float> ones(nout, 1.0f);
@@ -930,12 +931,22 @@ extern "C" int isk_target(isk_engine* e, float* out) {
 // ---------------------------------------------------------------------------------------
 // training
 // ---------------------------------------------------------------------------------------
-static void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div) {
+// nslab > 1: the layer-1 gradient GEMM splits the batch rows over `nslab` workgroups per feature tile
+// (twice the CUs, half the MFMA chain each); the optimizer kernel sums the slabs.  The data-parallel
+// path keeps nslab = 1 because the flat all-reduce buffer is slab 0.
+static int pick_slabs(int B) {
+    const int nchunks = (B + 15) / 16;
+    int s = (nchunks + 47) / 48;                  // about three 16-row chunks per wave
+    return s < 1 ? 1 : (s > ISK_MAX_SLABS ? ISK_MAX_SLABS : s);
+}
+
+static void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nslab = 1) {
     const TrainShape s = train_shape(e);
     const TrainBuffers b = train_buffers(e);
     isk_launch_train_fwd1(s, b, d_idx, B, e->stream);
     isk_launch_train_tail(s, b, d_idx, B, inv_div, e->stream);
-    isk_launch_train_grad1(s, b, d_idx, B, 1, e->stream);
+    isk_launch_train_grad1(s, b, d_idx, B, nslab, e->stream);
+    e->last_nslab = nslab;
 }
 
 static void launch_opt(isk_engine* e, float gscale) {
@@ -945,6 +956,8 @@ static void launch_opt(isk_engine* e, float gscale) {
     a.eps = e->cfg.opt_eps; a.rho = e->cfg.rho;
     a.bc1 = (float)(1.0 - e->bt1); a.bc2 = (float)(1.0 - e->bt2);
     a.gscale = gscale; a.loss_acc = e->d_loss_acc;
+    a.nslab = e->last_nslab;
+    a.slab_prefix = (e->cfg.layernorm ? 2LL * e->F : 0LL) + (long long)e->F * e->cfg.widths[1] + e->cfg.widths[1];
     isk_launch_opt_step(a, e->stream);
     e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2;
     launch_fold(e);
@@ -980,7 +993,7 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
     {
         ScopedTimer t(e, ISK_T_TRAIN);
         for (long long b = 0; b < nb; ++b) {
-            launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs);
+            launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, pick_slabs((int)bs));
             launch_opt(e, 1.0f);
         }
     }

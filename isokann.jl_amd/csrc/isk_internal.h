@@ -122,7 +122,8 @@ struct TrainBuffers {
 // batch rows are perm[first .. first+B)
 void isk_launch_train_fwd1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, hipStream_t st);
 void isk_launch_train_tail(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div, hipStream_t st);
-void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int accumulate_loss, hipStream_t st);
+void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st);
+#define ISK_MAX_SLABS 8
 int  isk_train_tail_nblocks(int B);
 long long isk_train_part_floats(const TrainShape& s, int maxB);
 
@@ -131,6 +132,7 @@ struct OptArgs {
     long long n;
     int kind; float lr, reg, beta1, beta2, eps, rho;
     float bc1, bc2;         // 1 - beta1^t, 1 - beta2^t for this step
+    int nslab; long long slab_prefix;   // gradient slabs to sum for parameter indices < slab_prefix
     float gscale;           // gradient multiplier (1, or 1/global_batch in data-parallel mode)
     const double* loss_acc; // collapsed flag at [1]: skip the update when set (src/iso.jl:186-189 throws before update!)
 };

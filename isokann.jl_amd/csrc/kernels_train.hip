@@ -341,10 +341,12 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int ft = blockIdx.x;
+    const int slab = blockIdx.y, nslab = gridDim.y;     // batch rows are split over `nslab` workgroups per feature tile;
+    float* const gout = b.grad + (long long)slab * (s.nparams + 2);   // each writes its (linear) share to its own gradient slab
     const long long PS = part_size(s);
     const bool ln = s.layernorm != 0;
-    // small-gradient partial vectors: one element per 16-lane group, lanes split the partials
-    {
+    // small-gradient partial vectors: one element per 16-lane group, lanes split the partials (slab 0 only)
+    if (slab == 0) {
         const long long ngroups = (long long)gridDim.x * (NW * 4);
         const long long grp = (long long)blockIdx.x * (NW * 4) + (tid >> 4);
         for (long long e = grp; e < PS; e += ngroups) {
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
 #pragma unroll
             for (int sft = 8; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft, WAVE);
             const long long gi = part_to_grad(s, e);
-            if (li == 0 && gi >= 0) b.grad[gi] = acc;
+            if (li == 0 && gi >= 0) gout[gi] = acc;
         }
     }
     f32x4 acc[NT];
@@ -368,11 +370,11 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
     for (int t = 0; t < NT; ++t) { acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dsum[t] = 0.f; }
     const int nchunks = (B + 15) / 16;
     const float* Xc = b.xhat_xs + ft * 16 + li;
-    for (int c0 = wave; c0 < nchunks; c0 += NW * CB) {
+    for (int c0 = wave + NW * slab; c0 < nchunks; c0 += NW * CB * nslab) {
         long long rr[CB][4];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            const int chunk = c0 + cb * NW;
+            const int chunk = c0 + cb * NW * nslab;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = chunk * 16 + 4 * lq + j;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
         }
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            const int chunk = c0 + cb * NW;
+            const int chunk = c0 + cb * NW * nslab;
             if (chunk < nchunks) {                                    // wave-uniform
                 const int r0 = chunk * 16 + 4 * lq;
                 float av[4];
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
         Dsh[tid] = d;
         const int t = tid >> 4, l2 = tid & 15;
         const int o = (t < 4 * NB4) ? 64 * (t >> 2) + 4 * l2 + (t & 3) : 16 * t + l2;
-        if (ft == 0 && o < H1) b.grad[s.off_b[0] + o] = d;             // db1 == D
+        if (ft == 0 && o < H1) gout[s.off_b[0] + o] = d;                // db1 == D (this slab's rows)
     }
     __syncthreads();
     // Epilogue, coalesced: wave w owns feature row f = 16*ft + w (NW >= 16 waves cover the tile; with
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
     const float* W1 = b.theta + s.off_W[0];
     const float* g = ln ? b.theta + s.off_lns : nullptr;
     const float* beta = ln ? b.theta + s.off_lnb : nullptr;
-    float* gW1 = b.grad + s.off_W[0];
+    float* gW1 = gout + s.off_W[0];
     for (int fl = wave; fl < 16; fl += NW) {
         const int f = ft * 16 + fl;
         if (f >= F) continue;                                   // wave-uniform
@@ -468,27 +470,27 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
         if (ln) {
             pg = wave_sum_t(pg);
             pb = wave_sum_t(pb);
-            if (lane == 0) { b.grad[s.off_lns + f] = pg; b.grad[s.off_lnb + f] = pb; }
+            if (lane == 0) { gout[s.off_lns + f] = pg; gout[s.off_lnb + f] = pb; }
         }
     }
 }
 
 template <int NT, int NW>
-static void launch_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, hipStream_t st) {
+static void launch_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st) {
     const int nparts = (B + 15) / 16;
     const size_t lds = (size_t)(NW * NT * 256 + NW * NT * 16 + NT * 16) * sizeof(float);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)train_grad1_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((train_grad1_kernel<NT, NW>), dim3(b.Fp / 16), dim3(NW * 64), lds, st, s, b, perm, B, nparts);
+    hipLaunchKernelGGL((train_grad1_kernel<NT, NW>), dim3(b.Fp / 16, nslab), dim3(NW * 64), lds, st, s, b, perm, B, nparts);
 }
 
-void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int, hipStream_t st) {
+void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st) {
     const int nt1 = isk_pad16(s.widths[1]) / 16;
     static const int nw8 = [] { const char* v = getenv("ISK_GRAD1_NW8"); return v ? atoi(v) : 0; }();
-#define G1CASE(NT_) case NT_: if (nw8) launch_grad1<NT_, 8>(s, b, perm, B, st); else launch_grad1<NT_, 16>(s, b, perm, B, st); break;
+#define G1CASE(NT_) case NT_: if (nw8) launch_grad1<NT_, 8>(s, b, perm, B, nslab, st); else launch_grad1<NT_, 16>(s, b, perm, B, nslab, st); break;
     switch (nt1) {
         G1CASE(1) G1CASE(2) G1CASE(3) G1CASE(4) G1CASE(5) G1CASE(6) G1CASE(7) G1CASE(8) G1CASE(9)
-        default: launch_grad1<10, 8>(s, b, perm, B, st); break;
+        default: launch_grad1<10, 8>(s, b, perm, B, nslab, st); break;
     }
 #undef G1CASE
 }
@@ -507,7 +509,10 @@ __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a, double* loss_a
     if (bad) return;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
         const float th = a.theta[i];
-        const float g = a.grad[i] * a.gscale + a.reg * th;
+        float gs = a.grad[i];
+        if (i < a.slab_prefix)                           // [LN | W1 | b1] gradients arrive split over row slabs
+            for (int sl = 1; sl < a.nslab; ++sl) gs += a.grad[(long long)sl * (a.n + 2) + i];
+        const float g = gs * a.gscale + a.reg * th;
         float d;
         if (a.kind == ISK_OPT_ADAM) {
             const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
