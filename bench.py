@@ -43,7 +43,7 @@ def build_iso(pkg, wl, seed, device, args):
     opt = pkg.AdamRegularized() if args.opt == "adam" else pkg.NesterovRegularized()
     data = pkg.SimulationData(xs, ys, feat)
     iso = pkg.Iso(data, opt=opt, model=model, minibatch=args.minibatch, device=device,
-                  featurize_every_iteration=not args.cached_features, seed=seed)
+                  featurize_every_iteration=not args.cached_features, seed=seed, forward_mode=args.forward_mode)
     del xs, ys
     return iso, c, widths
 
@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1000)
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--forward-mode", type=int, default=0, choices=[0, 1], help="0 = f32 MFMA forward, 1 = split-bf16 (bf16x3) forward")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel driver even with one rank (rehearsal)")
     args = ap.parse_args()
 

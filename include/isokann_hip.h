@@ -91,6 +91,11 @@ typedef struct isk_config {
     int32_t minibatch;                   /* Iso.minibatch (default 100; 0 = full batch) */
     uint64_t seed;                       /* shuffle seed for DataLoader(shuffle=true) when no
                                             permutation is injected */
+    int32_t forward_mode;                /* arithmetic of the layer-1 GEMM in the forward over the Koopman
+                                            samples: 0 = f32-input MFMA (exact f32 fma chain),
+                                            1 = split-bf16: three bf16 planes per operand, six bf16 MFMAs per
+                                            product block, f32 accumulate (f32-equivalent accuracy at 2.7x the
+                                            f32 MFMA rate).  Training kernels are f32 in both modes. */
 } isk_config;
 
 /* ---- library ------------------------------------------------------------------ */

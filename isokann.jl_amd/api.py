@@ -227,7 +227,7 @@ def featuredim(d) -> int:
 
 # -------------------------------------------------------------------------------- Iso --
 def _make_config(data: SimulationData, model: ModelSpec, opt: OptSpec, target, minibatch: int, device: int,
-                 featurize_every_iteration: bool, seed: int):
+                 featurize_every_iteration: bool, seed: int, forward_mode: int = 0):
     lib = capi.load()
     cfg = capi.Config()
     lib.isk_config_default(C.byref(cfg))
@@ -270,6 +270,7 @@ def _make_config(data: SimulationData, model: ModelSpec, opt: OptSpec, target, m
         raise TypeError(f"unsupported target transform {target!r}")
     cfg.minibatch = int(minibatch)
     cfg.seed = int(seed)
+    cfg.forward_mode = int(forward_mode)
     return cfg, keep
 
 
@@ -309,7 +310,7 @@ class Iso:
 
     def __init__(self, data: SimulationData, *, opt: Optional[OptSpec] = None, model: Optional[ModelSpec] = None,
                  target=None, minibatch: int = 100, loggers=None, device: int = 0,
-                 featurize_every_iteration: bool = False, seed: int = 0):
+                 featurize_every_iteration: bool = False, seed: int = 0, forward_mode: int = 0):
         self.data = data
         self.optspec = opt if opt is not None else NesterovRegularized()          # src/iso.jl:18
         self.modelspec = model if model is not None else pairnet(data)            # src/simulation.jl:126-127
@@ -324,7 +325,7 @@ class Iso:
         self.nout = outputdim(self.modelspec)
         self._lib = capi.load()
         cfg, keep = _make_config(data, self.modelspec, self.optspec, target, minibatch, device,
-                                 featurize_every_iteration, seed)
+                                 featurize_every_iteration, seed, forward_mode)
         h = C.c_void_p()
         capi.check(self._lib.isk_create(C.byref(cfg), C.byref(h)))
         self._h = h

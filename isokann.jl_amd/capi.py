@@ -54,6 +54,7 @@ class Config(C.Structure):
         ("featurize_every_iteration", C.c_int32),
         ("target_kind", C.c_int32), ("isa_permute", C.c_int32), ("isa_whitening", C.c_int32),
         ("minibatch", C.c_int32), ("seed", C.c_uint64),
+        ("forward_mode", C.c_int32),
     ]
 
 

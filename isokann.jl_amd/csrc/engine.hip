@@ -83,6 +83,7 @@ extern "C" void isk_config_default(isk_config* c) {
     c->isa_permute = 1; c->isa_whitening = 0;   // src/isotarget.jl:74-77
     c->minibatch = 100;                     // src/iso.jl:10
     c->seed = 0;
+    c->forward_mode = 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -106,6 +107,8 @@ struct isk_engine {
     float *d_theta = nullptr, *d_grad = nullptr, *d_m = nullptr, *d_v = nullptr;
     float* d_Wt[ISK_MAX_LAYERS] = {nullptr};
     float* d_bias[ISK_MAX_LAYERS] = {nullptr};
+    void* d_W16 = nullptr;           // split-bf16 planes of the folded layer-1 weights (forward_mode 1)
+    bool w16_dirty = true;
     double* d_loss_acc = nullptr;
     int* d_status = nullptr;
     float* d_mm = nullptr;
@@ -260,11 +263,12 @@ static TrainBuffers train_buffers(const isk_engine* e) {
 static void launch_fold(isk_engine* e) {
     FoldArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.theta = e->d_theta; a.nlayers = e->L;
+    a.theta = e->d_theta; a.nlayers = e->L; a.Kp0 = e->Fp;
     for (int i = 0; i <= e->L; ++i) a.widths[i] = e->cfg.widths[i];
     a.off_lns = e->off_lns; a.off_lnb = e->off_lnb;
     for (int l = 0; l < e->L; ++l) { a.off_W[l] = e->off_W[l]; a.off_b[l] = e->off_b[l]; a.Wt[l] = e->d_Wt[l]; a.bias[l] = e->d_bias[l]; }
     isk_launch_fold(a, e->stream);
+    e->w16_dirty = true;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -319,7 +323,9 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     isk_engine* e = new isk_engine();
     e->cfg = *cfg;
     e->cfg.pairs = nullptr;
-    e->L = cfg->n_layers; e->F = F; e->Fp = isk_pad16(F); e->Din = Din; e->nout = nout;
+    e->L = cfg->n_layers; e->F = F; e->Fp = isk_pad32(F); e->Din = Din; e->nout = nout;
+    if (const char* fm = getenv("ISK_FWD_MODE")) e->cfg.forward_mode = atoi(fm);
+    if (e->cfg.forward_mode != 0 && e->cfg.forward_mode != 1) { delete e; return fail(ISK_EINVAL, "unknown forward_mode"); }
     long long off = 0;
     if (cfg->layernorm) { e->off_lns = off; off += F; e->off_lnb = off; off += F; }
     for (int l = 0; l < e->L; ++l) {
@@ -350,8 +356,9 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     ALLOC(e->d_loss_acc, 2 * sizeof(double)); ALLOC(e->d_status, sizeof(int)); ALLOC(e->d_mm, 2 * sizeof(float));
     ALLOC(e->d_lossw, (size_t)nout * sizeof(float));
     ALLOC(e->d_At, (size_t)nout * nout * sizeof(float)); ALLOC(e->d_rowperm, (size_t)nout * sizeof(int));
+    ALLOC(e->d_W16, (size_t)e->Fp * isk_pad16(cfg->widths[1]) * 3 * sizeof(uint16_t));
     for (int l = 0; l < e->L; ++l) {
-        ALLOC(e->d_Wt[l], (size_t)isk_pad16(cfg->widths[l]) * isk_pad16(cfg->widths[l + 1]) * sizeof(float));
+        ALLOC(e->d_Wt[l], (size_t)(l == 0 ? e->Fp : isk_pad16(cfg->widths[l])) * isk_pad16(cfg->widths[l + 1]) * sizeof(float));
         ALLOC(e->d_bias[l], (size_t)isk_pad16(cfg->widths[l + 1]) * sizeof(float));
     }
     if (!pairs.empty()) {
@@ -391,6 +398,7 @@ extern "C" void isk_destroy(isk_engine* e) {
     free_dev(e->d_loss_acc); free_dev(e->d_status); free_dev(e->d_mm); free_dev(e->d_lossw);
     free_dev(e->d_At); free_dev(e->d_rowperm); free_dev(e->d_pairs); free_dev(e->d_packed); free_dev(e->d_isa_work_dp);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_Wt[l]); free_dev(e->d_bias[l]); }
+    free_dev(e->d_W16);
     drain_timers(e);
     for (auto& ep : e->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (e->ev_fwd_done) (void)hipEventDestroy(e->ev_fwd_done);
@@ -565,6 +573,8 @@ extern "C" int isk_data_shape(isk_engine* e, int64_t* D, int64_t* K, int64_t* N)
 // ---------------------------------------------------------------------------------------
 // featurizer / forward on caller-provided columns (not the resident data)
 // ---------------------------------------------------------------------------------------
+static int launch_forward(isk_engine* e, const MlpFwdArgs& f);
+
 struct TmpBuf {
     void* p = nullptr;
     ~TmpBuf() { if (p) (void)hipFree(p); }
@@ -606,7 +616,7 @@ static int forward_cols(isk_engine* e, const float* host_in, int64_t rowlen, int
     a.background = 0;
     isk_launch_featurize(a, e->stream);
     MlpFwdArgs f = fwd_args(e, (const float*)xh.p, ncols, (float*)o.p);
-    if (isk_launch_mlp_fwd(f, e->stream) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
+    if (launch_forward(e, f) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
     HIPCHK(hipMemcpyAsync(out, o.p, (size_t)ncols * e->nout * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipGetLastError());
@@ -632,6 +642,18 @@ extern "C" int isk_chicoords(isk_engine* e, const float* coords, int64_t D, int6
 // ---------------------------------------------------------------------------------------
 // resident forward, koopman, target
 // ---------------------------------------------------------------------------------------
+// the forward over feature rows: f32 MFMA or split-bf16 (cfg.forward_mode)
+static int launch_forward(isk_engine* e, const MlpFwdArgs& f) {
+    if (e->cfg.forward_mode == 1) {
+        if (e->w16_dirty) {
+            isk_launch_fold_bf16(e->d_Wt[0], e->d_W16, e->Fp, f.nt1, e->stream);
+            e->w16_dirty = false;
+        }
+        return isk_launch_mlp_fwd_bf16x3(f, e->d_W16, e->stream);
+    }
+    return isk_launch_mlp_fwd(f, e->stream);
+}
+
 static int need_data(isk_engine* e) {
     if (!e) return fail(ISK_EINVAL, "null engine");
     if (e->N == 0) return fail(ISK_ESTATE, "no data: call isk_set_data first");
@@ -652,7 +674,7 @@ static int forward_resident(isk_engine* e, int which, bool ahead = false) {
     {
         ScopedTimer t(e, tid);
         MlpFwdArgs f = fwd_args(e, X, S, out);
-        if (isk_launch_mlp_fwd(f, e->stream) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
+        if (launch_forward(e, f) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
     }
     if (ahead) featurize_ys_ahead(e);
     return ISK_OK;

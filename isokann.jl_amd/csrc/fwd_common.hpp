@@ -1,0 +1,130 @@
+// Device helpers shared by the forward kernels (f32 MFMA and split-bf16 variants).
+#pragma once
+#include "isk_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ float act_apply(int act, float z) {
+    switch (act) {
+        case ISK_ACT_SIGMOID: {
+            // NNlib sigmoid_fast semantics: overflow-free 1/(1+exp(-z))
+            float e = __expf(-fabsf(z));
+            float r = 1.0f / (1.0f + e);
+            return z >= 0.f ? r : e * r;
+        }
+        case ISK_ACT_TANH: return tanhf(z);
+        case ISK_ACT_RELU: return fmaxf(z, 0.f);
+        case ISK_ACT_SWISH: {
+            float e = __expf(-fabsf(z));
+            float r = 1.0f / (1.0f + e);
+            return z * (z >= 0.f ? r : e * r);
+        }
+        default: return z;
+    }
+}
+
+
+// epilogue + tail layers for one 16-row unit whose layer-1 pre-activations sit in acc[NT]
+template <int NT>
+__device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT], long long row_base, float* scrA,
+                                          float* scrB, const float* tailw, int lane) {
+    const int li = lane & 15, lq = lane >> 4;
+    int stride = a.stride_a;
+    const bool fast_sig = (a.act1 == ISK_ACT_SIGMOID) && a.ntail > 0;    // wave-uniform
+    // accumulator layout (row = 4*lq + r, col = 16*t + li) -> LDS rows; bias (and, on the common
+    // sigmoid path, the activation) applied on the way, in registers
+    if (fast_sig) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = t * 16 + li;
+            const float bcol = a.bias1[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = acc[t][r] + bcol;
+                const float e = __expf(-fabsf(z));
+                const float q = __builtin_amdgcn_rcpf(1.0f + e);
+                scrA[(lq * 4 + r) * stride + col] = z >= 0.f ? q : e * q;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = t * 16 + li;
+            const float bcol = a.bias1[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scrA[(lq * 4 + r) * stride + col] = acc[t][r] + bcol;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int H1p = NT * 16;
+    if (a.ntail == 0) {
+        for (int row = lq; row < 16; row += 4) {
+            const long long grow = row_base + row;
+            if (li < a.nout && grow < a.S) a.out[grow * a.nout + li] = act_apply(a.act1, scrA[row * stride + li]);
+        }
+        // nout > 16 with a single layer
+        for (int col = 16 + li; col < a.nout; col += 16)
+            for (int row = lq; row < 16; row += 4) {
+                const long long grow = row_base + row;
+                if (grow < a.S) a.out[grow * a.nout + col] = act_apply(a.act1, scrA[row * stride + col]);
+            }
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
+    if (!fast_sig) {
+        for (int row = 0; row < 16; ++row)
+            for (int col = lane; col < H1p; col += WAVE) scrA[row * stride + col] = act_apply(a.act1, scrA[row * stride + col]);
+        __builtin_amdgcn_wave_barrier();
+    }
+    float* in = scrA;
+    float* ob = scrB;
+    int ostride = a.stride_b;
+    for (int l = 0; l < a.ntail; ++l) {
+        const TailLayer L = a.tail[l];
+        const bool last = (l == a.ntail - 1);
+        const f32x4* Wp = (const f32x4*)(tailw + L.lds_off) + lane;     // staged once per workgroup
+        for (int t2 = 0; t2 < L.ntiles; ++t2) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < L.kchunks; ++c) {
+                const f32x4 xa = *(const f32x4*)(in + li * stride + c * 16 + lq * 4);
+                const f32x4 wf = Wp[(long long)(c * L.ntiles + t2) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], wf[j], z, 0, 0, 0);
+            }
+            const int col = t2 * 16 + li;
+            const float bcol = L.bias[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = act_apply(L.act, z[r] + bcol);
+                if (last) {
+                    const long long grow = row_base + lq * 4 + r;
+                    if (col < a.nout && grow < a.S) a.out[grow * a.nout + col] = v;
+                } else {
+                    ob[(lq * 4 + r) * ostride + col] = v;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        float* tmp = in; in = ob; ob = tmp;
+        const int ts = stride; stride = ostride; ostride = ts;
+    }
+}
+
+
+// stage the (small) fragment-linear tail weights in LDS once per workgroup
+__device__ __forceinline__ void stage_tail_weights(const MlpFwdArgs& a, float* smem) {
+    for (int l = 0; l < a.ntail; ++l) {
+        const int n4 = a.tail[l].kchunks * a.tail[l].ntiles * 64;
+        const f32x4* src = (const f32x4*)a.tail[l].Wt;
+        f32x4* dst = (f32x4*)(smem + a.tail[l].lds_off);
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+    }
+}

@@ -10,6 +10,7 @@
 #define ISK_NUM_CU 256
 
 static inline int isk_pad16(int x) { return (x + 15) & ~15; }
+static inline int isk_pad32(int x) { return (x + 31) & ~31; }   // feature rows: the bf16 MFMA contracts 32 at a time
 
 // ---------------------------------------------------------------- featurize -------
 // coords/features rows -> (optionally LayerNorm-standardised) zero-padded feature rows
@@ -54,12 +55,16 @@ struct MlpFwdArgs {
     int stride_a, stride_b; // floats per row of the two per-wave LDS ping-pong buffers (padded width + 4)
 };
 int  isk_launch_mlp_fwd(const MlpFwdArgs& a, hipStream_t st);   // returns 0 or ISK_EUNSUPPORTED
+// split-bf16 variant: W16 = three bf16 planes of the layer-1 weights from isk_launch_fold_bf16
+int  isk_launch_mlp_fwd_bf16x3(const MlpFwdArgs& a, const void* W16, hipStream_t st);
+void isk_launch_fold_bf16(const float* Wt, void* out, int Kp, int nt, hipStream_t st);
 
 // parameter "fold": flat Flux-order theta -> fragment-linear weights and folded bias
 struct FoldArgs {
     const float* theta;
     int nlayers;
     int widths[ISK_MAX_LAYERS + 1];
+    int Kp0;                              // padded input width of layer 0 (= Fp, a multiple of 32)
     long long off_lns, off_lnb;           // offsets in theta, -1 if no LayerNorm
     long long off_W[ISK_MAX_LAYERS], off_b[ISK_MAX_LAYERS];
     float* Wt[ISK_MAX_LAYERS];            // fragment-linear per layer

@@ -9,34 +9,7 @@
 #include <cstdlib>
 #include "isk_internal.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define WAVE 64
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
-
-__device__ __forceinline__ float act_apply(int act, float z) {
-    switch (act) {
-        case ISK_ACT_SIGMOID: {
-            // NNlib sigmoid_fast semantics: overflow-free 1/(1+exp(-z))
-            float e = __expf(-fabsf(z));
-            float r = 1.0f / (1.0f + e);
-            return z >= 0.f ? r : e * r;
-        }
-        case ISK_ACT_TANH: return tanhf(z);
-        case ISK_ACT_RELU: return fmaxf(z, 0.f);
-        case ISK_ACT_SWISH: {
-            float e = __expf(-fabsf(z));
-            float r = 1.0f / (1.0f + e);
-            return z * (z >= 0.f ? r : e * r);
-        }
-        default: return z;
-    }
-}
+#include "fwd_common.hpp"
 
 // =====================================================================================
 // featurize: one wave per sample.  The sample's 3A coordinates are staged in LDS
@@ -265,7 +238,7 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldArgs a) {
     const int layer = blockIdx.y;
     if (layer >= a.nlayers) return;
     const int K = a.widths[layer], N = a.widths[layer + 1];
-    const int Kp = (K + 15) & ~15, Np = (N + 15) & ~15;
+    const int Kp = (layer == 0) ? a.Kp0 : ((K + 15) & ~15), Np = (N + 15) & ~15;
     const int nt = Np / 16, nchunks = Kp / 16;
     const float* W = a.theta + a.off_W[layer];
     const float* b = a.theta + a.off_b[layer];
@@ -332,7 +305,7 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldArgs a) {
 void isk_launch_fold(const FoldArgs& a, hipStream_t st) {
     int bx = 1, maxNp = 16;
     for (int l = 0; l < a.nlayers; ++l) {
-        const int Kp = isk_pad16(a.widths[l]), Np = isk_pad16(a.widths[l + 1]);
+        const int Kp = (l == 0) ? a.Kp0 : isk_pad16(a.widths[l]), Np = isk_pad16(a.widths[l + 1]);
         bx = bx > (Kp / 16 + Np / 4) ? bx : (Kp / 16 + Np / 4);
         maxNp = maxNp > Np ? maxNp : Np;
     }
@@ -418,92 +391,6 @@ __device__ __forceinline__ void layer1_gemm(const MlpFwdArgs& a, const float* x0
     }
 }
 
-// epilogue + tail layers for one 16-row unit whose layer-1 pre-activations sit in acc[NT]
-template <int NT>
-__device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT], long long row_base, float* scrA,
-                                          float* scrB, const float* tailw, int lane) {
-    const int li = lane & 15, lq = lane >> 4;
-    int stride = a.stride_a;
-    const bool fast_sig = (a.act1 == ISK_ACT_SIGMOID) && a.ntail > 0;    // wave-uniform
-    // accumulator layout (row = 4*lq + r, col = 16*t + li) -> LDS rows; bias (and, on the common
-    // sigmoid path, the activation) applied on the way, in registers
-    if (fast_sig) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int col = t * 16 + li;
-            const float bcol = a.bias1[col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float z = acc[t][r] + bcol;
-                const float e = __expf(-fabsf(z));
-                const float q = __builtin_amdgcn_rcpf(1.0f + e);
-                scrA[(lq * 4 + r) * stride + col] = z >= 0.f ? q : e * q;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int col = t * 16 + li;
-            const float bcol = a.bias1[col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) scrA[(lq * 4 + r) * stride + col] = acc[t][r] + bcol;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int H1p = NT * 16;
-    if (a.ntail == 0) {
-        for (int row = lq; row < 16; row += 4) {
-            const long long grow = row_base + row;
-            if (li < a.nout && grow < a.S) a.out[grow * a.nout + li] = act_apply(a.act1, scrA[row * stride + li]);
-        }
-        // nout > 16 with a single layer
-        for (int col = 16 + li; col < a.nout; col += 16)
-            for (int row = lq; row < 16; row += 4) {
-                const long long grow = row_base + row;
-                if (grow < a.S) a.out[grow * a.nout + col] = act_apply(a.act1, scrA[row * stride + col]);
-            }
-        __builtin_amdgcn_wave_barrier();
-        return;
-    }
-    if (!fast_sig) {
-        for (int row = 0; row < 16; ++row)
-            for (int col = lane; col < H1p; col += WAVE) scrA[row * stride + col] = act_apply(a.act1, scrA[row * stride + col]);
-        __builtin_amdgcn_wave_barrier();
-    }
-    float* in = scrA;
-    float* ob = scrB;
-    int ostride = a.stride_b;
-    for (int l = 0; l < a.ntail; ++l) {
-        const TailLayer L = a.tail[l];
-        const bool last = (l == a.ntail - 1);
-        const f32x4* Wp = (const f32x4*)(tailw + L.lds_off) + lane;     // staged once per workgroup
-        for (int t2 = 0; t2 < L.ntiles; ++t2) {
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            for (int c = 0; c < L.kchunks; ++c) {
-                const f32x4 xa = *(const f32x4*)(in + li * stride + c * 16 + lq * 4);
-                const f32x4 wf = Wp[(long long)(c * L.ntiles + t2) * 64];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) z = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], wf[j], z, 0, 0, 0);
-            }
-            const int col = t2 * 16 + li;
-            const float bcol = L.bias[col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = act_apply(L.act, z[r] + bcol);
-                if (last) {
-                    const long long grow = row_base + lq * 4 + r;
-                    if (col < a.nout && grow < a.S) a.out[grow * a.nout + col] = v;
-                } else {
-                    ob[(lq * 4 + r) * ostride + col] = v;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        float* tmp = in; in = ob; ob = tmp;
-        const int ts = stride; stride = ostride; ostride = ts;
-    }
-}
-
 template <int NT>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a, long long units, long long units_per_wave) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -512,12 +399,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a, long long un
     float* scrA = smem + a.tailw_floats + (size_t)wave * 16 * (a.stride_a + a.stride_b);
     float* scrB = scrA + 16 * a.stride_a;
     // stage the (small) fragment-linear tail weights in LDS once: the per-unit tail then never waits on L2
-    for (int l = 0; l < a.ntail; ++l) {
-        const int n4 = a.tail[l].kchunks * a.tail[l].ntiles * 64;
-        const f32x4* src = (const f32x4*)a.tail[l].Wt;
-        f32x4* dst = (f32x4*)(smem + a.tail[l].lds_off);
-        for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
-    }
+    stage_tail_weights(a, smem);
     __syncthreads();
     __builtin_amdgcn_s_setprio(3);                 // MFMA waves win issue arbitration over co-resident streaming kernels
     const long long gw = (long long)blockIdx.x * 4 + wave;

@@ -1,0 +1,245 @@
+// Split-bf16 ("bf16x3") variant of the fused MLP forward for gfx950.
+//
+// gfx950's f32-input MFMA runs at 1/16 of the bf16 MFMA rate.  Layer 1 (99 % of the flops) is therefore
+// computed as an error-compensated bf16 product: every f32 operand is split into three bf16 planes
+//      a = a0 + a1 + a2,   a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)      (24 mantissa bits)
+// and a.b is accumulated in f32 from the six largest cross terms
+//      a0b0 + (a0b1 + a1b0) + (a0b2 + a2b0 + a1b1)          dropped: a1b2, a2b1, a2b2  (<= 2^-24 relative)
+// i.e. 6 x v_mfma_f32_16x16x32_bf16 per 16x16x32 block = 16/6 = 2.67x the f32 MFMA throughput at
+// f32-equivalent accuracy (measured on K = 1712 dot products: rms error 6.0e-7 vs 5.1e-7 for an f32 BLAS).
+//
+// Structure (differs from the f32 kernel because the matrix pipe is now 2.7x faster and the vector
+// memory path would saturate): the three weight planes of a 32-feature chunk (3*NT KiB, fragment-linear,
+// pre-split by fold_bf16_kernel) are staged through LDS once per workgroup and shared by its 4 waves
+// (register-staged T14 pipeline: global load one chunk ahead, ds_write after the compute, one barrier per
+// chunk); the sample rows stay private to a wave: f32 global -> VGPR in fragment shape, three chunks
+// ahead, split into planes in registers right before use.  Tail layers, bias and activation are the f32
+// code shared with the f32 kernel (fwd_common.hpp).
+#include <cstdlib>
+#include "fwd_common.hpp"
+
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Planes {
+    bf16x8 p0, p1, p2;
+};
+
+__device__ __forceinline__ Planes split3(const f32x8 v) {
+    Planes s;
+    s.p0 = __builtin_convertvector(v, bf16x8);
+    const f32x8 r1 = v - __builtin_convertvector(s.p0, f32x8);
+    s.p1 = __builtin_convertvector(r1, bf16x8);
+    const f32x8 r2 = r1 - __builtin_convertvector(s.p1, f32x8);
+    s.p2 = __builtin_convertvector(r2, bf16x8);
+    return s;
+}
+
+// fp32 fragment-linear layer-1 weights [chunk16][nt][64][4]  ->  bf16 planes [chunk32][3][nt][64][8]
+// lane = (kq << 4) | o_local holds W[o][k = 32*c + 8*kq + j], j = 0..7: the B operand of v_mfma_f32_16x16x32_bf16
+__global__ __launch_bounds__(256) void fold_bf16_kernel(const float* __restrict__ Wt, __bf16* __restrict__ out, int nchunk32,
+                                                        int nt, int nchunk16) {
+    const long long total = (long long)nchunk32 * nt * 64 * 8;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int j = e & 7;
+        const int lane = (e >> 3) & 63;
+        const long long ct = e >> 9;
+        const int t = (int)(ct % nt);
+        const int c32 = (int)(ct / nt);
+        const int li = lane & 15, kq = lane >> 4;
+        const int c16 = 2 * c32 + (kq >> 1);
+        const int k16 = 8 * (kq & 1) + j;
+        float w = 0.f;
+        if (c16 < nchunk16) w = Wt[(((long long)c16 * nt + t) * 64 + (((k16 >> 2) << 4) | li)) * 4 + (k16 & 3)];
+        const __bf16 b0 = (__bf16)w;
+        const float r1 = w - (float)b0;
+        const __bf16 b1 = (__bf16)r1;
+        const __bf16 b2 = (__bf16)(r1 - (float)b1);
+        const long long base = (long long)c32 * 3 * nt;
+        out[((base + 0 * nt + t) * 64 + lane) * 8 + j] = b0;
+        out[((base + 1 * nt + t) * 64 + lane) * 8 + j] = b1;
+        out[((base + 2 * nt + t) * 64 + lane) * 8 + j] = b2;
+    }
+}
+
+void isk_launch_fold_bf16(const float* Wt, void* out, int Kp, int nt, hipStream_t st) {
+    const int nchunk32 = (Kp + 31) / 32, nchunk16 = Kp / 16;
+    long long total = (long long)nchunk32 * nt * 64 * 8;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fold_bf16_kernel, dim3(blocks), dim3(256), 0, st, Wt, (__bf16*)out, nchunk32, nt, nchunk16);
+}
+
+template <int NT, bool TWO>
+__device__ __forceinline__ void mma6(const Planes& x0, const Planes& x1, const bf16x8* __restrict__ wl, int lane,
+                                     f32x4 (&acc0)[NT], f32x4 (&acc1)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const bf16x8 w0 = wl[(0 * NT + t) * 64 + lane];
+        const bf16x8 w1 = wl[(1 * NT + t) * 64 + lane];
+        const bf16x8 w2 = wl[(2 * NT + t) * 64 + lane];
+        // smallest terms first
+        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0.p1, w1, acc0[t], 0, 0, 0);
+        if (TWO) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1.p1, w1, acc1[t], 0, 0, 0);
+        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0.p2, w0, acc0[t], 0, 0, 0);
+        if (TWO) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1.p2, w0, acc1[t], 0, 0, 0);
+        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0.p0, w2, acc0[t], 0, 0, 0);
+        if (TWO) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1.p0, w2, acc1[t], 0, 0, 0);
+        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0.p1, w0, acc0[t], 0, 0, 0);
+        if (TWO) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1.p1, w0, acc1[t], 0, 0, 0);
+        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0.p0, w1, acc0[t], 0, 0, 0);
+        if (TWO) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1.p0, w1, acc1[t], 0, 0, 0);
+        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0.p0, w0, acc0[t], 0, 0, 0);
+        if (TWO) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1.p0, w0, acc1[t], 0, 0, 0);
+    }
+}
+
+#define XDEPTH 3       // sample fragments fetched XDEPTH chunks ahead (ring of XDEPTH + 1 slots)
+
+template <int NT, bool TWO>
+__device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __restrict__ W16, uint4* wbuf0, uint4* wbuf1,
+                                            const float* x0, const float* x1, int nch, int lane, f32x4 (&acc0)[NT],
+                                            f32x4 (&acc1)[NT], bool active) {
+    constexpr int STAGE16 = 3 * NT * 64;               // 16-byte units per staged chunk
+    constexpr int PER_T = (STAGE16 + 255) / 256;       // per-thread pieces
+    const int tid = threadIdx.x;
+    uint4 wreg[PER_T];
+    // ---- W pipeline prologue: chunk 0 -> LDS buffer 0, chunk 1 in flight
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+        const int idx = i * 256 + tid;
+        wreg[i] = (idx < STAGE16) ? W16[idx] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+        const int idx = i * 256 + tid;
+        if (idx < STAGE16) wbuf0[idx] = wreg[i];
+    }
+    __syncthreads();
+    if (nch > 1) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int idx = i * 256 + tid;
+            wreg[i] = (idx < STAGE16) ? W16[(long long)STAGE16 + idx] : make_uint4(0, 0, 0, 0);
+        }
+    }
+    // ---- X ring prologue
+    f32x8 xr0[XDEPTH + 1], xr1[XDEPTH + 1];
+    const int last = nch - 1;
+#pragma unroll
+    for (int i = 0; i < XDEPTH; ++i) {
+        const int ci = i < last ? i : last;
+        xr0[i] = *(const f32x8*)(x0 + ci * 32);
+        if (TWO) xr1[i] = *(const f32x8*)(x1 + ci * 32);
+    }
+    for (int c0 = 0; c0 < nch; c0 += XDEPTH + 1) {
+#pragma unroll
+        for (int s = 0; s <= XDEPTH; ++s) {
+            const int c = c0 + s;
+            if (c < nch) {                                            // workgroup-uniform
+                {
+                    const int cp = c + XDEPTH < last ? c + XDEPTH : last;
+                    xr0[(s + XDEPTH) % (XDEPTH + 1)] = *(const f32x8*)(x0 + cp * 32);
+                    if (TWO) xr1[(s + XDEPTH) % (XDEPTH + 1)] = *(const f32x8*)(x1 + cp * 32);
+                }
+                const uint4* cur = (c & 1) ? wbuf1 : wbuf0;
+                uint4* nxt = (c & 1) ? wbuf0 : wbuf1;
+                if (active) {
+                    const Planes p0 = split3(xr0[s]);
+                    Planes p1 = p0;
+                    if (TWO) p1 = split3(xr1[s]);
+                    mma6<NT, TWO>(p0, p1, (const bf16x8*)cur, lane, acc0, acc1);
+                }
+                // chunk c+1 (loaded one iteration ago) -> the other buffer; everyone finished reading it an iteration ago
+                if (c + 1 < nch) {
+#pragma unroll
+                    for (int i = 0; i < PER_T; ++i) {
+                        const int idx = i * 256 + tid;
+                        if (idx < STAGE16) nxt[idx] = wreg[i];
+                    }
+                }
+                __syncthreads();
+                if (c + 2 < nch) {
+#pragma unroll
+                    for (int i = 0; i < PER_T; ++i) {
+                        const int idx = i * 256 + tid;
+                        wreg[i] = (idx < STAGE16) ? W16[(long long)(c + 2) * STAGE16 + idx] : make_uint4(0, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void mlp_fwd_bf16x3_kernel(MlpFwdArgs a, const uint4* __restrict__ W16, long long units,
+                                                             long long units_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int STAGE_FLOATS = 3 * NT * 64 * 4;                  // 3*NT KiB per buffer
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    uint4* wbuf0 = (uint4*)(smem + a.tailw_floats);
+    uint4* wbuf1 = (uint4*)(smem + a.tailw_floats + STAGE_FLOATS);
+    float* scrA = smem + a.tailw_floats + 2 * STAGE_FLOATS + (size_t)wave * 16 * (a.stride_a + a.stride_b);
+    float* scrB = scrA + 16 * a.stride_a;
+    stage_tail_weights(a, smem);
+    __syncthreads();
+    const int nch = a.Fp / 32;
+    const long long gw = (long long)blockIdx.x * 4 + wave;
+    const long long ustart = gw * units_per_wave;
+    long long uend = ustart + units_per_wave;
+    if (uend > units) uend = units;
+    const long long npass = (units_per_wave + 1) / 2;              // identical for every wave: barriers inside
+    for (long long p = 0; p < npass; ++p) {
+        const long long u = ustart + 2 * p;
+        const bool active = u < uend;                              // wave-uniform
+        const bool two = (u + 1 < uend);
+        long long r0 = u * 16 + li, r1 = r0 + 16;
+        if (r0 > a.S - 1) r0 = a.S - 1;
+        if (r1 > a.S - 1) r1 = a.S - 1;
+        if (r0 < 0) r0 = 0;
+        if (a.rows) { r0 = a.rows[r0]; r1 = a.rows[r1]; }
+        const float* x0 = a.X + r0 * (long long)a.Fp + lq * 8;
+        const float* x1 = a.X + r1 * (long long)a.Fp + lq * 8;
+        f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        if (two) layer1_pass<NT, true>(a, W16, wbuf0, wbuf1, x0, x1, nch, lane, acc0, acc1, active);
+        else layer1_pass<NT, false>(a, W16, wbuf0, wbuf1, x0, x1, nch, lane, acc0, acc1, active);
+        if (active) unit_tail<NT>(a, acc0, u * 16, scrA, scrB, smem, lane);
+        if (two) unit_tail<NT>(a, acc1, (u + 1) * 16, scrA, scrB, smem, lane);
+    }
+}
+
+template <int NT>
+static void launch_bf16_nt(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
+    const long long units = (a.S + 15) / 16;
+    const long long waves_max = (long long)ISK_NUM_CU * 4;
+    long long upw = (units + waves_max - 1) / waves_max;
+    if (upw < 1) upw = 1;
+    const long long nwaves = (units + upw - 1) / upw;
+    const long long blocks = (nwaves + 3) / 4;
+    const size_t lds = ((size_t)a.tailw_floats + (size_t)2 * 3 * NT * 256 + (size_t)4 * 16 * (a.stride_a + a.stride_b)) * sizeof(float);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16x3_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(mlp_fwd_bf16x3_kernel<NT>, dim3((unsigned)blocks), dim3(256), lds, st, a, (const uint4*)W16, units, upw);
+}
+
+int isk_launch_mlp_fwd_bf16x3(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
+    if (a.S <= 0) return 0;
+    if (a.Fp % 32 != 0) return ISK_EUNSUPPORTED;
+    switch (a.nt1) {
+        case 1: launch_bf16_nt<1>(a, W16, st); break;
+        case 2: launch_bf16_nt<2>(a, W16, st); break;
+        case 3: launch_bf16_nt<3>(a, W16, st); break;
+        case 4: launch_bf16_nt<4>(a, W16, st); break;
+        case 5: launch_bf16_nt<5>(a, W16, st); break;
+        case 6: launch_bf16_nt<6>(a, W16, st); break;
+        case 7: launch_bf16_nt<7>(a, W16, st); break;
+        case 8: launch_bf16_nt<8>(a, W16, st); break;
+        case 9: launch_bf16_nt<9>(a, W16, st); break;
+        case 10: launch_bf16_nt<10>(a, W16, st); break;
+        default: return ISK_EUNSUPPORTED;
+    }
+    return 0;
+}
