@@ -649,7 +649,8 @@ static int launch_forward(isk_engine* e, const MlpFwdArgs& f) {
             isk_launch_fold_bf16(e->d_Wt[0], e->d_W16, e->Fp, f.nt1, e->stream);
             e->w16_dirty = false;
         }
-        return isk_launch_mlp_fwd_bf16x3(f, e->d_W16, e->stream);
+        if (isk_launch_mlp_fwd_bf16x3(f, e->d_W16, e->stream) == 0) return 0;
+        // shapes whose LDS footprint does not fit the split-bf16 kernel run on the f32 kernel
     }
     return isk_launch_mlp_fwd(f, e->stream);
 }

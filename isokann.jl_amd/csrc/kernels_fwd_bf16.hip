@@ -96,30 +96,30 @@ __device__ __forceinline__ void mma6(const Planes& x0, const Planes& x1, const b
 
 #define XDEPTH 3       // sample fragments fetched XDEPTH chunks ahead (ring of XDEPTH + 1 slots)
 
-template <int NT, bool TWO>
+template <int NT, bool TWO, int NTHR>
 __device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __restrict__ W16, uint4* wbuf0, uint4* wbuf1,
                                             const float* x0, const float* x1, int nch, int lane, f32x4 (&acc0)[NT],
                                             f32x4 (&acc1)[NT], bool active) {
     constexpr int STAGE16 = 3 * NT * 64;               // 16-byte units per staged chunk
-    constexpr int PER_T = (STAGE16 + 255) / 256;       // per-thread pieces
+    constexpr int PER_T = (STAGE16 + NTHR - 1) / NTHR;   // per-thread pieces
     const int tid = threadIdx.x;
     uint4 wreg[PER_T];
     // ---- W pipeline prologue: chunk 0 -> LDS buffer 0, chunk 1 in flight
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
-        const int idx = i * 256 + tid;
+        const int idx = i * NTHR + tid;
         wreg[i] = (idx < STAGE16) ? W16[idx] : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
-        const int idx = i * 256 + tid;
+        const int idx = i * NTHR + tid;
         if (idx < STAGE16) wbuf0[idx] = wreg[i];
     }
     __syncthreads();
     if (nch > 1) {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
-            const int idx = i * 256 + tid;
+            const int idx = i * NTHR + tid;
             wreg[i] = (idx < STAGE16) ? W16[(long long)STAGE16 + idx] : make_uint4(0, 0, 0, 0);
         }
     }
@@ -154,7 +154,7 @@ __device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __
                 if (c + 1 < nch) {
 #pragma unroll
                     for (int i = 0; i < PER_T; ++i) {
-                        const int idx = i * 256 + tid;
+                        const int idx = i * NTHR + tid;
                         if (idx < STAGE16) nxt[idx] = wreg[i];
                     }
                 }
@@ -162,7 +162,7 @@ __device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __
                 if (c + 2 < nch) {
 #pragma unroll
                     for (int i = 0; i < PER_T; ++i) {
-                        const int idx = i * 256 + tid;
+                        const int idx = i * NTHR + tid;
                         wreg[i] = (idx < STAGE16) ? W16[(long long)(c + 2) * STAGE16 + idx] : make_uint4(0, 0, 0, 0);
                     }
                 }
@@ -171,8 +171,8 @@ __device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void mlp_fwd_bf16x3_kernel(MlpFwdArgs a, const uint4* __restrict__ W16, long long units,
+template <int NT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3_kernel(MlpFwdArgs a, const uint4* __restrict__ W16, long long units,
                                                              long long units_per_wave) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int STAGE_FLOATS = 3 * NT * 64 * 4;                  // 3*NT KiB per buffer
@@ -180,12 +180,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_bf16x3_kernel(MlpFwdArgs a, const
     const int li = lane & 15, lq = lane >> 4;
     uint4* wbuf0 = (uint4*)(smem + a.tailw_floats);
     uint4* wbuf1 = (uint4*)(smem + a.tailw_floats + STAGE_FLOATS);
-    float* scrA = smem + a.tailw_floats + 2 * STAGE_FLOATS + (size_t)wave * 16 * (a.stride_a + a.stride_b);
+    float* scrA = smem + a.tailw_floats + 2 * STAGE_FLOATS + (size_t)wave * 16 * (a.stride_a + a.stride_b);   // NWV scratch slots follow
     float* scrB = scrA + 16 * a.stride_a;
     stage_tail_weights(a, smem);
     __syncthreads();
     const int nch = a.Fp / 32;
-    const long long gw = (long long)blockIdx.x * 4 + wave;
+    const long long gw = (long long)blockIdx.x * NWV + wave;
     const long long ustart = gw * units_per_wave;
     long long uend = ustart + units_per_wave;
     if (uend > units) uend = units;
@@ -204,41 +204,57 @@ __global__ __launch_bounds__(256) void mlp_fwd_bf16x3_kernel(MlpFwdArgs a, const
         f32x4 acc0[NT], acc1[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) { acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        if (two) layer1_pass<NT, true>(a, W16, wbuf0, wbuf1, x0, x1, nch, lane, acc0, acc1, active);
-        else layer1_pass<NT, false>(a, W16, wbuf0, wbuf1, x0, x1, nch, lane, acc0, acc1, active);
+        if (two) layer1_pass<NT, true, NWV * 64>(a, W16, wbuf0, wbuf1, x0, x1, nch, lane, acc0, acc1, active);
+        else layer1_pass<NT, false, NWV * 64>(a, W16, wbuf0, wbuf1, x0, x1, nch, lane, acc0, acc1, active);
         if (active) unit_tail<NT>(a, acc0, u * 16, scrA, scrB, smem, lane);
         if (two) unit_tail<NT>(a, acc1, (u + 1) * 16, scrA, scrB, smem, lane);
     }
 }
 
-template <int NT>
-static void launch_bf16_nt(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
+template <int NT, int NWV>
+static size_t bf16_lds_bytes(const MlpFwdArgs& a) {
+    return ((size_t)a.tailw_floats + (size_t)2 * 3 * NT * 256 + (size_t)NWV * 16 * (a.stride_a + a.stride_b)) * sizeof(float);
+}
+
+template <int NT, int NWV>
+static void launch_bf16_nw(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
     const long long units = (a.S + 15) / 16;
-    const long long waves_max = (long long)ISK_NUM_CU * 4;
+    const long long waves_max = (long long)ISK_NUM_CU * NWV;
     long long upw = (units + waves_max - 1) / waves_max;
     if (upw < 1) upw = 1;
     const long long nwaves = (units + upw - 1) / upw;
-    const long long blocks = (nwaves + 3) / 4;
-    const size_t lds = ((size_t)a.tailw_floats + (size_t)2 * 3 * NT * 256 + (size_t)4 * 16 * (a.stride_a + a.stride_b)) * sizeof(float);
+    const long long blocks = (nwaves + NWV - 1) / NWV;
+    const size_t lds = bf16_lds_bytes<NT, NWV>(a);
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16x3_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(mlp_fwd_bf16x3_kernel<NT>, dim3((unsigned)blocks), dim3(256), lds, st, a, (const uint4*)W16, units, upw);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16x3_kernel<NT, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mlp_fwd_bf16x3_kernel<NT, NWV>), dim3((unsigned)blocks), dim3(NWV * 64), lds, st, a, (const uint4*)W16, units, upw);
+}
+
+template <int NT>
+static int launch_bf16_nt(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
+    // two waves per SIMD by default: one converts / stages while the other feeds the matrix pipe;
+    // fall back to one wave per SIMD when the per-wave LDS scratch would not fit
+    static const int nwv = [] { const char* v = getenv("ISK_BF16_WAVES"); return v ? atoi(v) : 8; }();
+    const size_t cap = 158 * 1024;
+    if (nwv != 4 && bf16_lds_bytes<NT, 8>(a) <= cap) { launch_bf16_nw<NT, 8>(a, W16, st); return 0; }
+    if (bf16_lds_bytes<NT, 4>(a) <= cap) { launch_bf16_nw<NT, 4>(a, W16, st); return 0; }
+    return ISK_EUNSUPPORTED;
 }
 
 int isk_launch_mlp_fwd_bf16x3(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
     if (a.S <= 0) return 0;
     if (a.Fp % 32 != 0) return ISK_EUNSUPPORTED;
     switch (a.nt1) {
-        case 1: launch_bf16_nt<1>(a, W16, st); break;
-        case 2: launch_bf16_nt<2>(a, W16, st); break;
-        case 3: launch_bf16_nt<3>(a, W16, st); break;
-        case 4: launch_bf16_nt<4>(a, W16, st); break;
-        case 5: launch_bf16_nt<5>(a, W16, st); break;
-        case 6: launch_bf16_nt<6>(a, W16, st); break;
-        case 7: launch_bf16_nt<7>(a, W16, st); break;
-        case 8: launch_bf16_nt<8>(a, W16, st); break;
-        case 9: launch_bf16_nt<9>(a, W16, st); break;
-        case 10: launch_bf16_nt<10>(a, W16, st); break;
+        case 1: return launch_bf16_nt<1>(a, W16, st);
+        case 2: return launch_bf16_nt<2>(a, W16, st);
+        case 3: return launch_bf16_nt<3>(a, W16, st);
+        case 4: return launch_bf16_nt<4>(a, W16, st);
+        case 5: return launch_bf16_nt<5>(a, W16, st);
+        case 6: return launch_bf16_nt<6>(a, W16, st);
+        case 7: return launch_bf16_nt<7>(a, W16, st);
+        case 8: return launch_bf16_nt<8>(a, W16, st);
+        case 9: return launch_bf16_nt<9>(a, W16, st);
+        case 10: return launch_bf16_nt<10>(a, W16, st);
         default: return ISK_EUNSUPPORTED;
     }
     return 0;
