@@ -24,7 +24,7 @@ LN_MODE = {"var_eps2": 0, "std_eps": 1, "var_eps": 2}
 T_FEATURIZE, T_FWD_YS, T_FWD_XS, T_TARGET, T_TRAIN, T_COUNT = 0, 1, 2, 3, 4, 5
 TIMER_NAMES = ("featurize", "fwd_ys", "fwd_xs", "target", "train")
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libisokann_hip.so")
+LIB_PATH = os.environ.get("ISK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libisokann_hip.so")
 
 
 class IskError(RuntimeError):

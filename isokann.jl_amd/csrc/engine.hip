@@ -356,7 +356,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     ALLOC(e->d_loss_acc, 2 * sizeof(double)); ALLOC(e->d_status, sizeof(int)); ALLOC(e->d_mm, 2 * sizeof(float));
     ALLOC(e->d_lossw, (size_t)nout * sizeof(float));
     ALLOC(e->d_At, (size_t)nout * nout * sizeof(float)); ALLOC(e->d_rowperm, (size_t)nout * sizeof(int));
-    ALLOC(e->d_W16, (size_t)e->Fp * isk_pad16(cfg->widths[1]) * 3 * sizeof(uint16_t));
+    ALLOC(e->d_W16, (size_t)(e->Fp + 32) * isk_pad16(cfg->widths[1]) * 3 * sizeof(uint16_t));
     for (int l = 0; l < e->L; ++l) {
         ALLOC(e->d_Wt[l], (size_t)(l == 0 ? e->Fp : isk_pad16(cfg->widths[l])) * isk_pad16(cfg->widths[l + 1]) * sizeof(float));
         ALLOC(e->d_bias[l], (size_t)isk_pad16(cfg->widths[l + 1]) * sizeof(float));

@@ -10,7 +10,8 @@
 //
 // Structure (differs from the f32 kernel because the matrix pipe is now 2.7x faster and the vector
 // memory path would saturate): the three weight planes of a 32-feature chunk (3*NT KiB, fragment-linear,
-// pre-split by fold_bf16_kernel) are staged through LDS once per workgroup and shared by its 4 waves
+// pre-split by fold_bf16_kernel) are staged through LDS once per workgroup and shared by its 8 waves
+// (two per SIMD: while one converts / waits, the other feeds the matrix pipe)
 // (register-staged T14 pipeline: global load one chunk ahead, ds_write after the compute, one barrier per
 // chunk); the sample rows stay private to a wave: f32 global -> VGPR in fragment shape, three chunks
 // ahead, split into planes in registers right before use.  Tail layers, bias and activation are the f32
@@ -25,8 +26,20 @@ struct Planes {
     bf16x8 p0, p1, p2;
 };
 
+#ifndef ISK_ABLATE
+#define ISK_ABLATE 0
+#endif
 __device__ __forceinline__ Planes split3(const f32x8 v) {
     Planes s;
+#if ISK_ABLATE == 1
+    {   // ablation: no conversion arithmetic
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 b = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+        s.p0 = __builtin_bit_cast(bf16x8, b); s.p1 = s.p0; s.p2 = s.p0;
+        asm volatile("" :: "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+        return s;
+    }
+#endif
     s.p0 = __builtin_convertvector(v, bf16x8);
     const f32x8 r1 = v - __builtin_convertvector(s.p0, f32x8);
     s.p1 = __builtin_convertvector(r1, bf16x8);
@@ -94,22 +107,30 @@ __device__ __forceinline__ void mma6(const Planes& x0, const Planes& x1, const b
     }
 }
 
-#define XDEPTH 3       // sample fragments fetched XDEPTH chunks ahead (ring of XDEPTH + 1 slots)
+// One pass = the whole feature axis for this wave's (up to) two 16-row units.  The weight planes of one
+// 32-feature chunk (3*NT KiB) are staged per barrier, two LDS buffers.  Register-staged pipeline: the
+// global loads of chunk c+2 are issued right after the barrier that ends chunk c and are written to
+// LDS after the compute of chunk c+1.  The sample fragments come from HBM and are fetched XDEPTH chunks
+// ahead (ablation: with a 2-chunk lead the kernel loses 29 % to exposed HBM latency).
+#ifndef XDEPTH
+#define XDEPTH 3
+#endif
 
 template <int NT, bool TWO, int NTHR>
 __device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __restrict__ W16, uint4* wbuf0, uint4* wbuf1,
                                             const float* x0, const float* x1, int nch, int lane, f32x4 (&acc0)[NT],
                                             f32x4 (&acc1)[NT], bool active) {
-    constexpr int STAGE16 = 3 * NT * 64;               // 16-byte units per staged chunk
-    constexpr int PER_T = (STAGE16 + NTHR - 1) / NTHR;   // per-thread pieces
+    constexpr int STAGE16 = 3 * NT * 64;                 // 16-byte units per chunk
+    constexpr int PER_T = (STAGE16 + NTHR - 1) / NTHR;
     const int tid = threadIdx.x;
+    const int last = nch - 1;
     uint4 wreg[PER_T];
-    // ---- W pipeline prologue: chunk 0 -> LDS buffer 0, chunk 1 in flight
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
         const int idx = i * NTHR + tid;
         wreg[i] = (idx < STAGE16) ? W16[idx] : make_uint4(0, 0, 0, 0);
     }
+    __syncthreads();                                     // the previous pass's epilogue scratch aliases the buffers
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
         const int idx = i * NTHR + tid;
@@ -123,9 +144,7 @@ __device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __
             wreg[i] = (idx < STAGE16) ? W16[(long long)STAGE16 + idx] : make_uint4(0, 0, 0, 0);
         }
     }
-    // ---- X ring prologue
     f32x8 xr0[XDEPTH + 1], xr1[XDEPTH + 1];
-    const int last = nch - 1;
 #pragma unroll
     for (int i = 0; i < XDEPTH; ++i) {
         const int ci = i < last ? i : last;
@@ -150,7 +169,6 @@ __device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __
                     if (TWO) p1 = split3(xr1[s]);
                     mma6<NT, TWO>(p0, p1, (const bf16x8*)cur, lane, acc0, acc1);
                 }
-                // chunk c+1 (loaded one iteration ago) -> the other buffer; everyone finished reading it an iteration ago
                 if (c + 1 < nch) {
 #pragma unroll
                     for (int i = 0; i < PER_T; ++i) {
@@ -173,14 +191,16 @@ __device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __
 
 template <int NT, int NWV>
 __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3_kernel(MlpFwdArgs a, const uint4* __restrict__ W16, long long units,
-                                                             long long units_per_wave) {
+                                                                  long long units_per_wave) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int STAGE_FLOATS = 3 * NT * 64 * 4;                  // 3*NT KiB per buffer
+    constexpr int STAGE_FLOATS = 3 * NT * 64 * 4;                   // one chunk per buffer
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
     uint4* wbuf0 = (uint4*)(smem + a.tailw_floats);
     uint4* wbuf1 = (uint4*)(smem + a.tailw_floats + STAGE_FLOATS);
-    float* scrA = smem + a.tailw_floats + 2 * STAGE_FLOATS + (size_t)wave * 16 * (a.stride_a + a.stride_b);   // NWV scratch slots follow
+    // the per-wave epilogue scratch ALIASES the weight buffers: it is only used between the last barrier
+    // of a pass and the first barrier of the next one
+    float* scrA = smem + a.tailw_floats + (size_t)wave * 16 * (a.stride_a + a.stride_b);
     float* scrB = scrA + 16 * a.stride_a;
     stage_tail_weights(a, smem);
     __syncthreads();
@@ -213,7 +233,8 @@ __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3_kernel(MlpFwdArgs a, 
 
 template <int NT, int NWV>
 static size_t bf16_lds_bytes(const MlpFwdArgs& a) {
-    return ((size_t)a.tailw_floats + (size_t)2 * 3 * NT * 256 + (size_t)NWV * 16 * (a.stride_a + a.stride_b)) * sizeof(float);
+    const size_t wb = (size_t)2 * 3 * NT * 256, scr = (size_t)NWV * 16 * (a.stride_a + a.stride_b);
+    return ((size_t)a.tailw_floats + (wb > scr ? wb : scr)) * sizeof(float);
 }
 
 template <int NT, int NWV>
