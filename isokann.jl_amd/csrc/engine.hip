@@ -505,6 +505,17 @@ static void featurize_resident(isk_engine* e) {
     featurize_rows(e, e->d_in_xs, e->N, e->d_xhat + (long long)e->N * e->K * e->Fp);
 }
 
+// Where the next iteration's ys featurization runs (ISK_OVERLAP_FEATURIZE):
+//   2 (default)  on the side stream BESIDE THE TRAINING KERNELS of this iteration, throttled to two
+//                workgroups per CU: the training steps are latency-bound chains of small launches that
+//                leave most CUs idle, the featurizer is HBM-bound.  Measured on C3: 1.87 -> 1.74 ms/step.
+//   1            beside the MFMA-bound forward: measured net LOSS (forward 0.57 -> 0.75 ms), kept for tuning
+//   0            inline on the main stream
+static int overlap_mode() {
+    static const int mode = [] { const char* v = getenv("ISK_OVERLAP_FEATURIZE"); return v ? atoi(v) : 2; }();
+    return mode;
+}
+
 // Called right after this iteration's forward has been enqueued on the main stream: featurize ys for
 // the NEXT iteration on the side stream into the other buffer.  The featurizer is HBM-bound, the
 // forward f32-MFMA-bound, so the two share the chip.  `ev_main_point` (recorded before the forward)
@@ -514,8 +525,21 @@ static void featurize_ys_ahead(isk_engine* e) {
     // slows the forward from 0.83 to 1.5 ms (the featurizer's streaming evicts the L2-resident
     // weights and saturates the memory queues), a net loss against running them back to back.
     // Kept behind ISK_OVERLAP_FEATURIZE=1 for further tuning.
-    static const int mode = [] { const char* v = getenv("ISK_OVERLAP_FEATURIZE"); return v ? atoi(v) : 0; }();
-    if (mode != 1 || !e->d_xhat_alt) return;
+    if (overlap_mode() != 1 || !e->d_xhat_alt) return;
+    (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
+    {
+        ScopedTimer t(e, ISK_T_FEATURIZE, e->side);
+        featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat_alt, e->side);
+    }
+    (void)hipEventRecord(e->ev_ys_ready, e->side);
+    e->ys_ahead = true;
+}
+
+// mode 2: called once the target of this iteration is enqueued (every earlier reader of the other
+// buffer precedes this point on the main stream)
+static void featurize_ys_beside_training(isk_engine* e) {
+    if (overlap_mode() != 2 || !e->cfg.featurize_every_iteration || !e->d_xhat_alt || e->ys_ahead) return;
+    (void)hipEventRecord(e->ev_fwd_done, e->stream);
     (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
     {
         ScopedTimer t(e, ISK_T_FEATURIZE, e->side);
@@ -968,7 +992,8 @@ static void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, 
     const TrainBuffers b = train_buffers(e);
     isk_launch_train_fwd1(s, b, d_idx, B, e->stream);
     isk_launch_train_tail(s, b, d_idx, B, inv_div, e->stream);
-    isk_launch_train_grad1(s, b, d_idx, B, nslab, e->stream);
+    // while the throttled featurizer shares the CUs, use the 8-wave variant (80 KB LDS instead of 158 KB) so both fit
+    isk_launch_train_grad1(s, b, d_idx, B, nslab | (e->ys_ahead ? 0x100 : 0), e->stream);
     e->last_nslab = nslab;
 }
 
@@ -1062,16 +1087,7 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
         if (e->cfg.featurize_every_iteration) featurize_resident(e);
         // the constant-chi check needs the device status word; it is read together with the loss
         CHK(compute_target(e, false, e->cfg.featurize_every_iteration != 0));
-        {   // experimental: ISK_OVERLAP_FEATURIZE=2 runs the next ys featurization beside the training kernels
-            static const int mode = [] { const char* v = getenv("ISK_OVERLAP_FEATURIZE"); return v ? atoi(v) : 0; }();
-            if (mode == 2 && e->cfg.featurize_every_iteration && e->d_xhat_alt) {
-                (void)hipEventRecord(e->ev_fwd_done, e->stream);
-                (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
-                { ScopedTimer t(e, ISK_T_FEATURIZE, e->side); featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat_alt, e->side); }
-                (void)hipEventRecord(e->ev_ys_ready, e->side);
-                e->ys_ahead = true;
-            }
-        }
+        featurize_ys_beside_training(e);
         for (int ep = 0; ep < epochs; ++ep) {
             double l = 0;
             const int32_t* p = perms ? perms + k * e->N : nullptr;
@@ -1233,6 +1249,7 @@ extern "C" int isk_dp_epoch_begin(isk_engine* e, const int32_t* perm, int32_t n)
     HIPCHK(hipMemsetAsync(e->d_loss_acc, 0, 2 * sizeof(double), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));                 // perm is caller-owned
     e->dp_perm_len = n;
+    featurize_ys_beside_training(e);
     return ISK_OK;
 }
 

@@ -177,8 +177,8 @@ static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream
     const bool pd = a.pairs != nullptr;
     const size_t lds = pd ? (size_t)4 * (a.D / 3) * 16 : 0;
     // waves per CU bounded by the wave-private LDS image (160 KiB) and by 16 (4 per SIMD)
-    static const int cap_env = [] { const char* v = getenv("ISK_FEAT_WG_PER_CU"); return v ? atoi(v) : 0; }();
-    int wg_per_cu = (a.background && cap_env > 0) ? cap_env : 4;
+    static const int cap_env = [] { const char* v = getenv("ISK_FEAT_WG_PER_CU"); return v ? atoi(v) : 2; }();
+    int wg_per_cu = (a.background && cap_env > 0) ? cap_env : 4;      // background launches leave half of each CU free
     if (lds > 0) {
         const int fit = (int)((150 * 1024) / lds);
         if (fit < wg_per_cu) wg_per_cu = fit < 1 ? 1 : fit;

@@ -484,9 +484,11 @@ static void launch_grad1(const TrainShape& s, const TrainBuffers& b, const int* 
     hipLaunchKernelGGL((train_grad1_kernel<NT, NW>), dim3(b.Fp / 16, nslab), dim3(NW * 64), lds, st, s, b, perm, B, nparts);
 }
 
-void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st) {
+void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab_flags, hipStream_t st) {
     const int nt1 = isk_pad16(s.widths[1]) / 16;
-    static const int nw8 = [] { const char* v = getenv("ISK_GRAD1_NW8"); return v ? atoi(v) : 0; }();
+    const int nslab = nslab_flags & 0xff;
+    static const int nw8_env = [] { const char* v = getenv("ISK_GRAD1_NW8"); return v ? atoi(v) : -1; }();
+    const int nw8 = nw8_env >= 0 ? nw8_env : ((nslab_flags & 0x100) != 0);
 #define G1CASE(NT_) case NT_: if (nw8) launch_grad1<NT_, 8>(s, b, perm, B, nslab, st); else launch_grad1<NT_, 16>(s, b, perm, B, nslab, st); break;
     switch (nt1) {
         G1CASE(1) G1CASE(2) G1CASE(3) G1CASE(4) G1CASE(5) G1CASE(6) G1CASE(7) G1CASE(8) G1CASE(9)
