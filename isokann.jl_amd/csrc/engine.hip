@@ -506,9 +506,9 @@ static void featurize_resident(isk_engine* e) {
 }
 
 // Where the next iteration's ys featurization runs (ISK_OVERLAP_FEATURIZE):
-//   2 (default)  on the side stream BESIDE THE TRAINING KERNELS of this iteration, throttled to two
-//                workgroups per CU: the training steps are latency-bound chains of small launches that
-//                leave most CUs idle, the featurizer is HBM-bound.  Measured on C3: 1.87 -> 1.74 ms/step.
+//   2 (default)  on the side stream BESIDE THE TRAINING KERNELS of this iteration, throttled to one
+//                (software-pipelined) workgroup per CU: the training steps are latency-bound chains of small launches that
+//                leave most CUs idle, the featurizer is HBM-bound.  Measured on C3: 1.90 -> 1.74 ms/step.
 //   1            beside the MFMA-bound forward: measured net LOSS (forward 0.57 -> 0.75 ms), kept for tuning
 //   0            inline on the main stream
 static int overlap_mode() {

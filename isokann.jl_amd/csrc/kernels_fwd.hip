@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeatArgs a) {
 // ds_read_b128; mean / variance by wavefront shuffles; the standardised row goes out as
 // coalesced 256-B store instructions.
 // -------------------------------------------------------------------------------------
-template <int NFL, bool PDIST>
+template <int NFL, int NDL, bool PDIST>
 __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const unsigned* __restrict__ packed_pairs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -108,27 +108,43 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
     }
     const float invF = 1.0f / (float)a.F;
     const long long nw = (long long)gridDim.x * 4;
-    for (long long s = (long long)blockIdx.x * 4 + wave; s < a.S; s += nw) {
+    long long s = (long long)blockIdx.x * 4 + wave;
+    // software pipeline: the NEXT sample's row (NDL or NFL dwords per lane) is in flight in registers while
+    // the current one is featurized, so a wave keeps HBM busy on its own (needed when the kernel runs
+    // throttled beside the training kernels)
+    float nxt[PDIST ? NDL : NFL];
+    if (s < a.S) {
         const float* row = a.in + s * (long long)a.D;
+#pragma unroll
+        for (int u = 0; u < (PDIST ? NDL : NFL); ++u) {
+            const int i = 64 * u + lane;
+            nxt[u] = (i < a.D) ? row[i] : 0.f;
+        }
+    }
+    for (; s < a.S; s += nw) {
         float d[NFL];
         if (PDIST) {
-            // coalesced row read, 8 loads in flight, scattered into the padded LDS image
-            for (int base = 0; base < a.D; base += 512) {
-                float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = base + 64 * u + lane;
-                    v[u] = (i < a.D) ? row[i] : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = base + 64 * u + lane;
-                    if (i < a.D) {
-                        const int at = i / 3;
-                        ((float*)cw)[4 * at + (i - 3 * at)] = v[u];
-                    }
+            for (int u = 0; u < NDL; ++u) {
+                const int i = 64 * u + lane;
+                if (i < a.D) {
+                    const int at = i / 3;
+                    ((float*)cw)[4 * at + (i - 3 * at)] = nxt[u];
                 }
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NFL; ++i) d[i] = nxt[i];
+        }
+        if (s + nw < a.S) {                                  // wave-uniform: prefetch the next sample
+            const float* row = a.in + (s + nw) * (long long)a.D;
+#pragma unroll
+            for (int u = 0; u < (PDIST ? NDL : NFL); ++u) {
+                const int i = 64 * u + lane;
+                nxt[u] = (i < a.D) ? row[i] : 0.f;
+            }
+        }
+        if (PDIST) {
             __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes have landed
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -139,12 +155,6 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
                 d[i] = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
             }
             __builtin_amdgcn_wave_barrier();             // all reads issued before the next trip's writes
-        } else {
-#pragma unroll
-            for (int i = 0; i < NFL; ++i) {
-                const int f = lane + 64 * i;
-                d[i] = (f < a.F) ? row[f] : 0.f;
-            }
         }
         float mu = 0.f, rstd = 1.f;
         if (a.normalize) {
@@ -172,13 +182,15 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
     }
 }
 
-template <int NFL>
+template <int NFL, int NDL>
 static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream_t st) {
     const bool pd = a.pairs != nullptr;
     const size_t lds = pd ? (size_t)4 * (a.D / 3) * 16 : 0;
     // waves per CU bounded by the wave-private LDS image (160 KiB) and by 16 (4 per SIMD)
-    static const int cap_env = [] { const char* v = getenv("ISK_FEAT_WG_PER_CU"); return v ? atoi(v) : 2; }();
-    int wg_per_cu = (a.background && cap_env > 0) ? cap_env : 4;      // background launches leave half of each CU free
+    static const int cap_env = [] { const char* v = getenv("ISK_FEAT_WG_PER_CU"); return v ? atoi(v) : 1; }();
+    // background launches (beside the training kernels) run ONE self-pipelined workgroup per CU: measured
+    // 1.74 ms/step against 1.87 with two
+    int wg_per_cu = (a.background && cap_env > 0) ? cap_env : 4;
     if (lds > 0) {
         const int fit = (int)((150 * 1024) / lds);
         if (fit < wg_per_cu) wg_per_cu = fit < 1 ? 1 : fit;
@@ -188,29 +200,36 @@ static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream
     if (blocks > cap) blocks = cap;
     if (pd) {
         if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)featurize_reg_kernel<NFL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((featurize_reg_kernel<NFL, true>), dim3((unsigned)blocks), dim3(256), lds, st, a, packed);
+            (void)hipFuncSetAttribute((const void*)featurize_reg_kernel<NFL, NDL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((featurize_reg_kernel<NFL, NDL, true>), dim3((unsigned)blocks), dim3(256), lds, st, a, packed);
     } else {
-        hipLaunchKernelGGL((featurize_reg_kernel<NFL, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, packed);
+        hipLaunchKernelGGL((featurize_reg_kernel<NFL, 1, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, packed);
     }
+}
+
+template <int NFL>
+static void launch_feat_nd(const FeatArgs& a, const unsigned* packed, hipStream_t st) {
+    const int nd = (a.D + 63) / 64;
+    if (a.pairs == nullptr || nd <= 8) launch_feat_reg<NFL, 8>(a, packed, st);
+    else if (nd <= 16) launch_feat_reg<NFL, 16>(a, packed, st);
+    else if (nd <= 28) launch_feat_reg<NFL, 28>(a, packed, st);
+    else launch_feat_reg<NFL, 32>(a, packed, st);
 }
 
 void isk_launch_featurize(const FeatArgs& a, hipStream_t st) {
     if (a.S <= 0) return;
     const bool pd = a.pairs != nullptr;
     const int need = (a.Fp + 63) / 64;
-    const bool reg_ok = need <= 32 && (!pd || (a.packed_pairs != nullptr && (size_t)4 * (a.D / 3) * 16 <= 150 * 1024));
+    const bool reg_ok = need <= 32 && (!pd || (a.packed_pairs != nullptr && a.D <= 2048 && (size_t)4 * (a.D / 3) * 16 <= 150 * 1024));
     if (reg_ok) {
-        if (need <= 1) launch_feat_reg<1>(a, a.packed_pairs, st);
-        else if (need <= 2) launch_feat_reg<2>(a, a.packed_pairs, st);
-        else if (need <= 4) launch_feat_reg<4>(a, a.packed_pairs, st);
-        else if (need <= 8) launch_feat_reg<8>(a, a.packed_pairs, st);
-        else if (need <= 12) launch_feat_reg<12>(a, a.packed_pairs, st);
-        else if (need <= 16) launch_feat_reg<16>(a, a.packed_pairs, st);
-        else if (need <= 20) launch_feat_reg<20>(a, a.packed_pairs, st);
-        else if (need <= 24) launch_feat_reg<24>(a, a.packed_pairs, st);
-        else if (need <= 28) launch_feat_reg<28>(a, a.packed_pairs, st);
-        else launch_feat_reg<32>(a, a.packed_pairs, st);
+        if (need <= 1) launch_feat_nd<1>(a, a.packed_pairs, st);
+        else if (need <= 2) launch_feat_nd<2>(a, a.packed_pairs, st);
+        else if (need <= 4) launch_feat_nd<4>(a, a.packed_pairs, st);
+        else if (need <= 8) launch_feat_nd<8>(a, a.packed_pairs, st);
+        else if (need <= 16) launch_feat_nd<16>(a, a.packed_pairs, st);
+        else if (need <= 24) launch_feat_nd<24>(a, a.packed_pairs, st);
+        else if (need <= 28) launch_feat_nd<28>(a, a.packed_pairs, st);
+        else launch_feat_nd<32>(a, a.packed_pairs, st);
         return;
     }
     // generic fallback (any F, any atom count): LDS stash variant
