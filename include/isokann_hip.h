@@ -143,6 +143,14 @@ int  isk_chis(isk_engine* e, float* out);
 /* koopman(iso) = expectation(model, propfeatures)   src/isotarget.jl:18,20 : (nout, N) */
 int  isk_koopman(isk_engine* e, float* out);
 
+/* ---- evaluation callers on the same kernels ----------- */
+/* expectation(model, featurizer(ys)) for caller-provided coordinates ys (D, K, ncols) -> (nout, ncols)
+ * src/isotarget.jl:18 on data that is not the resident set (validation data, resampling) */
+int  isk_koopman_coords(isk_engine* e, const float* ys, int64_t D, int64_t K, int64_t ncols, float* out);
+/* validationloss(iso, valdata)   src/iso.jl:160-168 : mean |chi(vx) - shiftscale([K chi(vy); K chi(ys)])|^2,
+ * 1-D chi only; vxs (D, Nv), vys (D, K, Nv) are validation COORDINATES */
+int  isk_validationloss(isk_engine* e, const float* vxs, const float* vys, int64_t D, int64_t K, int64_t Nv, double* loss);
+
 /* ---- target: isotarget(iso)   src/isotarget.jl:10-42, 74-127 ------------------- */
 /* Computes the target on the resident data, keeps it on the device for training and,
  * if out != NULL, copies it to out (nout, N). */

@@ -14,5 +14,6 @@ from .api import (  # noqa: F401
     AdamRegularized, DomainError, FeaturesAll, FeaturesAtoms, FeaturesPairs, HipModel, IskError, Iso, ModelSpec,
     NesterovRegularized, OptSpec, SimulationData, TransformISA, TransformShiftscale, batch_grads, chicoords, chis,
     coords, densenet, featuredim, features, halfinds, identity, inputdim, isotarget, koopman, outputdim, pairnet,
-    pairnet_widths, propcoords, propfeatures, run, train_batch,
+    pairnet_widths, propcoords, propfeatures, run, train_batch, koopman_coords, chi_kchi, validationloss,
+    ValidationLossLogger, koopman_variance,
 )

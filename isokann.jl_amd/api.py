@@ -481,3 +481,52 @@ def features(iso: Iso, coords_=None) -> np.ndarray:
 def propfeatures(iso: Iso) -> np.ndarray:
     """propfeatures(data) (src/simulation.jl:143)"""
     return features(iso, iso.data.coords[1])
+
+
+# --------------------------------------------------- evaluation callers (SURVEY 8f rank 1) --
+def koopman_coords(iso: Iso, ys) -> np.ndarray:
+    """expectation(model, featurizer(ys)) (src/isotarget.jl:18) for coordinates ys (D, K, n) -> (nout, n)"""
+    y = capi.f32(ys)
+    d, k, n = y.shape
+    out = np.empty((iso.nout, n), np.float32, order="F")
+    capi.check(iso._lib.isk_koopman_coords(iso._h, capi.ptr_f32(y), d, k, n, capi.ptr_f32(out)))
+    return out
+
+
+def chi_kchi(iso: Iso):
+    """chi_kchi(iso) (src/isotarget.jl:22-23)"""
+    return chis(iso), koopman(iso)
+
+
+def validationloss(iso: Iso, valdata: SimulationData) -> float:
+    """validationloss(iso, valdata) (src/iso.jl:160-168)"""
+    vx, vy = valdata.coords
+    d, k, n = vy.shape
+    loss = C.c_double(0)
+    capi.check(iso._lib.isk_validationloss(iso._h, capi.ptr_f32(vx), capi.ptr_f32(vy), d, k, n, C.byref(loss)))
+    return float(loss.value)
+
+
+class ValidationLossLogger:
+    """ValidationLossLogger(data; logevery=10) (src/iso.jl:132-177): a logger for Iso(...; loggers=[...])"""
+
+    def __init__(self, data: SimulationData, logevery: int = 10):
+        self.data, self.logevery = data, logevery
+        self.losses: List[float] = []
+        self.iters: List[int] = []
+
+    def __call__(self, iso: Iso, **kw):                                   # log!(v; iso)
+        if len(iso.losses) % self.logevery != 0:
+            return
+        self.losses.append(validationloss(iso, self.data))
+        self.iters.append(len(iso.losses))
+
+    def diagnostic(self):
+        return ("validation loss", self.losses[-1] if self.losses else None)
+
+
+def koopman_variance(iso: Iso, ys=None) -> float:
+    """koopman_variance(iso, ys) (src/iso.jl:355-359)"""
+    chi = chicoords(iso, iso.data.coords[1] if ys is None else ys)
+    i, k, n = chi.shape
+    return float(np.sum((chi - chi.sum(axis=1, keepdims=True) / k) ** 2) / i / n)

@@ -964,6 +964,67 @@ static int compute_target(isk_engine* e, bool check, bool ahead = false) {
     return ISK_OK;
 }
 
+// featurize + forward + K-mean on caller-provided coordinates; result stays in `ks_dev` ([ncols][nout]) when given
+static int koopman_cols(isk_engine* e, const float* ys, int64_t D, int64_t K, int64_t ncols, float* out_host) {
+    const bool is_coords = e->cfg.featurizer != ISK_FEAT_IDENTITY;
+    const long long S = K * ncols;
+    TmpBuf in, xh, o, ks;
+    HIPCHK(hipMalloc(&in.p, (size_t)S * D * sizeof(float)));
+    HIPCHK(hipMalloc(&xh.p, (size_t)S * e->Fp * sizeof(float)));
+    HIPCHK(hipMalloc(&o.p, (size_t)S * e->nout * sizeof(float)));
+    HIPCHK(hipMalloc(&ks.p, (size_t)ncols * e->nout * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(in.p, ys, (size_t)S * D * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    FeatArgs a;
+    a.in = (const float*)in.p; a.pairs = is_coords ? e->d_pairs : nullptr; a.packed_pairs = is_coords ? e->d_packed : nullptr;
+    a.xhat = (float*)xh.p; a.S = S; a.D = (int)D; a.F = e->F; a.Fp = e->Fp;
+    a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps; a.background = 0;
+    isk_launch_featurize(a, e->stream);
+    MlpFwdArgs f = fwd_args(e, (const float*)xh.p, S, (float*)o.p);
+    if (launch_forward(e, f) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
+    KmeanArgs k;
+    k.out_ys = (const float*)o.p; k.ks = (float*)ks.p; k.N = ncols; k.K = (int)K; k.nout = e->nout;
+    isk_launch_kmean(k, e->stream);
+    HIPCHK(hipMemcpyAsync(out_host, ks.p, (size_t)ncols * e->nout * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    return ISK_OK;
+}
+
+extern "C" int isk_koopman_coords(isk_engine* e, const float* ys, int64_t D, int64_t K, int64_t ncols, float* out) {
+    if (!e || !ys || !out) return fail(ISK_EINVAL, "null argument");
+    if (D != e->Din) return fail(ISK_EINVAL, "coordinate dimension mismatch");
+    if (K < 1) return fail(ISK_EINVAL, "K must be positive");
+    if (ncols <= 0) return ISK_OK;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    return koopman_cols(e, ys, D, K, ncols, out);
+}
+
+extern "C" int isk_validationloss(isk_engine* e, const float* vxs, const float* vys, int64_t D, int64_t K, int64_t Nv, double* loss) {
+    CHK(need_data(e));
+    if (!vxs || !vys || !loss || Nv < 1) return fail(ISK_EINVAL, "bad argument");
+    if (e->nout != 1) return fail(ISK_EINVAL, "TransformShiftscale only works with one dimensional chi functions");
+    if (D != e->Din) return fail(ISK_EINVAL, "coordinate dimension mismatch");
+    std::vector<float> c(Nv), k1(Nv), k2(e->N);
+    CHK(forward_cols(e, vxs, D, Nv, e->cfg.featurizer != ISK_FEAT_IDENTITY, c.data()));       // chi(vx)
+    CHK(koopman_cols(e, vys, D, K, Nv, k1.data()));                                            // K chi on the validation pairs
+    CHK(forward_resident(e, 1));                                                               // K chi on ALL training data
+    launch_kmean(e);
+    HIPCHK(hipMemcpyAsync(k2.data(), e->d_ks, (size_t)e->N * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    float lo = INFINITY, hi = -INFINITY;
+    for (float v : k1) { lo = std::fmin(lo, v); hi = std::fmax(hi, v); }
+    for (float v : k2) { lo = std::fmin(lo, v); hi = std::fmax(hi, v); }
+    if (!(hi > lo)) return fail(ISK_ECONSTANT_CHI, isk_status_string(ISK_ECONSTANT_CHI));
+    double acc = 0;
+    for (int64_t i = 0; i < Nv; ++i) {
+        const float sk = (k1[i] - lo) / (hi - lo);
+        const double d = (double)c[i] - (double)sk;
+        acc += d * d;
+    }
+    *loss = acc / (double)Nv;
+    return ISK_OK;
+}
+
 extern "C" int isk_target(isk_engine* e, float* out) {
     CHK(need_data(e));
     CHK(compute_target(e, true));

@@ -615,6 +615,36 @@ def koopman(iso: Iso) -> np.ndarray:
     return expectation(iso.model, iso.data.features[1])
 
 
+def validationloss(iso: Iso, valdata: SimulationData) -> float:
+    """src/iso.jl:160-168: mean(abs2, chi(vx) - shiftscale([K chi(vy); K chi(ys)])[1:nv]); 1-D chi"""
+    xs, ys = iso.data.features
+    vx, vy = valdata.features
+    c = iso.model(vx).reshape(-1)
+    k1 = expectation(iso.model, vy).reshape(-1)
+    k2 = expectation(iso.model, ys).reshape(-1)
+    skc = shiftscale(np.concatenate([k1, k2]))[:len(c)]
+    return float(np.mean((c - skc) ** 2))
+
+
+def koopman_variance(iso: Iso, ys_features: Optional[np.ndarray] = None) -> float:
+    """src/iso.jl:355-359: sum(abs2, chi - mean_k chi) / nout / N over the propagated samples"""
+    ys = iso.data.features[1] if ys_features is None else ys_features
+    chi = iso.model(ys)
+    i, k, n = chi.shape
+    return float(np.sum((chi - chi.sum(axis=1, keepdims=True) / k) ** 2) / i / n)
+
+
+def rates(x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """src/iso.jl:345-351: log(y / x) with the 1-D case extended by (1 - chi); y / x is Julia's
+    right division (least squares for non-square operands)"""
+    import scipy.linalg
+    if x.shape[0] == 1:
+        x = np.concatenate([x, 1 - x], axis=0)
+        y = np.concatenate([y, 1 - y], axis=0)
+    q = np.linalg.lstsq(x.T, y.T, rcond=None)[0].T
+    return scipy.linalg.logm(q)
+
+
 # ----------------------------------------------------------------------------------
 # synthetic workloads shared by tests, smoke and bench (SURVEY.md section 8d)
 # ----------------------------------------------------------------------------------

@@ -353,3 +353,28 @@ def test_dp_driver_single_rank_matches_run(gpu_pkg, nout, minibatch):
     np.testing.assert_allclose(pkg.chis(b), pkg.chis(a), atol=1e-5)
     a.close()
     b.close()
+
+
+def test_evaluation_callers(gpu_pkg):
+    """koopman on foreign data, validation loss (+ logger), Koopman variance"""
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 18, 50, 120, 4, 1, seed=41)
+    vxs, vys = O.synthetic_coords(18, 40, 4, seed=77)
+    feat = O.FeaturesPairs(O.random_pairs(18, 50, seed=42))
+    oval = O.SimulationData(np.asarray(vxs, np.float64), np.asarray(vys, np.float64), feat)
+    val = pkg.SimulationData(vxs, vys, data.featurizer)
+    logger = pkg.ValidationLossLogger(val, logevery=2)
+    iso = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(), minibatch=0, loggers=[logger])
+    oiso = O.Iso(odata, om, O.setup(O.AdamRegularized(), om), minibatch=0)
+    np.testing.assert_allclose(pkg.koopman_coords(iso, vys), O.expectation(om, oval.features[1]), atol=2e-5)
+    assert pkg.validationloss(iso, val) == pytest.approx(O.validationloss(oiso, oval), rel=2e-4, abs=1e-9)
+    assert pkg.koopman_variance(iso) == pytest.approx(O.koopman_variance(oiso), rel=1e-3)
+    perms = np.stack([np.arange(120)] * 4)
+    pkg.run(iso, 4, 1, perms=perms)
+    O.run(oiso, 4, 1, perms=list(perms))
+    assert logger.iters == [2, 4] and len(logger.losses) == 2
+    assert logger.losses[-1] == pytest.approx(O.validationloss(oiso, oval), rel=1e-3, abs=1e-9)
+    x, y = pkg.chi_kchi(iso)
+    np.testing.assert_allclose(O.rates(x.astype(np.float64), y.astype(np.float64)),
+                               O.rates(O.chis(oiso), O.koopman(oiso)), atol=2e-3)
+    iso.close()
