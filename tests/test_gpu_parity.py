@@ -378,3 +378,47 @@ def test_evaluation_callers(gpu_pkg):
     np.testing.assert_allclose(O.rates(x.astype(np.float64), y.astype(np.float64)),
                                O.rates(O.chis(oiso), O.koopman(oiso)), atol=2e-3)
     iso.close()
+
+
+@pytest.mark.parametrize("F,N,K,widths,minibatch", [
+    (1, 2, 1, [1, 1, 1], 0),            # smallest non-degenerate problem
+    (1, 17, 1, [1, 3, 1], 5),           # K = 1, ragged N, ragged minibatch tail
+    (3, 33, 7, [3, 2, 1, 1], 100),      # minibatch > N -> full batch (src/iso.jl:180)
+    (6, 128, 2, [6, 12, 5], 16),        # ISA, 5-dimensional chi (5! row permutations)
+    (2, 100, 5, [2, 2, 1, 1], 100),     # C1 shape
+])
+def test_edge_shapes_run_matches_oracle(gpu_pkg, F, N, K, widths, minibatch):
+    pkg = gpu_pkg
+    rng = np.random.default_rng(F * 100 + N)
+    xs = rng.uniform(size=(F, N)) + 0.5
+    ys = xs[:, None, :] + 0.3 * rng.uniform(size=(F, K, N))
+    om = _rand_model(widths, seed=N, ln=F > 1)      # LayerNorm over a single feature is identically zero
+    nout = widths[-1]
+    tr, otr = (pkg.TransformShiftscale(), O.TransformShiftscale()) if nout == 1 else (pkg.TransformISA(), O.TransformISA())
+    iso = pkg.Iso(pkg.SimulationData(xs, ys), model=_mk_model(pkg, om), opt=pkg.NesterovRegularized(1e-2, 1e-3), target=tr,
+                  minibatch=minibatch)
+    x32, y32 = np.asarray(xs, np.float32).astype(np.float64), np.asarray(ys, np.float32).astype(np.float64)
+    oiso = O.Iso(O.SimulationData(x32, y32), om, O.setup(O.NesterovRegularized(1e-2, 1e-3), om), target=otr, minibatch=minibatch)
+    perms = np.stack([rng.permutation(N) for _ in range(3)])
+    t = pkg.isotarget(iso)
+    want = O.isotarget(otr, om, x32, y32)
+    scale = max(1.0, np.abs(want).max())
+    np.testing.assert_allclose(t, want, atol=5e-4 * scale)
+    pkg.run(iso, 3, 1, perms=perms)
+    O.run(oiso, 3, 1, perms=list(perms))
+    np.testing.assert_allclose(iso.losses, oiso.losses, rtol=5e-3 if nout > 1 else 2e-4)
+    np.testing.assert_allclose(pkg.chis(iso), O.chis(oiso), atol=2e-4 if nout > 1 else 2e-5)
+    iso.close()
+
+
+def test_data_slicing_and_reupload(gpu_pkg):
+    """iso.data[6:10]-style slicing (src/simulation.jl:135) builds a new resident data set"""
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 12, 30, 50, 3, 1, seed=13)
+    sub = data[10:30]
+    assert len(sub) == 20
+    a = pkg.Iso(sub, model=_mk_model(pkg, om), minibatch=0)
+    f = O.FeaturesPairs(O.random_pairs(12, 30, seed=14))
+    want = om(f(np.asarray(sub.coords[0], np.float64)))
+    np.testing.assert_allclose(pkg.chis(a), want, atol=2e-5)
+    a.close()
