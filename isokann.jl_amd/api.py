@@ -530,3 +530,75 @@ def koopman_variance(iso: Iso, ys=None) -> float:
     chi = chicoords(iso, iso.data.coords[1] if ys is None else ys)
     i, k, n = chi.shape
     return float(np.sum((chi - chi.sum(axis=1, keepdims=True) / k) ** 2) / i / n)
+
+
+# ------------------------------------- checkpoint / data growth --
+def lastcat(a, b):
+    """lastcat(x, y) (src/data.jl:59-62): concatenate along the last (sample) axis"""
+    return np.concatenate([np.asarray(a), np.asarray(b)], axis=-1)
+
+
+def mergedata(d1: SimulationData, d2: SimulationData) -> SimulationData:
+    """mergedata(d1, d2) (src/simulation.jl:162-171): coords of both, featurizer of d1"""
+    return SimulationData(lastcat(d1.coords[0], d2.coords[0]), lastcat(d1.coords[1], d2.coords[1]), d1.featurizer)
+
+
+def set_data(iso: Iso, data: SimulationData) -> Iso:
+    """`iso.data = newdata` (src/iso.jl:238,289): re-upload and re-featurize; model and optimizer state stay"""
+    if featuredim(data) != iso.modelspec.widths[0]:
+        raise ValueError("feature dimension of the new data does not match the model")
+    xs, ys = data.coords
+    d, k, n = ys.shape
+    capi.check(iso._lib.isk_set_data(iso._h, capi.ptr_f32(xs), capi.ptr_f32(ys), d, k, n))
+    iso.data = data
+    return iso
+
+
+def _featurizer_state(f):
+    if f is identity:
+        return ("identity", None)
+    if isinstance(f, FeaturesAll):
+        return ("all", None)
+    if isinstance(f, FeaturesAtoms):
+        return ("atoms", np.asarray(f.atominds, np.int64))
+    if isinstance(f, FeaturesPairs):
+        return ("pairs", np.asarray(f.pairlist, np.int64))
+    raise TypeError(f)
+
+
+def save(path: str, iso: Iso) -> None:
+    """save(path, iso) (src/iso.jl:405-408): cpu(iso) then one file with model, optimizer state, data,
+    target and losses.  Parameters and Adam/Nesterov state are stored flat in Flux trainables order
+    (W column-major), the layout a Julia host needs to rebuild a Flux.Chain + Optimisers state tree."""
+    m, v, bt = iso.get_opt_state()
+    fk, fv = _featurizer_state(iso.data.featurizer)
+    t = iso.target
+    np.savez(path, format_version=1,
+             widths=np.asarray(iso.modelspec.widths), activation=iso.modelspec.activation,
+             lastactivation=iso.modelspec.lastactivation, layernorm=iso.modelspec.layernorm,
+             ln_eps=iso.modelspec.ln_eps, ln_mode=iso.modelspec.ln_mode, params=iso.model.get_params(),
+             opt_kind=iso.optspec.kind, opt_hyper=np.asarray([iso.optspec.lr, iso.optspec.reg, iso.optspec.beta1,
+                                                             iso.optspec.beta2, iso.optspec.eps, iso.optspec.rho]),
+             opt_m=m, opt_v=v, opt_bt=bt,
+             xs=iso.data.coords[0], ys=iso.data.coords[1], featurizer_kind=fk,
+             featurizer_arg=np.zeros(0) if fv is None else fv,
+             target_kind=type(t).__name__, target_args=np.asarray([getattr(t, "permute", True), getattr(t, "whitening", False)]),
+             minibatch=iso.minibatch, losses=np.asarray(iso.losses, np.float64))
+
+
+def load(path: str, **iso_kwargs) -> Iso:
+    """load(path) (src/iso.jl:417-420)"""
+    z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz", allow_pickle=False)
+    fk = str(z["featurizer_kind"])
+    feat = {"identity": lambda a: identity, "all": lambda a: FeaturesAll(), "atoms": lambda a: FeaturesAtoms(a),
+            "pairs": lambda a: FeaturesPairs(a)}[fk](z["featurizer_arg"])
+    model = ModelSpec([int(w) for w in z["widths"]], str(z["activation"]), str(z["lastactivation"]), bool(z["layernorm"]),
+                      z["params"].astype(np.float32), float(z["ln_eps"]), str(z["ln_mode"]))
+    h = z["opt_hyper"]
+    opt = OptSpec(str(z["opt_kind"]), *[float(x) for x in h])
+    tk, ta = str(z["target_kind"]), z["target_args"]
+    target = TransformISA(bool(ta[0]), bool(ta[1])) if tk == "TransformISA" else TransformShiftscale()
+    iso = Iso(SimulationData(z["xs"], z["ys"], feat), opt=opt, model=model, target=target, minibatch=int(z["minibatch"]), **iso_kwargs)
+    iso.set_opt_state(z["opt_m"], z["opt_v"], z["opt_bt"])
+    iso.losses = [float(l) for l in z["losses"]]
+    return iso

@@ -422,3 +422,37 @@ def test_data_slicing_and_reupload(gpu_pkg):
     want = om(f(np.asarray(sub.coords[0], np.float64)))
     np.testing.assert_allclose(pkg.chis(a), want, atol=2e-5)
     a.close()
+
+
+def test_save_load_roundtrip_and_data_growth(gpu_pkg, tmp_path):
+    """the reference's own ops test: save / load with coords equality, then keep training
+    (test/runtests.jl:69-78); plus mergedata + set_data (src/simulation.jl:162-171)"""
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 14, 36, 96, 3, 3, seed=51)
+    iso = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(1e-2, 1e-3), minibatch=32, seed=4)
+    pkg.run(iso, 3)
+    path = str(tmp_path / "iso.npz")
+    pkg.save(path, iso)
+    isol = pkg.load(path, seed=4)
+    assert np.array_equal(iso.data.coords[0], isol.data.coords[0]) and np.array_equal(iso.data.coords[1], isol.data.coords[1])
+    assert isol.losses == iso.losses and isinstance(isol.target, pkg.TransformISA)
+    np.testing.assert_array_equal(isol.model.get_params(), iso.model.get_params())
+    for a, b in zip(isol.get_opt_state(), iso.get_opt_state()):
+        np.testing.assert_array_equal(a, b)
+    # resumed training continues exactly like the original (same injected shuffles)
+    perms = np.stack([np.random.default_rng(9).permutation(96) for _ in range(2)])
+    pkg.run(iso, 2, 1, perms=perms)
+    pkg.run(isol, 2, 1, perms=perms)
+    np.testing.assert_allclose(isol.losses, iso.losses, rtol=1e-6)
+    np.testing.assert_allclose(pkg.chis(isol), pkg.chis(iso), atol=1e-6)
+    # data growth: append 32 new starts, model and optimizer state stay
+    xs2, ys2 = O.synthetic_coords(14, 32, 3, seed=99)
+    merged = pkg.mergedata(iso.data, pkg.SimulationData(xs2, ys2, iso.data.featurizer))
+    p_before = iso.model.get_params()
+    pkg.set_data(iso, merged)
+    assert len(iso.data) == 128 and pkg.chis(iso).shape == (3, 128)
+    np.testing.assert_array_equal(iso.model.get_params(), p_before)
+    pkg.run(iso, 1)
+    assert np.isfinite(iso.losses[-1])
+    iso.close()
+    isol.close()
