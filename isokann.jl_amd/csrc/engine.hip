@@ -537,7 +537,10 @@ static void featurize_ys_ahead(isk_engine* e) {
 
 // mode 2: called once the target of this iteration is enqueued (every earlier reader of the other
 // buffer precedes this point on the main stream)
-static void featurize_ys_beside_training(isk_engine* e) {
+static void featurize_ys_beside_training(isk_engine* e, long long train_launch_steps) {
+    // only worth it when the training phase is a long chain of small launches: with a handful of big steps the
+    // throttled featurizer would outlast them and become the critical path (measured at minibatch = 0)
+    if (train_launch_steps < 4) return;
     if (overlap_mode() != 2 || !e->cfg.featurize_every_iteration || !e->d_xhat_alt || e->ys_ahead) return;
     (void)hipEventRecord(e->ev_fwd_done, e->stream);
     (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
@@ -1148,7 +1151,11 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
         if (e->cfg.featurize_every_iteration) featurize_resident(e);
         // the constant-chi check needs the device status word; it is read together with the loss
         CHK(compute_target(e, false, e->cfg.featurize_every_iteration != 0));
-        featurize_ys_beside_training(e);
+        {
+            const int mb = e->cfg.minibatch;
+            const long long bs = (mb == 0 || e->N < mb) ? e->N : mb;
+            featurize_ys_beside_training(e, (e->N / bs) * epochs);
+        }
         for (int ep = 0; ep < epochs; ++ep) {
             double l = 0;
             const int32_t* p = perms ? perms + k * e->N : nullptr;
@@ -1310,7 +1317,7 @@ extern "C" int isk_dp_epoch_begin(isk_engine* e, const int32_t* perm, int32_t n)
     HIPCHK(hipMemsetAsync(e->d_loss_acc, 0, 2 * sizeof(double), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));                 // perm is caller-owned
     e->dp_perm_len = n;
-    featurize_ys_beside_training(e);
+    featurize_ys_beside_training(e, 4);      // the host-driven step loop leaves the GPU even idler
     return ISK_OK;
 }
 
