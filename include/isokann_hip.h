@@ -151,6 +151,13 @@ int  isk_koopman_coords(isk_engine* e, const float* ys, int64_t D, int64_t K, in
  * 1-D chi only; vxs (D, Nv), vys (D, K, Nv) are validation COORDINATES */
 int  isk_validationloss(isk_engine* e, const float* vxs, const float* vys, int64_t D, int64_t K, int64_t Nv, double* loss);
 
+/* ---- d chi / d coords ----------------------------------- */
+/* Zygote-style pullback of chicoords: grad (D, ncols) = (d chi(coords_n) / d coords_n)' * cot[:, n], through
+ * the MLP, the LayerNorm and the pairwise-distance featurizer.  Counterpart of the reference's
+ * sqpairdist_bwd_kernel! + rrule (src/utils/pairdists.jl:153-196); consumers: src/utils/minimumpath.jl:3-13,
+ * src/simulators/metadynamics.jl:40-43, src/simulators/openmm.jl:659-664.  cot is (nout, ncols). */
+int  isk_chicoords_pullback(isk_engine* e, const float* coords, int64_t D, int64_t ncols, const float* cot, float* grad);
+
 /* ---- target: isotarget(iso)   src/isotarget.jl:10-42, 74-127 ------------------- */
 /* Computes the target on the resident data, keeps it on the device for training and,
  * if out != NULL, copies it to out (nout, N). */

@@ -602,3 +602,25 @@ def load(path: str, **iso_kwargs) -> Iso:
     iso.set_opt_state(z["opt_m"], z["opt_v"], z["opt_bt"])
     iso.losses = [float(l) for l in z["losses"]]
     return iso
+
+
+# ------------------------------------------------ d chi / d coords --
+def chicoords_pullback(iso: Iso, xs, cot) -> np.ndarray:
+    """Zygote pullback of chicoords(iso, xs) (src/iso.jl:211): (d chi / d xs)' * cot, cot (nout, n) -> (D, n).
+    What `Zygote.gradient(x -> sum(cot .* chicoords(iso, x)), xs)` returns in the reference
+    (src/utils/minimumpath.jl:3-13, src/simulators/metadynamics.jl:40-43)."""
+    x = capi.f32(xs)
+    if x.ndim == 1:
+        x = x.reshape(-1, 1, order="F")
+    d, n = x.shape
+    c = capi.f32(np.asarray(cot).reshape(iso.nout, n, order="F"))
+    out = np.empty((d, n), np.float32, order="F")
+    capi.check(iso._lib.isk_chicoords_pullback(iso._h, capi.ptr_f32(x), d, n, capi.ptr_f32(c), capi.ptr_f32(out)))
+    return out
+
+
+def dchidx(iso: Iso, x) -> np.ndarray:
+    """Jacobian d chi / d x of chicoords at ONE coordinate vector x (D,) -> (nout, D) (dchidx, src/simulators/openmm.jl:659-664)"""
+    x = np.asarray(x, np.float32).reshape(-1)
+    xs = np.repeat(x[:, None], iso.nout, axis=1)
+    return chicoords_pullback(iso, xs, np.eye(iso.nout, dtype=np.float32)).T

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "isk_koopman": (C.c_int, [_H, _f32p]),
     "isk_koopman_coords": (C.c_int, [_H, _f32p, C.c_int64, C.c_int64, C.c_int64, _f32p]),
     "isk_validationloss": (C.c_int, [_H, _f32p, _f32p, C.c_int64, C.c_int64, C.c_int64, _f64p]),
+    "isk_chicoords_pullback": (C.c_int, [_H, _f32p, C.c_int64, C.c_int64, _f32p, _f32p]),
     "isk_target": (C.c_int, [_H, _f32p]),
     "isk_train_batch": (C.c_int, [_H, _f32p, C.c_int32, _i32p, _f64p]),
     "isk_batch_grads": (C.c_int, [_H, _f32p, _i32p, C.c_int32, _f32p, _f64p]),

@@ -482,7 +482,7 @@ extern "C" int isk_reset_opt_state(isk_engine* e) {
 // data
 // ---------------------------------------------------------------------------------------
 static void featurize_rows(isk_engine* e, const float* in, long long S, float* xhat, hipStream_t st = nullptr) {
-    FeatArgs a;
+    FeatArgs a = {};
     a.in = in; a.pairs = e->d_pairs; a.packed_pairs = e->d_packed; a.xhat = xhat; a.S = S; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
     a.background = (st != nullptr);
@@ -616,7 +616,7 @@ extern "C" int isk_features(isk_engine* e, const float* coords, int64_t D, int64
     HIPCHK(hipMalloc(&in.p, (size_t)ncols * D * sizeof(float)));
     HIPCHK(hipMalloc(&xh.p, (size_t)ncols * e->Fp * sizeof(float)));
     HIPCHK(hipMemcpyAsync(in.p, coords, (size_t)ncols * D * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    FeatArgs a;
+    FeatArgs a = {};
     a.in = (const float*)in.p; a.pairs = e->d_pairs; a.packed_pairs = e->d_packed; a.xhat = (float*)xh.p; a.S = ncols; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
     a.normalize = 0; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;   // raw features: the featurizer alone
     a.background = 0;
@@ -635,7 +635,7 @@ static int forward_cols(isk_engine* e, const float* host_in, int64_t rowlen, int
     HIPCHK(hipMalloc(&xh.p, (size_t)ncols * e->Fp * sizeof(float)));
     HIPCHK(hipMalloc(&o.p, (size_t)ncols * e->nout * sizeof(float)));
     HIPCHK(hipMemcpyAsync(in.p, host_in, (size_t)ncols * rowlen * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    FeatArgs a;
+    FeatArgs a = {};
     a.in = (const float*)in.p; a.pairs = is_coords ? e->d_pairs : nullptr; a.packed_pairs = is_coords ? e->d_packed : nullptr;
     a.xhat = (float*)xh.p; a.S = ncols;
     a.D = (int)rowlen; a.F = e->F; a.Fp = e->Fp;
@@ -977,7 +977,7 @@ static int koopman_cols(isk_engine* e, const float* ys, int64_t D, int64_t K, in
     HIPCHK(hipMalloc(&o.p, (size_t)S * e->nout * sizeof(float)));
     HIPCHK(hipMalloc(&ks.p, (size_t)ncols * e->nout * sizeof(float)));
     HIPCHK(hipMemcpyAsync(in.p, ys, (size_t)S * D * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    FeatArgs a;
+    FeatArgs a = {};
     a.in = (const float*)in.p; a.pairs = is_coords ? e->d_pairs : nullptr; a.packed_pairs = is_coords ? e->d_packed : nullptr;
     a.xhat = (float*)xh.p; a.S = S; a.D = (int)D; a.F = e->F; a.Fp = e->Fp;
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps; a.background = 0;
@@ -1025,6 +1025,58 @@ extern "C" int isk_validationloss(isk_engine* e, const float* vxs, const float* 
         acc += d * d;
     }
     *loss = acc / (double)Nv;
+    return ISK_OK;
+}
+
+// chicoords pullback: grad (D, ncols) = (d chi / d coords)' * cot, column by column
+extern "C" int isk_chicoords_pullback(isk_engine* e, const float* coords, int64_t D, int64_t ncols, const float* cot, float* grad) {
+    if (!e || !coords || !cot || !grad) return fail(ISK_EINVAL, "null argument");
+    if (D != e->Din) return fail(ISK_EINVAL, "coordinate dimension mismatch");
+    if (ncols <= 0) return ISK_OK;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const bool is_coords = e->cfg.featurizer != ISK_FEAT_IDENTITY;
+    if (is_coords && !e->d_packed) return fail(ISK_EUNSUPPORTED, "pullback needs the register featurizer (<= 65535 atoms)");
+    if (e->Fp > 2048 || D > 2048) return fail(ISK_EUNSUPPORTED, "pullback covers <= 2048 features / coordinates per sample");
+    const int H1p = isk_pad16(e->cfg.widths[1]);
+    const TrainShape ts = train_shape(e);
+    const int64_t CH = 16384;
+    for (int64_t c0 = 0; c0 < ncols; c0 += CH) {
+        const int64_t n = std::min<int64_t>(CH, ncols - c0);
+        const int64_t npad = ((n + 15) / 16) * 16;
+        TmpBuf in, xh, raw, st, z1, d1, part, ct, gr;
+        HIPCHK(hipMalloc(&in.p, (size_t)n * D * sizeof(float)));
+        HIPCHK(hipMalloc(&xh.p, (size_t)n * e->Fp * sizeof(float)));
+        HIPCHK(hipMalloc(&raw.p, (size_t)n * e->Fp * sizeof(float)));
+        HIPCHK(hipMalloc(&st.p, (size_t)n * 2 * sizeof(float)));
+        HIPCHK(hipMalloc(&z1.p, (size_t)npad * H1p * sizeof(float)));
+        HIPCHK(hipMalloc(&d1.p, (size_t)npad * H1p * sizeof(float)));
+        HIPCHK(hipMalloc(&part.p, (size_t)isk_train_part_floats(ts, (int)n) * sizeof(float)));
+        HIPCHK(hipMalloc(&ct.p, (size_t)n * e->nout * sizeof(float)));
+        HIPCHK(hipMalloc(&gr.p, (size_t)n * D * sizeof(float)));
+        HIPCHK(hipMemcpyAsync(in.p, coords + c0 * D, (size_t)n * D * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(ct.p, cot + c0 * e->nout, (size_t)n * e->nout * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        FeatArgs a = {};
+        a.in = (const float*)in.p; a.pairs = is_coords ? e->d_pairs : nullptr; a.packed_pairs = is_coords ? e->d_packed : nullptr;
+        a.xhat = (float*)xh.p; a.S = n; a.D = (int)D; a.F = e->F; a.Fp = e->Fp;
+        a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
+        a.raw = (float*)raw.p; a.stats = (float*)st.p;
+        isk_launch_featurize(a, e->stream);
+        TrainBuffers tb = train_buffers(e);
+        tb.xhat_xs = (const float*)xh.p; tb.target = (const float*)ct.p; tb.a1 = (float*)z1.p; tb.delta1 = (float*)d1.p;
+        tb.part = (float*)part.p; tb.cot_mode = 1;
+        isk_launch_train_fwd1(ts, tb, nullptr, (int)n, e->stream);
+        isk_launch_train_tail(ts, tb, nullptr, (int)n, 1.0f, e->stream);
+        VjpArgs v = {};
+        v.delta1 = (const float*)d1.p; v.xhat = (const float*)xh.p; v.raw = (const float*)raw.p; v.stats = (const float*)st.p;
+        v.coords = (const float*)in.p; v.pairs = is_coords ? e->d_pairs : nullptr; v.theta = e->d_theta;
+        v.off_W0 = e->off_W[0]; v.off_lns = e->cfg.layernorm ? e->off_lns : -1;
+        v.grad = (float*)gr.p; v.S = n; v.D = (int)D; v.F = e->F; v.Fp = e->Fp; v.H1 = e->cfg.widths[1]; v.H1p = H1p;
+        v.ln_mode = e->cfg.ln_mode;
+        isk_launch_vjp_back(v, e->stream);
+        HIPCHK(hipMemcpyAsync(grad + c0 * D, gr.p, (size_t)n * D * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipGetLastError());
+    }
     return ISK_OK;
 }
 

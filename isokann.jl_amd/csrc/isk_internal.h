@@ -25,6 +25,8 @@ struct FeatArgs {
     int ln_mode;            // isk_ln_mode
     float eps;
     int background;         // launched on the side stream next to other kernels: may be throttled
+    float* raw;             // optional [S][Fp]: un-normalised features (needed by the coordinate pullback)
+    float* stats;           // optional [S][2]: mean, 1/denominator of the LayerNorm standardisation
 };
 void isk_launch_featurize(const FeatArgs& a, hipStream_t st);
 
@@ -122,11 +124,13 @@ struct TrainBuffers {
     float* part;            // per-workgroup partial sums from the tail kernel
     float* grad;            // flat gradient [nparams] + [loss, nonfinite]
     double* loss_acc;       // [2]: epoch loss sum (double), collapsed flag (as double)
+    int cot_mode;           // 1: `target` is a cotangent (coordinate pullback), see isk_launch_train_tail
     int Fp;
 };
 // batch rows are perm[first .. first+B)
 void isk_launch_train_fwd1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, hipStream_t st);
 void isk_launch_train_tail(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div, hipStream_t st);
+// cotangent mode: b.target holds the cotangent [B][nout]; delta_L = cot .* act'(z_L), no loss, no weights
 void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st);
 #define ISK_MAX_SLABS 8
 int  isk_train_tail_nblocks(int B);
@@ -142,3 +146,21 @@ struct OptArgs {
     const double* loss_acc; // collapsed flag at [1]: skip the update when set (src/iso.jl:186-189 throws before update!)
 };
 void isk_launch_opt_step(const OptArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------- coordinate pullback ----
+// grad[n] = (d chi / d coords_n)' * cot[n]  (Zygote pullback of chicoords; the counterpart of the reference's
+// sqpairdist_bwd_kernel!, src/utils/pairdists.jl:153-196, extended through LayerNorm and the MLP)
+struct VjpArgs {
+    const float* delta1;    // [Bpad][H1p] dL/dz1 from the tail kernel (cotangent mode)
+    const float* xhat;      // [S][Fp]
+    const float* raw;       // [S][Fp] distances (pdist featurizers) -- unused for identity
+    const float* stats;     // [S][2]
+    const float* coords;    // [S][D]
+    const int2*  pairs;     // [F] or nullptr (identity featurizer: the gradient is w.r.t. the features)
+    const float* theta;     // flat parameters
+    long long off_W0, off_lns;   // offsets of W1 and the LayerNorm scale (off_lns < 0: no LayerNorm)
+    float* grad;            // [S][D]
+    long long S;
+    int D, F, Fp, H1, H1p, ln_mode;
+};
+void isk_launch_vjp_back(const VjpArgs& a, hipStream_t st);

@@ -179,6 +179,15 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
             const int f = lane + 64 * i;
             if (f < a.Fp) orow[f] = (f < a.F) ? (d[i] - mu) * rstd : 0.f;
         }
+        if (a.raw) {                                         // wave-uniform: kept for the coordinate pullback
+            float* rrow = a.raw + s * (long long)a.Fp;
+#pragma unroll
+            for (int i = 0; i < NFL; ++i) {
+                const int f = lane + 64 * i;
+                if (f < a.Fp) rrow[f] = (f < a.F) ? d[i] : 0.f;
+            }
+        }
+        if (a.stats && lane == 0) { a.stats[2 * s] = mu; a.stats[2 * s + 1] = rstd; }
     }
 }
 

@@ -227,13 +227,17 @@ __global__ __launch_bounds__(TAIL_THREADS) void train_tail_kernel(TrainShape s, 
             const bool valid = row < B;
             const int rowc = valid ? row : B - 1;
             const long long prow = perm ? perm[rowc] : rowc;
-            const float w = b.lossw[o];
             const float out = AL[p];
-            const float r = (out - b.target[prow * nout + o]) * w;
             float d = 0.f;
-            if (valid) {
-                lsum += r * r;
-                d = 2.f * r * w * inv_div * t_dact(s.lastact, ZL[p], out);
+            if (b.cot_mode) {                              // pullback: delta_L = cotangent .* act'(z_L)
+                if (valid) d = b.target[prow * nout + o] * t_dact(s.lastact, ZL[p], out);
+            } else {
+                const float w = b.lossw[o];
+                const float r = (out - b.target[prow * nout + o]) * w;
+                if (valid) {
+                    lsum += r * r;
+                    d = 2.f * r * w * inv_div * t_dact(s.lastact, ZL[p], out);
+                }
             }
             ZL[p] = d;
         }
@@ -536,4 +540,95 @@ void isk_launch_opt_step(const OptArgs& a, hipStream_t st) {
     if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     hipLaunchKernelGGL(opt_step_kernel, dim3((unsigned)b), dim3(256), 0, st, a, (double*)a.loss_acc);
+}
+
+// ------------------------------------------------------------------ coordinate pullback ---
+// one workgroup per sample column:
+//   dxhat[f] = g[f] * sum_o delta1[o] * W1[o][f]                       (layer 1 + LayerNorm scale)
+//   dfeat[f] = rstd * (dxhat[f] - mean(dxhat) - xhat[f] * mean(dxhat .* xhat) * c)   (standardisation; c = 1, or
+//              (std+eps)/std for the (x-mu)/(std+eps) variant)
+//   grad[a] += dfeat[f] * (x_a - x_b) / d_f,  grad[b] -= ...           (pairwise distances; LDS float atomics)
+__global__ __launch_bounds__(256) void vjp_back_kernel(VjpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float red[2][4];
+    float* dl = sm;                        // [H1p]  delta1 of this sample
+    float* dx = sm + a.H1p;                // [Fp]   dxhat, then dfeat
+    float* gc = dx + a.Fp;                 // [D]    coordinate gradient accumulator (pdist) 
+    const long long n = blockIdx.x;
+    const int tid = threadIdx.x;
+    const bool ln = a.off_lns >= 0;
+    for (int o = tid; o < a.H1p; o += 256) dl[o] = a.delta1[n * a.H1p + o];
+    if (a.pairs)
+        for (int i = tid; i < a.D; i += 256) gc[i] = 0.f;
+    __syncthreads();
+    const float* W1 = a.theta + a.off_W0;
+    const float* g = ln ? a.theta + a.off_lns : nullptr;
+    const float* xh = a.xhat + n * a.Fp;
+    float s1 = 0.f, s2 = 0.f;
+    for (int f = tid; f < a.F; f += 256) {
+        const float* w = W1 + (long long)f * a.H1;
+        float acc0 = 0.f, acc1 = 0.f;
+        int o = 0;
+        for (; o + 1 < a.H1; o += 2) { acc0 += dl[o] * w[o]; acc1 += dl[o + 1] * w[o + 1]; }
+        if (o < a.H1) acc0 += dl[o] * w[o];
+        float v = acc0 + acc1;
+        if (ln) v *= g[f];
+        dx[f] = v;
+        s1 += v;
+        s2 += v * xh[f];
+    }
+    if (ln) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, WAVE); s2 += __shfl_xor(s2, o, WAVE); }
+        if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
+        __syncthreads();
+        const float m1 = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)a.F;
+        float m2 = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)a.F;
+        const float rstd = a.stats[2 * n + 1];
+        if (a.ln_mode == ISK_LN_STD_EPS) {
+            // xhat = (x-mu)/(std+eps): d(std+eps)/dx_j = (x_j-mu)/(F*std)
+            float var = 0.f;   // recover std from xhat: mean(xhat^2) = var/(std+eps)^2
+            float q = 0.f;
+            for (int f = tid; f < a.F; f += 256) q += xh[f] * xh[f];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, WAVE);
+            __syncthreads();
+            if ((tid & 63) == 0) red[0][tid >> 6] = q;
+            __syncthreads();
+            var = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)a.F;   // = std^2 * rstd^2
+            const float stdv = sqrtf(var) / rstd;
+            m2 *= (stdv > 0.f) ? (1.0f / rstd) / stdv : 0.f;
+        }
+        for (int f = tid; f < a.F; f += 256) dx[f] = rstd * (dx[f] - m1 - xh[f] * m2);
+    }
+    __syncthreads();
+    if (!a.pairs) {                        // identity featurizer: the input IS the feature vector
+        float* out = a.grad + n * (long long)a.D;
+        for (int f = tid; f < a.F; f += 256) out[f] = dx[f];
+        return;
+    }
+    const float* c = a.coords + n * (long long)a.D;
+    const float* raw = a.raw + n * a.Fp;
+    for (int f = tid; f < a.F; f += 256) {
+        const int2 p = a.pairs[f];
+        const float d = raw[f];
+        const float sc = d > 0.f ? dx[f] / d : 0.f;        // d|x_a - x_b|/dx is undefined at 0: subgradient 0, as sqrt'(0)*0
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = sc * (c[3 * p.x + k] - c[3 * p.y + k]);
+            atomicAdd(&gc[3 * p.x + k], v);
+            atomicAdd(&gc[3 * p.y + k], -v);
+        }
+    }
+    __syncthreads();
+    float* out = a.grad + n * (long long)a.D;
+    for (int i = tid; i < a.D; i += 256) out[i] = gc[i];
+}
+
+void isk_launch_vjp_back(const VjpArgs& a, hipStream_t st) {
+    if (a.S <= 0) return;
+    const size_t lds = (size_t)(a.H1p + a.Fp + (a.pairs ? a.D : 0)) * sizeof(float);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)vjp_back_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(vjp_back_kernel, dim3((unsigned)a.S), dim3(256), lds, st, a);
 }

@@ -456,3 +456,70 @@ def test_save_load_roundtrip_and_data_growth(gpu_pkg, tmp_path):
     assert np.isfinite(iso.losses[-1])
     iso.close()
     isol.close()
+
+
+def _torch_chi_of_coords(om, pairs, x):
+    """independent double-precision chi(coords) in torch (pdist -> LayerNorm -> MLP) for autograd"""
+    import torch
+    if pairs is None:
+        a = x
+    else:
+        c = x.reshape(-1, 3)
+        a = torch.linalg.norm(c[[p[0] for p in pairs]] - c[[p[1] for p in pairs]], dim=1)
+    if om.layernorm:
+        mu = a.mean()
+        var = ((a - mu) ** 2).mean()
+        if om.ln_mode == "var_eps2":
+            a = (a - mu) / torch.sqrt(var + om.ln_eps ** 2)
+        elif om.ln_mode == "std_eps":
+            a = (a - mu) / (torch.sqrt(var) + om.ln_eps)
+        else:
+            a = (a - mu) / torch.sqrt(var + om.ln_eps)
+        a = a * torch.tensor(om.ln_scale) + torch.tensor(om.ln_bias)
+    fn = {"sigmoid": torch.sigmoid, "identity": lambda z: z, "tanh": torch.tanh, "relu": torch.relu,
+          "swish": lambda z: z * torch.sigmoid(z)}
+    for W, b, act in zip(om.W, om.b, om.acts()):
+        a = fn[act](torch.tensor(W) @ a + torch.tensor(b))
+    return a
+
+
+@pytest.mark.parametrize("nout,mode,act,pdist", [(1, "var_eps2", "sigmoid", True), (3, "std_eps", "tanh", True),
+                                                   (2, "var_eps2", "swish", False)])
+def test_chicoords_pullback_matches_torch_autograd(gpu_pkg, nout, mode, act, pdist):
+    """d chi / d coords through MLP, LayerNorm and pairwise distances"""
+    import torch
+    pkg = gpu_pkg
+    A, F, N = 15, 40, 24
+    rng = np.random.default_rng(60 + nout)
+    if pdist:
+        xs, ys = O.synthetic_coords(A, N, 2, seed=61)
+        pairs = O.random_pairs(A, F, seed=62)
+        feat = pkg.FeaturesPairs(pairs)
+        widths = [F, 11, 5, nout]
+    else:
+        xs = rng.normal(size=(F, N)) + 1
+        ys = rng.normal(size=(F, 2, N)) + 1
+        pairs, feat = None, pkg.identity
+        widths = [F, 11, 5, nout]
+    om = _rand_model(widths, seed=63, act=act)
+    om.ln_mode = mode
+    tr = pkg.TransformShiftscale() if nout == 1 else pkg.TransformISA()
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, feat), model=_mk_model(pkg, om), target=tr, minibatch=0)
+    cot = rng.normal(size=(nout, N))
+    got = pkg.chicoords_pullback(iso, xs, cot)
+    x32 = np.asarray(xs, np.float32).astype(np.float64)
+    want = np.zeros_like(x32)
+    for n in range(N):
+        xt = torch.tensor(x32[:, n], requires_grad=True)
+        (_torch_chi_of_coords(om, pairs, xt) * torch.tensor(cot[:, n])).sum().backward()
+        want[:, n] = xt.grad.numpy()
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(got, want, atol=2e-5 * scale, rtol=2e-4)
+    # Jacobian helper: rows are the gradients of the individual chi components
+    J = pkg.dchidx(iso, xs[:, 0])
+    assert J.shape == (nout, x32.shape[0])
+    for o in range(nout):
+        xt = torch.tensor(x32[:, 0], requires_grad=True)
+        _torch_chi_of_coords(om, pairs, xt)[o].backward()
+        np.testing.assert_allclose(J[o], xt.grad.numpy(), atol=2e-5 * scale, rtol=2e-4)
+    iso.close()
