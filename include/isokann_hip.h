@@ -128,6 +128,9 @@ int  isk_reset_opt_state(isk_engine* e);            /* Flux.setup(opt, model) */
 int  isk_set_data(isk_engine* e, const float* xs, const float* ys, int64_t D, int64_t K, int64_t N);
 int  isk_set_data_dev(isk_engine* e, const float* xs_dev, const float* ys_dev, int64_t D, int64_t K, int64_t N);
 int  isk_data_shape(isk_engine* e, int64_t* D, int64_t* K, int64_t* N);
+/* WeightedSamples (Girsanov reweighting), src/data.jl:187-215: expectation becomes sum_k w[k,n] f(y[k,n]) / K.
+ * w is (1, K, N) column-major, i.e. [N][K]; NULL restores the plain K-mean. */
+int  isk_set_koopman_weights(isk_engine* e, const float* w, int64_t K, int64_t N);
 
 /* ---- featurizer: f(coords)   src/utils/features.jl:22-35, pairdists.jl:6-24,109-127 */
 /* coords (D, ncols) -> out (F, ncols) */

@@ -624,3 +624,42 @@ def dchidx(iso: Iso, x) -> np.ndarray:
     x = np.asarray(x, np.float32).reshape(-1)
     xs = np.repeat(x[:, None], iso.nout, axis=1)
     return chicoords_pullback(iso, xs, np.eye(iso.nout, dtype=np.float32)).T
+
+
+# -------------------------- trajectory builders and weighted samples --
+def data_from_trajectory(xs, reverse: bool = True, stride: int = 1, lag: int = 1):
+    """data_from_trajectory(xs; reverse, stride, lag) (src/data.jl:88-100): (x, y) pairs from a trajectory
+    xs (D, T); with reverse=true each start gets the two time-symmetric partners (K = 2)"""
+    xs = np.asarray(xs)
+    n = xs.shape[1]
+    if reverse:
+        rng = np.arange(lag, n - lag, stride)
+        ys = np.stack([xs[:, rng - lag], xs[:, rng + lag]], axis=1)
+    else:
+        rng = np.arange(0, n - lag, stride)
+        ys = xs[:, rng + lag][:, None, :]
+    return xs[:, rng], ys
+
+
+def data_from_trajectories(xss, **kwargs):
+    """data_from_trajectories(xss; kwargs...) (src/data.jl:111-130)"""
+    if isinstance(xss, np.ndarray) and xss.ndim == 3:
+        xss = [xss[:, :, i] for i in range(xss.shape[2])]
+    datas = [data_from_trajectory(x, **kwargs) for x in xss]
+    return np.concatenate([d[0] for d in datas], axis=1), np.concatenate([d[1] for d in datas], axis=2)
+
+
+@dataclass
+class WeightedSamples:
+    """WeightedSamples(values, weights) (src/data.jl:187-190): ys with Girsanov weights (1, K, N)"""
+    values: np.ndarray
+    weights: np.ndarray
+
+
+def set_koopman_weights(iso: Iso, weights) -> None:
+    """use the weighted expectation (src/data.jl:215) for the resident ys: sum_k w f(y_k) / K; None resets"""
+    if weights is None:
+        capi.check(iso._lib.isk_set_koopman_weights(iso._h, None, 0, 0))
+        return
+    w = capi.f32(np.asarray(weights).reshape(iso.data.nk, len(iso.data), order="F"))
+    capi.check(iso._lib.isk_set_koopman_weights(iso._h, capi.ptr_f32(w), w.shape[0], w.shape[1]))

@@ -122,6 +122,7 @@ struct isk_engine {
     float* d_xhat_alt = nullptr;                     // the other buffer of the pair (per-iteration featurize mode)
     float* d_out = nullptr;                          // [(N*K + N)][nout]
     float *d_ks = nullptr, *d_target = nullptr, *d_lossw = nullptr;
+    float* d_kw = nullptr;                           // optional Koopman sample weights [N][K] (WeightedSamples)
     bool have_target = false, have_ks = false;
     // training workspace
     float *d_z1 = nullptr, *d_delta1 = nullptr, *d_part = nullptr;
@@ -147,7 +148,7 @@ static void free_data(isk_engine* e) {
     if (e->side) (void)hipStreamSynchronize(e->side);
     e->ys_ahead = false;
     free_dev(e->d_in_xs); free_dev(e->d_in_ys); free_dev(e->d_xhat); free_dev(e->d_xhat_alt); free_dev(e->d_out); free_dev(e->d_ks);
-    free_dev(e->d_target); free_dev(e->d_z1); free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm); free_dev(e->d_isa_work);
+    free_dev(e->d_target); free_dev(e->d_kw); e->d_kw = nullptr; free_dev(e->d_z1); free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm); free_dev(e->d_isa_work);
     e->d_isa_work = nullptr;
     e->d_in_xs = e->d_in_ys = e->d_xhat = e->d_xhat_alt = e->d_out = e->d_ks = e->d_target = e->d_z1 = e->d_delta1 = e->d_part = nullptr;
     e->d_perm = nullptr;
@@ -591,6 +592,19 @@ extern "C" int isk_set_data(isk_engine* e, const float* xs, const float* ys, int
 extern "C" int isk_set_data_dev(isk_engine* e, const float* xs, const float* ys, int64_t D, int64_t K, int64_t N) {
     return set_data_impl(e, xs, ys, D, K, N, hipMemcpyDeviceToDevice);
 }
+// WeightedSamples(values, weights) (src/data.jl:187-215): weights (1, K, N) column-major == [N][K]
+extern "C" int isk_set_koopman_weights(isk_engine* e, const float* w, int64_t K, int64_t N) {
+    CHK(need_data(e));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (!w) { free_dev(e->d_kw); e->d_kw = nullptr; return ISK_OK; }
+    if (K != e->K || N != e->N) return fail(ISK_EINVAL, "weights must be (1, K, N) for the resident data");
+    if (!e->d_kw) HIPCHK(hipMalloc((void**)&e->d_kw, (size_t)N * K * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(e->d_kw, w, (size_t)N * K * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->have_ks = e->have_target = false;
+    return ISK_OK;
+}
+
 extern "C" int isk_data_shape(isk_engine* e, int64_t* D, int64_t* K, int64_t* N) {
     if (!e) return fail(ISK_EINVAL, "null engine");
     if (D) *D = e->D; if (K) *K = e->K; if (N) *N = e->N;
@@ -710,7 +724,7 @@ static int forward_resident(isk_engine* e, int which, bool ahead = false) {
 
 static void launch_kmean(isk_engine* e) {
     KmeanArgs k;
-    k.out_ys = e->d_out; k.ks = e->d_ks; k.N = e->N; k.K = (int)e->K; k.nout = e->nout;
+    k.out_ys = e->d_out; k.ks = e->d_ks; k.w = e->d_kw; k.N = e->N; k.K = (int)e->K; k.nout = e->nout;
     isk_launch_kmean(k, e->stream);
     e->have_ks = true;
 }
@@ -985,7 +999,7 @@ static int koopman_cols(isk_engine* e, const float* ys, int64_t D, int64_t K, in
     MlpFwdArgs f = fwd_args(e, (const float*)xh.p, S, (float*)o.p);
     if (launch_forward(e, f) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
     KmeanArgs k;
-    k.out_ys = (const float*)o.p; k.ks = (float*)ks.p; k.N = ncols; k.K = (int)K; k.nout = e->nout;
+    k.out_ys = (const float*)o.p; k.ks = (float*)ks.p; k.w = nullptr; k.N = ncols; k.K = (int)K; k.nout = e->nout;
     isk_launch_kmean(k, e->stream);
     HIPCHK(hipMemcpyAsync(out_host, ks.p, (size_t)ncols * e->nout * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));

@@ -78,6 +78,7 @@ void isk_launch_fold(const FoldArgs& a, hipStream_t st);
 struct KmeanArgs {
     const float* out_ys;    // [N*K][nout]
     float* ks;              // [N][nout]
+    const float* w;         // optional [N][K] sample weights (WeightedSamples / Girsanov): sum_k w*f / K
     long long N; int K, nout;
 };
 void isk_launch_kmean(const KmeanArgs& a, hipStream_t st);

@@ -495,17 +495,18 @@ __global__ __launch_bounds__(256) void kmean_kernel(KmeanArgs a) {
     const int lane = threadIdx.x & 63;
     if (n >= a.N) return;
     const float* base = a.out_ys + n * (long long)a.K * a.nout;
+    const float* w = a.w ? a.w + n * (long long)a.K : nullptr;
     const int tot = a.K * a.nout;
     if (a.nout <= 64 && (64 % a.nout) == 0) {
         // lane l always sees output index l % nout (stride 64 is a multiple of nout)
         float s = 0.f;
-        for (int i = lane; i < tot; i += WAVE) s += base[i];
+        for (int i = lane; i < tot; i += WAVE) s += w ? base[i] * w[i / a.nout] : base[i];
         for (int o = 32; o >= a.nout; o >>= 1) s += __shfl_xor(s, o, WAVE);
         if (lane < a.nout) a.ks[n * a.nout + lane] = s / (float)a.K;
     } else {
         for (int o = lane; o < a.nout; o += WAVE) {
             float s = 0.f;
-            for (int k = 0; k < a.K; ++k) s += base[k * a.nout + o];
+            for (int k = 0; k < a.K; ++k) s += w ? base[k * a.nout + o] * w[k] : base[k * a.nout + o];
             a.ks[n * a.nout + o] = s / (float)a.K;
         }
     }

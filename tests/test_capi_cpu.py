@@ -87,3 +87,20 @@ def test_host_mirror_shapes_and_defaults(pkg):
         pkg.SimulationData(xs, ys[:, :, :1])
     with pytest.raises(ValueError):
         pkg.SimulationData(xs[:5], ys[:5], pkg.FeaturesAll())
+
+
+def test_data_from_trajectory_matches_reference_slicing(pkg):
+    """src/data.jl:88-100, in 0-based terms: reverse=true pairs frame t with (t-lag, t+lag)"""
+    xs = np.arange(2 * 9, dtype=np.float64).reshape(2, 9)
+    x, y = pkg.data_from_trajectory(xs, reverse=True, stride=2, lag=1)
+    assert x.shape == (2, 4) and y.shape == (2, 2, 4)
+    np.testing.assert_array_equal(x, xs[:, [1, 3, 5, 7]])
+    np.testing.assert_array_equal(y[:, 0], xs[:, [0, 2, 4, 6]])
+    np.testing.assert_array_equal(y[:, 1], xs[:, [2, 4, 6, 8]])
+    x, y = pkg.data_from_trajectory(xs, reverse=False, lag=2)
+    assert x.shape == (2, 7) and y.shape == (2, 1, 7)
+    np.testing.assert_array_equal(y[:, 0], xs[:, 2:])
+    xx, yy = pkg.data_from_trajectories([xs, xs[:, :5]], reverse=True)
+    assert xx.shape == (2, 7 + 3) and yy.shape == (2, 2, 10)
+    d = pkg.SimulationData(*pkg.data_from_trajectory(np.random.default_rng(0).normal(size=(6, 20))), pkg.FeaturesAll())
+    assert len(d) == 18 and d.nk == 2

@@ -523,3 +523,20 @@ def test_chicoords_pullback_matches_torch_autograd(gpu_pkg, nout, mode, act, pdi
         _torch_chi_of_coords(om, pairs, xt)[o].backward()
         np.testing.assert_allclose(J[o], xt.grad.numpy(), atol=2e-5 * scale, rtol=2e-4)
     iso.close()
+
+
+def test_weighted_samples_expectation(gpu_pkg):
+    """WeightedSamples (Girsanov): expectation = sum_k w f(y_k) / K  (src/data.jl:215)"""
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 12, 30, 70, 5, 1, seed=71)
+    iso = pkg.Iso(data, model=_mk_model(pkg, om), minibatch=0)
+    w = np.random.default_rng(3).uniform(0.2, 1.8, size=(1, 5, 70))
+    pkg.set_koopman_weights(iso, w)
+    fy = om(odata.features[1])                                   # (1, 5, 70)
+    want = (fy * w).sum(axis=1) / 5
+    np.testing.assert_allclose(pkg.koopman(iso), want, atol=2e-5)
+    t = pkg.isotarget(iso)
+    np.testing.assert_allclose(t, O.shiftscale(want), atol=5e-5)
+    pkg.set_koopman_weights(iso, None)
+    np.testing.assert_allclose(pkg.koopman(iso), fy.mean(axis=1), atol=2e-5)
+    iso.close()
