@@ -592,6 +592,8 @@ extern "C" int isk_set_data(isk_engine* e, const float* xs, const float* ys, int
 extern "C" int isk_set_data_dev(isk_engine* e, const float* xs, const float* ys, int64_t D, int64_t K, int64_t N) {
     return set_data_impl(e, xs, ys, D, K, N, hipMemcpyDeviceToDevice);
 }
+static int need_data(isk_engine* e);
+
 // WeightedSamples(values, weights) (src/data.jl:187-215): weights (1, K, N) column-major == [N][K]
 extern "C" int isk_set_koopman_weights(isk_engine* e, const float* w, int64_t K, int64_t N) {
     CHK(need_data(e));
