@@ -38,8 +38,8 @@ def build_iso(pkg, wl, seed, device, args):
         feat, F = pkg.FeaturesAll(), c["atoms"] * (c["atoms"] - 1) // 2
     else:
         feat, F = pkg.FeaturesPairs(synth.random_pairs(c["atoms"], c["feat"], seed=0)), c["feat"]
-    widths = pkg.pairnet_widths(F, nout=c["nout"])
-    model = pkg.densenet(widths, layernorm=True, seed=0)       # glorot init, identical on every rank
+    widths = c.get("widths") or pkg.pairnet_widths(F, nout=c["nout"])
+    model = pkg.densenet(widths, layernorm=c.get("layernorm", True), seed=0)       # glorot init, identical on every rank
     opt = pkg.AdamRegularized() if args.opt == "adam" else pkg.NesterovRegularized()
     data = pkg.SimulationData(xs, ys, feat)
     iso = pkg.Iso(data, opt=opt, model=model, minibatch=args.minibatch, device=device,
@@ -71,7 +71,8 @@ def cpu_baseline(wl, args):
     else:
         feat = O.FeaturesPairs(synth.random_pairs(c["atoms"], c["feat"], seed=0))
         F = c["feat"]
-    om = O.glorot_model(O.pairnet_widths(F, nout=c["nout"]), np.random.default_rng(0), dtype=np.float32)
+    om = O.glorot_model(c.get("widths") or O.pairnet_widths(F, nout=c["nout"]), np.random.default_rng(0),
+                        layernorm=c.get("layernorm", True), dtype=np.float32)
     rule = O.AdamRegularized() if args.opt == "adam" else O.NesterovRegularized()
     st = O.setup(rule, om)
     rng = np.random.default_rng(0)
@@ -104,7 +105,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5shard"])
     ap.add_argument("--minibatch", type=int, default=1000, help="per-rank minibatch (scripts/villin.jl:37 uses 1000); 0 = full batch")
     ap.add_argument("--opt", default="adam", choices=["adam", "nesterov"])
     ap.add_argument("--cached-features", action="store_true", help="featurize once at set_data (reference semantics) instead of every iteration")

@@ -109,6 +109,16 @@ struct isk_engine {
     float* d_bias[ISK_MAX_LAYERS] = {nullptr};
     void* d_W16 = nullptr;           // split-bf16 planes of the folded layer-1 weights (forward_mode 1)
     bool w16_dirty = true;
+    // layered path (networks too wide for the fused kernels): per-layer images and HBM activations
+    bool layered = false;
+    void* d_W16L[ISK_MAX_LAYERS] = {nullptr};     // bf16 planes per layer (forward_mode 1)
+    float* d_WtT[ISK_MAX_LAYERS] = {nullptr};     // fragment-linear W' per layer l >= 1 (delta back-propagation)
+    float *d_actA = nullptr, *d_actB = nullptr;   // resident forward ping-pong [(N*K+N)][max pad32(H)]
+    float* d_lz[ISK_MAX_LAYERS] = {nullptr};      // training: pre-activations per layer [Bpad][pad16(N_l)]
+    float* d_la[ISK_MAX_LAYERS] = {nullptr};      //           activations
+    float* d_ld[ISK_MAX_LAYERS] = {nullptr};      //           deltas
+    float *d_G0 = nullptr, *d_D0 = nullptr;       // raw layer-0 gradient for the LayerNorm unfold
+    float* d_zero = nullptr;                      // zero bias for the transposed GEMMs
     double* d_loss_acc = nullptr;
     int* d_status = nullptr;
     float* d_mm = nullptr;
@@ -142,6 +152,13 @@ struct isk_engine {
     long long t_cnt[ISK_T_COUNT] = {0};
 };
 
+// padded input width of layer l: the feature rows are padded to 32; hidden activations to 16 on the fused path
+// and to 32 on the layered path (the split-bf16 GEMM contracts 32 at a time)
+static int layer_kp(const isk_engine* e, int l) {
+    if (l == 0) return e->Fp;
+    return e->layered ? isk_pad32(e->cfg.widths[l]) : isk_pad16(e->cfg.widths[l]);
+}
+
 static void free_dev(void* p) { if (p) (void)hipFree(p); }
 
 static void free_data(isk_engine* e) {
@@ -150,6 +167,8 @@ static void free_data(isk_engine* e) {
     free_dev(e->d_in_xs); free_dev(e->d_in_ys); free_dev(e->d_xhat); free_dev(e->d_xhat_alt); free_dev(e->d_out); free_dev(e->d_ks);
     free_dev(e->d_target); free_dev(e->d_kw); e->d_kw = nullptr; free_dev(e->d_z1); free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm); free_dev(e->d_isa_work);
     e->d_isa_work = nullptr;
+    free_dev(e->d_actA); free_dev(e->d_actB); e->d_actA = e->d_actB = nullptr;
+    for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_lz[l]); free_dev(e->d_la[l]); free_dev(e->d_ld[l]); e->d_lz[l] = e->d_la[l] = e->d_ld[l] = nullptr; }
     e->d_in_xs = e->d_in_ys = e->d_xhat = e->d_xhat_alt = e->d_out = e->d_ks = e->d_target = e->d_z1 = e->d_delta1 = e->d_part = nullptr;
     e->d_perm = nullptr;
     e->N = e->K = e->D = 0;
@@ -264,11 +283,15 @@ static TrainBuffers train_buffers(const isk_engine* e) {
 static void launch_fold(isk_engine* e) {
     FoldArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.theta = e->d_theta; a.nlayers = e->L; a.Kp0 = e->Fp;
+    a.theta = e->d_theta; a.nlayers = e->L;
+    for (int l = 0; l < e->L; ++l) a.Kp[l] = layer_kp(e, l);
     for (int i = 0; i <= e->L; ++i) a.widths[i] = e->cfg.widths[i];
     a.off_lns = e->off_lns; a.off_lnb = e->off_lnb;
     for (int l = 0; l < e->L; ++l) { a.off_W[l] = e->off_W[l]; a.off_b[l] = e->off_b[l]; a.Wt[l] = e->d_Wt[l]; a.bias[l] = e->d_bias[l]; }
     isk_launch_fold(a, e->stream);
+    if (e->layered)
+        for (int l = 1; l < e->L; ++l)
+            isk_launch_fold_T(e->d_theta, e->off_W[l], e->cfg.widths[l], e->cfg.widths[l + 1], e->d_WtT[l], e->stream);
     e->w16_dirty = true;
 }
 
@@ -291,10 +314,8 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     if (cfg->target_kind == ISK_TARGET_ISA && nout < 2)
         return fail(ISK_EINVAL, "TransformISA does not work with one dimensional chi functions");
     if (cfg->target_kind == ISK_TARGET_ISA && nout > 8) return fail(ISK_EUNSUPPORTED, "ISA fixperm is brute force over d! permutations; d <= 8");
-    if (isk_pad16(cfg->widths[1]) / 16 > ISK_MAX_NT)
-        return fail(ISK_EUNSUPPORTED, "first hidden width > 160 is not covered by the fused f32 forward kernel yet");
-    for (int l = 2; l <= cfg->n_layers; ++l)
-        if (cfg->widths[l] > 256) return fail(ISK_EUNSUPPORTED, "tail layer width > 256 not covered yet");
+    for (int l = 1; l <= cfg->n_layers; ++l)
+        if (cfg->widths[l] > 4096) return fail(ISK_EUNSUPPORTED, "layer width > 4096");
     int F = cfg->widths[0], Din = F;
     std::vector<int2> pairs;
     if (cfg->featurizer == ISK_FEAT_ALLPAIRS) {
@@ -327,6 +348,22 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     e->L = cfg->n_layers; e->F = F; e->Fp = isk_pad32(F); e->Din = Din; e->nout = nout;
     if (const char* fm = getenv("ISK_FWD_MODE")) e->cfg.forward_mode = atoi(fm);
     if (e->cfg.forward_mode != 0 && e->cfg.forward_mode != 1) { delete e; return fail(ISK_EINVAL, "unknown forward_mode"); }
+    {
+        bool fits = isk_pad16(cfg->widths[1]) / 16 <= ISK_MAX_NT;
+        size_t tailw = 0, tail_train = 0;
+        int sa = isk_pad16(cfg->widths[1]) + 4, sb = 4;
+        for (int l = 1; l < e->L; ++l) {
+            tailw += (size_t)isk_pad16(cfg->widths[l]) * isk_pad16(cfg->widths[l + 1]);
+            tail_train += (size_t)cfg->widths[l] * cfg->widths[l + 1];
+            const int w = isk_pad16(cfg->widths[l + 1]) + 4;
+            if (l + 1 < e->L) { if (l % 2 == 0) sa = std::max(sa, w); else sb = std::max(sb, w); }
+        }
+        for (int l = 0; l < e->L; ++l) tail_train += (size_t)32 * cfg->widths[l + 1];
+        if ((tailw + (size_t)8 * 16 * (sa + sb)) * sizeof(float) > 150 * 1024) fits = false;   // fused forward LDS
+        if (tail_train * sizeof(float) > 150 * 1024) fits = false;                              // train_tail LDS
+        if (getenv("ISK_FORCE_LAYERED")) fits = false;
+        e->layered = !fits;
+    }
     long long off = 0;
     if (cfg->layernorm) { e->off_lns = off; off += F; e->off_lnb = off; off += F; }
     for (int l = 0; l < e->L; ++l) {
@@ -359,7 +396,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     ALLOC(e->d_At, (size_t)nout * nout * sizeof(float)); ALLOC(e->d_rowperm, (size_t)nout * sizeof(int));
     ALLOC(e->d_W16, (size_t)(e->Fp + 32) * isk_pad16(cfg->widths[1]) * 3 * sizeof(uint16_t));
     for (int l = 0; l < e->L; ++l) {
-        ALLOC(e->d_Wt[l], (size_t)(l == 0 ? e->Fp : isk_pad16(cfg->widths[l])) * isk_pad16(cfg->widths[l + 1]) * sizeof(float));
+        ALLOC(e->d_Wt[l], (size_t)layer_kp(e, l) * isk_pad16(cfg->widths[l + 1]) * sizeof(float));
         ALLOC(e->d_bias[l], (size_t)isk_pad16(cfg->widths[l + 1]) * sizeof(float));
     }
     if (!pairs.empty()) {
@@ -372,17 +409,24 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
             (void)hipMemcpy(e->d_packed, pk.data(), pk.size() * sizeof(unsigned), hipMemcpyHostToDevice);
         }
     }
+    // fused kernels keep the whole tail in LDS; anything wider runs layer by layer through HBM
+    if (e->layered) {
+        for (int l = 1; l < e->L; ++l) {
+            ALLOC(e->d_WtT[l], (size_t)isk_pad16(cfg->widths[l]) * isk_pad16(cfg->widths[l + 1]) * sizeof(float));
+        }
+        for (int l = 0; l < e->L; ++l)
+            ALLOC(e->d_W16L[l], (size_t)(layer_kp(e, l) + 32) * isk_pad16(cfg->widths[l + 1]) * 3 * sizeof(uint16_t));
+        ALLOC(e->d_G0, (size_t)F * cfg->widths[1] * sizeof(float));
+        ALLOC(e->d_D0, (size_t)cfg->widths[1] * sizeof(float));
+        ALLOC(e->d_zero, (size_t)4096 * sizeof(float));
+        (void)hipMemset(e->d_zero, 0, (size_t)4096 * sizeof(float));
+    }
 #undef ALLOC
     (void)hipMemset(e->d_theta, 0, pb); (void)hipMemset(e->d_grad, 0, pb * ISK_MAX_SLABS);
     (void)hipMemset(e->d_m, 0, pb); (void)hipMemset(e->d_v, 0, pb);
     (void)hipMemset(e->d_loss_acc, 0, 2 * sizeof(double)); (void)hipMemset(e->d_status, 0, sizeof(int));
     std::vector<float> ones(nout, 1.0f);
     (void)hipMemcpy(e->d_lossw, ones.data(), nout * sizeof(float), hipMemcpyHostToDevice);
-    {
-        const MlpFwdArgs fa = fwd_args(e, nullptr, 0, nullptr);
-        const size_t lds = ((size_t)fa.tailw_floats + (size_t)4 * 16 * (fa.stride_a + fa.stride_b)) * sizeof(float);
-        if (lds > 150 * 1024) { isk_destroy(e); return fail(ISK_EUNSUPPORTED, "tail layers too wide for the LDS-resident fused forward kernel"); }
-    }
     launch_fold(e);
     (void)hipStreamSynchronize(e->stream);
     *out = e;
@@ -400,6 +444,8 @@ extern "C" void isk_destroy(isk_engine* e) {
     free_dev(e->d_At); free_dev(e->d_rowperm); free_dev(e->d_pairs); free_dev(e->d_packed); free_dev(e->d_isa_work_dp);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_Wt[l]); free_dev(e->d_bias[l]); }
     free_dev(e->d_W16);
+    for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_W16L[l]); free_dev(e->d_WtT[l]); }
+    free_dev(e->d_G0); free_dev(e->d_D0); free_dev(e->d_zero);
     drain_timers(e);
     for (auto& ep : e->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (e->ev_fwd_done) (void)hipEventDestroy(e->ev_fwd_done);
@@ -578,6 +624,20 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
     HIPCHK(hipMalloc((void**)&e->d_part, (size_t)isk_train_part_floats(ts, (int)N) * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_perm, (size_t)N * sizeof(int)));
     if (e->cfg.target_kind == ISK_TARGET_ISA) HIPCHK(hipMalloc((void**)&e->d_isa_work, (size_t)isk_isa_work_doubles(N, e->nout) * sizeof(double)));
+    if (e->layered) {
+        int mh = 32;
+        for (int l = 1; l < e->L; ++l) mh = std::max(mh, isk_pad32(e->cfg.widths[l]));
+        HIPCHK(hipMalloc((void**)&e->d_actA, (size_t)S * mh * sizeof(float)));
+        HIPCHK(hipMalloc((void**)&e->d_actB, (size_t)S * mh * sizeof(float)));
+        HIPCHK(hipMemsetAsync(e->d_actA, 0, (size_t)S * mh * sizeof(float), e->stream));
+        HIPCHK(hipMemsetAsync(e->d_actB, 0, (size_t)S * mh * sizeof(float), e->stream));
+        for (int l = 0; l < e->L; ++l) {
+            const size_t nb = (size_t)Bpad * isk_pad16(e->cfg.widths[l + 1]) * sizeof(float);
+            HIPCHK(hipMalloc((void**)&e->d_lz[l], nb));
+            HIPCHK(hipMalloc((void**)&e->d_la[l], nb));
+            HIPCHK(hipMalloc((void**)&e->d_ld[l], nb));
+        }
+    }
     HIPCHK(hipMemcpyAsync(e->d_in_xs, xs, (size_t)N * D * sizeof(float), kind, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_in_ys, ys, (size_t)N * K * D * sizeof(float), kind, e->stream));
     featurize_resident(e);
@@ -685,8 +745,62 @@ extern "C" int isk_chicoords(isk_engine* e, const float* coords, int64_t D, int6
 // ---------------------------------------------------------------------------------------
 // resident forward, koopman, target
 // ---------------------------------------------------------------------------------------
+// layer-by-layer forward: every layer is a sequence of dense-block launches of the same GEMM kernels; hidden
+// activations [S][pad32(H)] ping-pong between actA / actB (zero-initialised: the padding columns stay 0)
+static int forward_layered(isk_engine* e, const float* X, long long S, float* out, float* actA, float* actB) {
+    const float* in = X;
+    int in_ld = e->Fp;
+    for (int l = 0; l < e->L; ++l) {
+        const bool last = (l == e->L - 1);
+        const int N = e->cfg.widths[l + 1];
+        const int nt_total = isk_pad16(N) / 16;
+        float* dst = last ? out : ((l % 2 == 0) ? actA : actB);
+        const int out_ld = last ? e->nout : isk_pad32(N);
+        if (e->cfg.forward_mode == 1 && e->w16_dirty)
+            isk_launch_fold_bf16(e->d_Wt[l], e->d_W16L[l], layer_kp(e, l), nt_total, e->stream);
+        for (int t0 = 0; t0 < nt_total; t0 += 8) {
+            const int ntb = std::min(8, nt_total - t0);
+            MlpFwdArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.X = in; a.S = S; a.Fp = in_ld; a.nchunks = in_ld / 16;
+            a.W1t = e->d_Wt[l]; a.bias1 = e->d_bias[l] + t0 * 16;
+            a.act1 = act_of_layer(e, l); a.H1 = N; a.nt1 = ntb; a.ntail = 0;
+            a.out = dst; a.nout = out_ld;
+            a.dense_mode = 1; a.w_nt_total = nt_total; a.w_tile0 = t0; a.out_ld = out_ld; a.out_col0 = t0 * 16;
+            a.stride_a = ntb * 16 + 4; a.stride_b = 4;
+            int r = ISK_EUNSUPPORTED;
+            if (e->cfg.forward_mode == 1) r = isk_launch_mlp_fwd_bf16x3(a, e->d_W16L[l], e->stream);
+            if (r != 0) r = isk_launch_mlp_fwd(a, e->stream);
+            if (r != 0) return r;
+        }
+        in = dst;
+        in_ld = out_ld;
+    }
+    e->w16_dirty = false;
+    return 0;
+}
+
 // the forward over feature rows: f32 MFMA or split-bf16 (cfg.forward_mode)
 static int launch_forward(isk_engine* e, const MlpFwdArgs& f) {
+    if (e->layered) {
+        float *a = e->d_actA, *b = e->d_actB;
+        TmpBuf ta, tb;
+        const bool resident = (f.X >= e->d_xhat && e->d_xhat && f.X < e->d_xhat + (long long)(e->N * e->K + e->N) * e->Fp) ||
+                              (e->d_xhat_alt && f.X >= e->d_xhat_alt && f.X < e->d_xhat_alt + (long long)(e->N * e->K + e->N) * e->Fp);
+        if (!resident || !a) {
+            int mh = 32;
+            for (int l = 1; l < e->L; ++l) mh = std::max(mh, isk_pad32(e->cfg.widths[l]));
+            if (hipMalloc(&ta.p, (size_t)f.S * mh * sizeof(float)) != hipSuccess || hipMalloc(&tb.p, (size_t)f.S * mh * sizeof(float)) != hipSuccess)
+                return ISK_ENOMEM;
+            (void)hipMemsetAsync(ta.p, 0, (size_t)f.S * mh * sizeof(float), e->stream);
+            (void)hipMemsetAsync(tb.p, 0, (size_t)f.S * mh * sizeof(float), e->stream);
+            a = (float*)ta.p; b = (float*)tb.p;
+            const int r = forward_layered(e, f.X, f.S, f.out, a, b);
+            (void)hipStreamSynchronize(e->stream);     // the temporaries die with this scope
+            return r;
+        }
+        return forward_layered(e, f.X, f.S, f.out, a, b);
+    }
     if (e->cfg.forward_mode == 1) {
         if (e->w16_dirty) {
             isk_launch_fold_bf16(e->d_Wt[0], e->d_W16, e->Fp, f.nt1, e->stream);
@@ -1052,6 +1166,7 @@ extern "C" int isk_chicoords_pullback(isk_engine* e, const float* coords, int64_
     HIPCHK(hipSetDevice(e->cfg.device));
     const bool is_coords = e->cfg.featurizer != ISK_FEAT_IDENTITY;
     if (is_coords && !e->d_packed) return fail(ISK_EUNSUPPORTED, "pullback needs the register featurizer (<= 65535 atoms)");
+    if (e->layered) return fail(ISK_EUNSUPPORTED, "pullback is not implemented for the layered (wide-network) path yet");
     if (e->Fp > 2048 || D > 2048) return fail(ISK_EUNSUPPORTED, "pullback covers <= 2048 features / coordinates per sample");
     const int H1p = isk_pad16(e->cfg.widths[1]);
     const TrainShape ts = train_shape(e);
@@ -1119,7 +1234,42 @@ static int pick_slabs(int B) {
     return s < 1 ? 1 : (s > ISK_MAX_SLABS ? ISK_MAX_SLABS : s);
 }
 
+// layered path: one optimizer step's gradient, layer by layer (see kernels_layered.hip)
+static void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float inv_div) {
+    const int L = e->L;
+    const long long Bpad = ((B + 15) / 16) * 16;
+    const float* xs = e->d_xhat + (long long)e->N * e->K * e->Fp;
+    hipStream_t st = e->stream;
+    for (int l = 0; l < L; ++l) {
+        const int N = e->cfg.widths[l + 1], Np = isk_pad16(N);
+        const float* X = (l == 0) ? xs : e->d_la[l - 1];
+        const int ldx = (l == 0) ? e->Fp : isk_pad16(e->cfg.widths[l]);
+        isk_launch_gemm_rows(X, ldx, e->d_Wt[l], e->d_bias[l], Np / 16, l == 0 ? d_idx : nullptr, B, e->d_lz[l], st);
+        if (l < L - 1) isk_launch_act(e->d_lz[l], e->d_la[l], Bpad, Np, N, act_of_layer(e, l), st);
+    }
+    const int nop = isk_pad16(e->nout);
+    isk_launch_loss_delta(e->d_lz[L - 1], nop, e->d_target, e->d_lossw, d_idx, B, e->nout, inv_div, e->cfg.lastactivation,
+                          e->d_ld[L - 1], nop, e->d_grad + e->nparams, st);
+    for (int l = L - 1; l >= 0; --l) {
+        const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1], Np = isk_pad16(N);
+        const float* X = (l == 0) ? xs : e->d_la[l - 1];
+        const int ldx = (l == 0) ? e->Fp : isk_pad16(K);
+        const bool ln0 = (l == 0 && e->cfg.layernorm);
+        isk_launch_dense_dw(X, ldx, l == 0 ? d_idx : nullptr, e->d_ld[l], Np, B, K, N, ln0 ? e->d_G0 : e->d_grad + e->off_W[l],
+                            e->d_grad + e->off_b[l], st);
+        if (ln0)
+            isk_launch_ln_unfold(e->d_G0, e->d_grad + e->off_b[0], e->d_theta, e->off_W[0], e->off_lns, e->off_lnb, e->F, N, e->d_grad, st);
+        if (l > 0) {
+            // delta_{l-1} = (delta_l W_l) .* act'(z_{l-1});  a_{l-1} is dead after dW_l and receives the raw product
+            isk_launch_gemm_rows(e->d_ld[l], Np, e->d_WtT[l], e->d_zero, isk_pad16(K) / 16, nullptr, B, e->d_la[l - 1], st);
+            isk_launch_dact_mul(e->d_la[l - 1], e->d_lz[l - 1], e->d_ld[l - 1], Bpad, isk_pad16(K), K, act_of_layer(e, l - 1), st);
+        }
+    }
+    e->last_nslab = 1;
+}
+
 static void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nslab = 1) {
+    if (e->layered) { launch_grads_layered(e, d_idx, B, inv_div); return; }
     const TrainShape s = train_shape(e);
     const TrainBuffers b = train_buffers(e);
     isk_launch_train_fwd1(s, b, d_idx, B, e->stream);

@@ -38,7 +38,7 @@ __device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT],
                                           float* scrB, const float* tailw, int lane) {
     const int li = lane & 15, lq = lane >> 4;
     int stride = a.stride_a;
-    const bool fast_sig = (a.act1 == ISK_ACT_SIGMOID) && a.ntail > 0;    // wave-uniform
+    const bool fast_sig = (a.act1 == ISK_ACT_SIGMOID) && a.ntail > 0 && !a.dense_mode;    // wave-uniform
     // accumulator layout (row = 4*lq + r, col = 16*t + li) -> LDS rows; bias (and, on the common
     // sigmoid path, the activation) applied on the way, in registers
     if (fast_sig) {
@@ -65,6 +65,19 @@ __device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT],
     }
     __builtin_amdgcn_wave_barrier();
     const int H1p = NT * 16;
+    if (a.dense_mode) {
+        // one layer of the layered path: every padded column of this block gets act(z) (finite, so the next
+        // layer's zero weight rows annihilate it)
+        for (int row = 0; row < 16; ++row) {
+            const long long grow = row_base + row;
+            if (grow < a.S)
+                for (int col = lane; col < H1p; col += WAVE)
+                    if (a.out_col0 + col < a.out_ld)
+                        a.out[grow * a.out_ld + a.out_col0 + col] = act_apply(a.act1, scrA[row * stride + col]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
     if (a.ntail == 0) {
         for (int row = lq; row < 16; row += 4) {
             const long long grow = row_base + row;

@@ -53,6 +53,9 @@ struct MlpFwdArgs {
     TailLayer tail[ISK_MAX_LAYERS];
     float* out;             // [S][nout]
     int nout;
+    // dense-block mode (layer-by-layer path for networks too wide for the fused kernel): ntail == 0 and the
+    // kernel computes columns [16*w_tile0, 16*(w_tile0+nt1)) of ONE layer, writing act(z) for every padded column
+    int dense_mode, w_nt_total, w_tile0, out_ld, out_col0;
     int tailw_floats;       // total floats of tail weights staged in LDS
     int stride_a, stride_b; // floats per row of the two per-wave LDS ping-pong buffers (padded width + 4)
 };
@@ -61,12 +64,29 @@ int  isk_launch_mlp_fwd(const MlpFwdArgs& a, hipStream_t st);   // returns 0 or 
 int  isk_launch_mlp_fwd_bf16x3(const MlpFwdArgs& a, const void* W16, hipStream_t st);
 void isk_launch_fold_bf16(const float* Wt, void* out, int Kp, int nt, hipStream_t st);
 
+// ---------------------------------------------------------------- layered (wide-network) path ----
+void isk_launch_act(const float* z, float* a, long long rows, int ld, int width, int act, hipStream_t st);
+// delta_L and the batch loss (written to *loss_slot) from the last layer's pre-activations
+void isk_launch_loss_delta(const float* z, int ld, const float* target, const float* lossw, const int* perm, int B, int nout,
+                           float inv_div, int lastact, float* delta, int delta_ld, float* loss_slot, hipStream_t st);
+// G[k][o] = sum_n x[row(n)][k] * delta[n][o] written in Flux layout gW[o + k*N] (or to a temporary for the LayerNorm unfold);
+// db[o] = sum_n delta[n][o]
+void isk_launch_dense_dw(const float* x, int x_ld, const int* perm, const float* delta, int delta_ld, int B, int K, int N,
+                         float* gW, float* gb, hipStream_t st);
+// delta_prev = dz .* act'(z_prev) (dz from the transposed-weight GEMM), zero padded
+void isk_launch_dact_mul(const float* dz, const float* z, float* delta_prev, long long rows, int ld, int width, int act, hipStream_t st);
+// fragment-linear image of W' (for delta_prev = delta * W): WtT[(c*(Kp/16) + t)*64 + lane][j] = W[o = 16c + 4q + j][k = 16t + li]
+void isk_launch_fold_T(const float* theta, long long off_W, int K, int N, float* WtT, hipStream_t st);
+// LayerNorm unfold of layer 0 from the raw G (Flux layout): dW1 = g.*G + beta*D', dg = sum_o W1.*G, dbeta = W1'*D
+void isk_launch_ln_unfold(const float* G, const float* D, const float* theta, long long off_W, long long off_lns, long long off_lnb,
+                          int F, int H1, float* grad, hipStream_t st);
+
 // parameter "fold": flat Flux-order theta -> fragment-linear weights and folded bias
 struct FoldArgs {
     const float* theta;
     int nlayers;
     int widths[ISK_MAX_LAYERS + 1];
-    int Kp0;                              // padded input width of layer 0 (= Fp, a multiple of 32)
+    int Kp[ISK_MAX_LAYERS];               // padded input width per layer (layer 0: Fp; others pad16, or pad32 on the layered path)
     long long off_lns, off_lnb;           // offsets in theta, -1 if no LayerNorm
     long long off_W[ISK_MAX_LAYERS], off_b[ISK_MAX_LAYERS];
     float* Wt[ISK_MAX_LAYERS];            // fragment-linear per layer
@@ -130,6 +150,9 @@ struct TrainBuffers {
 };
 // batch rows are perm[first .. first+B)
 void isk_launch_train_fwd1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, hipStream_t st);
+// out[n][.] (row stride 16*nt) = X[row(n)][0..ldx) * Wt + bias   (train_fwd1_kernel on any layer; ldx multiple of 16)
+void isk_launch_gemm_rows(const float* X, int ldx, const float* Wt, const float* bias, int nt, const int* perm, int B, float* out,
+                          hipStream_t st);
 void isk_launch_train_tail(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div, hipStream_t st);
 // cotangent mode: b.target holds the cotangent [B][nout]; delta_L = cot .* act'(z_L), no loss, no weights
 void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st);

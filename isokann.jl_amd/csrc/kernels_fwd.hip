@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldArgs a) {
     const int layer = blockIdx.y;
     if (layer >= a.nlayers) return;
     const int K = a.widths[layer], N = a.widths[layer + 1];
-    const int Kp = (layer == 0) ? a.Kp0 : ((K + 15) & ~15), Np = (N + 15) & ~15;
+    const int Kp = a.Kp[layer], Np = (N + 15) & ~15;
     const int nt = Np / 16, nchunks = Kp / 16;
     const float* W = a.theta + a.off_W[layer];
     const float* b = a.theta + a.off_b[layer];
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldArgs a) {
 void isk_launch_fold(const FoldArgs& a, hipStream_t st) {
     int bx = 1, maxNp = 16;
     for (int l = 0; l < a.nlayers; ++l) {
-        const int Kp = (l == 0) ? a.Kp0 : isk_pad16(a.widths[l]), Np = isk_pad16(a.widths[l + 1]);
+        const int Kp = a.Kp[l], Np = isk_pad16(a.widths[l + 1]);
         bx = bx > (Kp / 16 + Np / 4) ? bx : (Kp / 16 + Np / 4);
         maxNp = maxNp > Np ? maxNp : Np;
     }
@@ -364,9 +364,9 @@ struct XFrags {
 };
 
 template <int NT>
-__device__ __forceinline__ void load_w(WFrags<NT>& f, const f32x4* __restrict__ Wp, int c) {
+__device__ __forceinline__ void load_w(WFrags<NT>& f, const f32x4* __restrict__ Wp, int c, int nt_total) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) f.w[t] = Wp[(long long)(c * NT + t) * 64];
+    for (int t = 0; t < NT; ++t) f.w[t] = Wp[(long long)(c * nt_total + t) * 64];
 }
 template <bool TWO>
 __device__ __forceinline__ void load_x(XFrags& f, const float* __restrict__ x0, const float* __restrict__ x1, int c) {
@@ -397,7 +397,8 @@ __device__ __forceinline__ void layer1_gemm(const MlpFwdArgs& a, const float* x0
     constexpr int XPF = 5;                        // sample fragments: 5 chunks ahead, ring of 6
     constexpr int WPF = 2;                        // weight fragments: 2 chunks ahead, ring of 3
     constexpr int UNR = 6;                        // lcm(XPF + 1, WPF + 1): ring slots are compile-time
-    const f32x4* Wp = (const f32x4*)a.W1t + lane;
+    const int ntt = a.dense_mode ? a.w_nt_total : NT;
+    const f32x4* Wp = (const f32x4*)a.W1t + (long long)(a.dense_mode ? a.w_tile0 : 0) * 64 + lane;
     const int nch = a.nchunks;
     const int last = nch - 1;
     XFrags xr[XPF + 1];
@@ -405,13 +406,13 @@ __device__ __forceinline__ void layer1_gemm(const MlpFwdArgs& a, const float* x0
 #pragma unroll
     for (int i = 0; i < XPF; ++i) load_x<TWO>(xr[i], x0, x1, i < last ? i : last);
 #pragma unroll
-    for (int i = 0; i < WPF; ++i) load_w<NT>(w[i], Wp, i < last ? i : last);
+    for (int i = 0; i < WPF; ++i) load_w<NT>(w[i], Wp, i < last ? i : last, ntt);
     for (int c = 0; c < nch; c += UNR) {
 #pragma unroll
         for (int s = 0; s < UNR; ++s) {
             const int cc = c + s;
             load_x<TWO>(xr[(s + XPF) % (XPF + 1)], x0, x1, cc + XPF < last ? cc + XPF : last);
-            load_w<NT>(w[(s + WPF) % (WPF + 1)], Wp, cc + WPF < last ? cc + WPF : last);
+            load_w<NT>(w[(s + WPF) % (WPF + 1)], Wp, cc + WPF < last ? cc + WPF : last, ntt);
             __builtin_amdgcn_sched_barrier(0);
             if (cc < nch) mma_frags<NT, TWO>(xr[s % (XPF + 1)], w[s % (WPF + 1)], acc0, acc1);
             __builtin_amdgcn_sched_barrier(0);

@@ -120,15 +120,25 @@ template <int NT, bool TWO, int NTHR>
 __device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __restrict__ W16, uint4* wbuf0, uint4* wbuf1,
                                             const float* x0, const float* x1, int nch, int lane, f32x4 (&acc0)[NT],
                                             f32x4 (&acc1)[NT], bool active) {
-    constexpr int STAGE16 = 3 * NT * 64;                 // 16-byte units per chunk
+    constexpr int STAGE16 = 3 * NT * 64;                 // 16-byte units staged per chunk (this block's tiles)
     constexpr int PER_T = (STAGE16 + NTHR - 1) / NTHR;
     const int tid = threadIdx.x;
     const int last = nch - 1;
+    // global image: [chunk][plane][nt_total tiles][64]; the block stages tiles [tile0, tile0 + NT) of each plane
+    const int ntt = a.dense_mode ? a.w_nt_total : NT;
+    const long long gchunk = (long long)3 * ntt * 64;
+    int goff[PER_T];
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+        const int idx = i * NTHR + tid;
+        const int p = idx / (NT * 64), rem = idx - p * (NT * 64);
+        goff[i] = (p * ntt + (a.dense_mode ? a.w_tile0 : 0)) * 64 + rem;
+    }
     uint4 wreg[PER_T];
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
         const int idx = i * NTHR + tid;
-        wreg[i] = (idx < STAGE16) ? W16[idx] : make_uint4(0, 0, 0, 0);
+        wreg[i] = (idx < STAGE16) ? W16[goff[i]] : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();                                     // the previous pass's epilogue scratch aliases the buffers
 #pragma unroll
@@ -141,7 +151,7 @@ __device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
             const int idx = i * NTHR + tid;
-            wreg[i] = (idx < STAGE16) ? W16[(long long)STAGE16 + idx] : make_uint4(0, 0, 0, 0);
+            wreg[i] = (idx < STAGE16) ? W16[gchunk + goff[i]] : make_uint4(0, 0, 0, 0);
         }
     }
     f32x8 xr0[XDEPTH + 1], xr1[XDEPTH + 1];
@@ -181,7 +191,7 @@ __device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __
 #pragma unroll
                     for (int i = 0; i < PER_T; ++i) {
                         const int idx = i * NTHR + tid;
-                        wreg[i] = (idx < STAGE16) ? W16[(long long)(c + 2) * STAGE16 + idx] : make_uint4(0, 0, 0, 0);
+                        wreg[i] = (idx < STAGE16) ? W16[(long long)(c + 2) * gchunk + goff[i]] : make_uint4(0, 0, 0, 0);
                     }
                 }
             }

@@ -118,6 +118,14 @@ void isk_launch_train_fwd1(const TrainShape& s, const TrainBuffers& b, const int
                        b.bias1, nt1, perm, B, b.a1);
 }
 
+// generic row GEMM on the same kernel: out[n][16*t + j] = sum_k X[row(n)][k] * Wt(k, t) + bias, any layer
+void isk_launch_gemm_rows(const float* X, int ldx, const float* Wt, const float* bias, int nt, const int* perm, int B, float* out,
+                          hipStream_t st) {
+    const int units = (B + 15) / 16;
+    const int upx = (units + 7) / 8;
+    hipLaunchKernelGGL(train_fwd1_kernel, dim3(8 * upx * nt), dim3(FW1_WAVES * 64), 0, st, X, ldx, ldx / 16, Wt, bias, nt, perm, B, out);
+}
+
 // ------------------------------------------------------------------ train_tail -------
 // partial vector layout (per workgroup):
 //   [0] loss, [1 .. 1+H1) unused (D = sum_s delta1[s][.] is rebuilt inside train_grad1), then for

@@ -38,4 +38,7 @@ WORKLOADS = {
     # name: atoms, features ("all" or count), N, K, nout   (BASELINE.json configs[1], configs[2])
     "c2": dict(atoms=22, feat="all", N=1000, K=10, nout=1, label="C2 ADP 22 atoms -> 231 all-pair feats, N=1000, K=10, [231,38,6,1]+LN, shiftscale"),
     "c3": dict(atoms=591, feat=1700, N=10000, K=20, nout=3, label="C3 villin 591 atoms -> 1700 pair feats, N=10000, K=20, [1700,142,12,3]+LN, TransformISA"),
+    # one GPU's shard of BASELINE.json configs[4] (N = 100 000 over 8 GPUs): wide densenet without LayerNorm
+    "c5shard": dict(atoms=304, feat=2000, N=12500, K=32, nout=1, widths=[2000, 512, 512, 512, 1], layernorm=False,
+                    label="C5 shard: Trp-cage 304 atoms -> 2000 pair feats, N=12500 (=100000/8), K=32, densenet [2000,512,512,512,1], shiftscale"),
 }
