@@ -253,6 +253,7 @@ static MlpFwdArgs fwd_args(const isk_engine* e, const float* X, long long S, flo
     }
     a.stride_a = std::max(sa, 4); a.stride_b = std::max(sb, 4);
     a.out = out; a.nout = e->nout;
+    isk_fwd_layout_biases(a);
     return a;
 }
 
@@ -394,7 +395,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     ALLOC(e->d_loss_acc, 2 * sizeof(double)); ALLOC(e->d_status, sizeof(int)); ALLOC(e->d_mm, 2 * sizeof(float));
     ALLOC(e->d_lossw, (size_t)nout * sizeof(float));
     ALLOC(e->d_At, (size_t)nout * nout * sizeof(float)); ALLOC(e->d_rowperm, (size_t)nout * sizeof(int));
-    ALLOC(e->d_W16, (size_t)(e->Fp + 32) * isk_pad16(cfg->widths[1]) * 3 * sizeof(uint16_t));
+    ALLOC(e->d_W16, (size_t)isk_bf16_chunks(e->Fp) * 32 * isk_pad16(cfg->widths[1]) * 3 * sizeof(uint16_t));
     for (int l = 0; l < e->L; ++l) {
         ALLOC(e->d_Wt[l], (size_t)layer_kp(e, l) * isk_pad16(cfg->widths[l + 1]) * sizeof(float));
         ALLOC(e->d_bias[l], (size_t)isk_pad16(cfg->widths[l + 1]) * sizeof(float));
@@ -415,7 +416,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
             ALLOC(e->d_WtT[l], (size_t)isk_pad16(cfg->widths[l]) * isk_pad16(cfg->widths[l + 1]) * sizeof(float));
         }
         for (int l = 0; l < e->L; ++l)
-            ALLOC(e->d_W16L[l], (size_t)(layer_kp(e, l) + 32) * isk_pad16(cfg->widths[l + 1]) * 3 * sizeof(uint16_t));
+            ALLOC(e->d_W16L[l], (size_t)isk_bf16_chunks(layer_kp(e, l)) * 32 * isk_pad16(cfg->widths[l + 1]) * 3 * sizeof(uint16_t));
         ALLOC(e->d_G0, (size_t)F * cfg->widths[1] * sizeof(float));
         ALLOC(e->d_D0, (size_t)cfg->widths[1] * sizeof(float));
         ALLOC(e->d_zero, (size_t)4096 * sizeof(float));
@@ -768,6 +769,7 @@ static int forward_layered(isk_engine* e, const float* X, long long S, float* ou
             a.out = dst; a.nout = out_ld;
             a.dense_mode = 1; a.w_nt_total = nt_total; a.w_tile0 = t0; a.out_ld = out_ld; a.out_col0 = t0 * 16;
             a.stride_a = ntb * 16 + 4; a.stride_b = 4;
+            isk_fwd_layout_biases(a);
             int r = ISK_EUNSUPPORTED;
             if (e->cfg.forward_mode == 1) r = isk_launch_mlp_fwd_bf16x3(a, e->d_W16L[l], e->stream);
             if (r != 0) r = isk_launch_mlp_fwd(a, e->stream);
@@ -832,7 +834,48 @@ static int forward_resident(isk_engine* e, int which, bool ahead = false) {
     {
         ScopedTimer t(e, tid);
         MlpFwdArgs f = fwd_args(e, X, S, out);
+        // diagnostic only (ISK_DEBUG_STAMPS=1 with a -DISK_STAMP build of the bf16x3 kernel): phase cycle sums
+        static const bool stamps = getenv("ISK_DEBUG_STAMPS") != nullptr;
+        static unsigned long long* dbg_st = nullptr;
+        if (stamps) {
+            if (!dbg_st) (void)hipMalloc((void**)&dbg_st, (size_t)4096 * 12 * 8);
+            (void)hipMemsetAsync(dbg_st, 0, (size_t)4096 * 12 * 8, e->stream);
+            f.dbg = dbg_st;
+        }
+        // diagnostic only (ISK_DEBUG_ROWMOD=m): every row reads row (r mod m), i.e. a cache-resident sample stream
+        static const long long rowmod = [] { const char* v = getenv("ISK_DEBUG_ROWMOD"); return v ? atoll(v) : 0LL; }();
+        static int* dbg_rows = nullptr;
+        if (rowmod > 0) {
+            if (!dbg_rows) {
+                std::vector<int> h(S);
+                for (long long i = 0; i < S; ++i) h[i] = (int)(i % rowmod);
+                (void)hipMalloc((void**)&dbg_rows, (size_t)S * sizeof(int));
+                (void)hipMemcpy(dbg_rows, h.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice);
+            }
+            f.rows = dbg_rows;
+        }
         if (launch_forward(e, f) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
+        if (stamps) {
+            (void)hipStreamSynchronize(e->stream);
+            std::vector<unsigned long long> h((size_t)4096 * 12);
+            (void)hipMemcpy(h.data(), dbg_st, h.size() * 8, hipMemcpyDeviceToHost);
+            double sum[10] = {0}; int nw = 0;
+            for (int w = 0; w < 4096; ++w) {
+                if (!h[(size_t)w * 12 + 8]) continue;
+                ++nw;
+                for (int k = 0; k < 10; ++k) sum[k] += (double)h[(size_t)w * 12 + k];
+            }
+            if (nw) {
+                fprintf(stderr, "[stamps] waves %d  total cyc %.0f  realtime(100MHz ticks) %.0f -> clock %.2f GHz\n", nw, sum[8] / nw, sum[9] / nw,
+                        sum[8] / sum[9] * 0.1);
+                const char* pipe_env = getenv("ISK_BF16_PIPE");
+                const bool oldk = pipe_env && atoi(pipe_env) == 0;
+                const char* nm_old[8] = {"xload-issue", "split(+x wait)", "mfma+ldsread", "w ds_write(+w wait)", "barrier", "w load issue", "pass tail", "epilogue"};
+                const char* nm_new[8] = {"pass prologue", "stage: up to barrier", "barrier", "stage: after barrier", "end-of-pass barrier", "epilogue", "-", "-"};
+                const char* const* nm = oldk ? nm_old : nm_new;
+                for (int k = 0; k < 8; ++k) fprintf(stderr, "[stamps]   %-20s %6.1f %%\n", nm[k], 100.0 * sum[k] / sum[8]);
+            }
+        }
     }
     if (ahead) featurize_ys_ahead(e);
     return ISK_OK;

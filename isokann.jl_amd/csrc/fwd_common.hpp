@@ -45,7 +45,7 @@ __device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT],
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int col = t * 16 + li;
-            const float bcol = a.bias1[col];
+            const float bcol = tailw[a.bias_lds0 + col];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float z = acc[t][r] + bcol;
@@ -58,7 +58,7 @@ __device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT],
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int col = t * 16 + li;
-            const float bcol = a.bias1[col];
+            const float bcol = tailw[a.bias_lds0 + col];
 #pragma unroll
             for (int r = 0; r < 4; ++r) scrA[(lq * 4 + r) * stride + col] = acc[t][r] + bcol;
         }
@@ -100,20 +100,35 @@ __device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT],
     float* in = scrA;
     float* ob = scrB;
     int ostride = a.stride_b;
+    int boff = a.bias_lds0 + NT * 16;
     for (int l = 0; l < a.ntail; ++l) {
         const TailLayer L = a.tail[l];
         const bool last = (l == a.ntail - 1);
         const f32x4* Wp = (const f32x4*)(tailw + L.lds_off) + lane;     // staged once per workgroup
         for (int t2 = 0; t2 < L.ntiles; ++t2) {
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            for (int c = 0; c < L.kchunks; ++c) {
+            // two independent accumulation chains (even / odd k-chunks) hide the MFMA and LDS latency
+            f32x4 z = {0.f, 0.f, 0.f, 0.f}, zb = {0.f, 0.f, 0.f, 0.f};
+            int c = 0;
+            for (; c + 1 < L.kchunks; c += 2) {
+                const f32x4 xa = *(const f32x4*)(in + li * stride + c * 16 + lq * 4);
+                const f32x4 wf = Wp[(long long)(c * L.ntiles + t2) * 64];
+                const f32x4 xb = *(const f32x4*)(in + li * stride + (c + 1) * 16 + lq * 4);
+                const f32x4 wg = Wp[(long long)((c + 1) * L.ntiles + t2) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    z = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], wf[j], z, 0, 0, 0);
+                    zb = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[j], wg[j], zb, 0, 0, 0);
+                }
+            }
+            if (c < L.kchunks) {
                 const f32x4 xa = *(const f32x4*)(in + li * stride + c * 16 + lq * 4);
                 const f32x4 wf = Wp[(long long)(c * L.ntiles + t2) * 64];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) z = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], wf[j], z, 0, 0, 0);
             }
+            z += zb;
             const int col = t2 * 16 + li;
-            const float bcol = L.bias[col];
+            const float bcol = tailw[boff + col];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = act_apply(L.act, z[r] + bcol);
@@ -128,6 +143,7 @@ __device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT],
         __builtin_amdgcn_wave_barrier();
         float* tmp = in; in = ob; ob = tmp;
         const int ts = stride; stride = ostride; ostride = ts;
+        boff += L.ntiles * 16;
     }
 }
 
@@ -139,5 +155,14 @@ __device__ __forceinline__ void stage_tail_weights(const MlpFwdArgs& a, float* s
         const f32x4* src = (const f32x4*)a.tail[l].Wt;
         f32x4* dst = (f32x4*)(smem + a.tail[l].lds_off);
         for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+    }
+    // bias block: [bias1][tail biases...]
+    float* bl = smem + a.bias_lds0;
+    for (int i = threadIdx.x; i < a.nt1 * 16; i += blockDim.x) bl[i] = a.bias1[i];
+    int off = a.nt1 * 16;
+    for (int l = 0; l < a.ntail; ++l) {
+        const int n = a.tail[l].ntiles * 16;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) bl[off + i] = a.tail[l].bias[i];
+        off += n;
     }
 }

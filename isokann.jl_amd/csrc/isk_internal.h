@@ -56,13 +56,23 @@ struct MlpFwdArgs {
     // dense-block mode (layer-by-layer path for networks too wide for the fused kernel): ntail == 0 and the
     // kernel computes columns [16*w_tile0, 16*(w_tile0+nt1)) of ONE layer, writing act(z) for every padded column
     int dense_mode, w_nt_total, w_tile0, out_ld, out_col0;
-    int tailw_floats;       // total floats of tail weights staged in LDS
+    int tailw_floats;       // total floats staged in LDS per workgroup: tail weights, then the bias block
+    int bias_lds0;          // float offset of the bias block: [bias1: nt1*16][tail 0 bias: ntiles*16]...
     int stride_a, stride_b; // floats per row of the two per-wave LDS ping-pong buffers (padded width + 4)
+    unsigned long long* dbg;   // diagnostic builds only (-DISK_STAMP): per-wave phase cycle sums, else nullptr
 };
+// append the bias block to the LDS image (call once nt1 / ntail / tail[] / tailw_floats are final)
+static inline void isk_fwd_layout_biases(MlpFwdArgs& a) {
+    a.bias_lds0 = a.tailw_floats;
+    int n = a.nt1 * 16;
+    for (int l = 0; l < a.ntail; ++l) n += a.tail[l].ntiles * 16;
+    a.tailw_floats += n;
+}
 int  isk_launch_mlp_fwd(const MlpFwdArgs& a, hipStream_t st);   // returns 0 or ISK_EUNSUPPORTED
 // split-bf16 variant: W16 = three bf16 planes of the layer-1 weights from isk_launch_fold_bf16
 int  isk_launch_mlp_fwd_bf16x3(const MlpFwdArgs& a, const void* W16, hipStream_t st);
 void isk_launch_fold_bf16(const float* Wt, void* out, int Kp, int nt, hipStream_t st);
+int  isk_bf16_chunks(int Kp);     // 32-feature chunks in the plane image (padded to the kernel's ring size)
 
 // ---------------------------------------------------------------- layered (wide-network) path ----
 void isk_launch_act(const float* z, float* a, long long rows, int ld, int width, int act, hipStream_t st);

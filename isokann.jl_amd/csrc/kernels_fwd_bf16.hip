@@ -75,8 +75,11 @@ __global__ __launch_bounds__(256) void fold_bf16_kernel(const float* __restrict_
     }
 }
 
+// chunks in the plane image: padded with zero planes (the pipelined kernel runs an even number of stages)
+int isk_bf16_chunks(int Kp) { return ((Kp + 31) / 32 + 5) / 6 * 6; }
+
 void isk_launch_fold_bf16(const float* Wt, void* out, int Kp, int nt, hipStream_t st) {
-    const int nchunk32 = (Kp + 31) / 32, nchunk16 = Kp / 16;
+    const int nchunk32 = isk_bf16_chunks(Kp), nchunk16 = Kp / 16;
     long long total = (long long)nchunk32 * nt * 64 * 8;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -115,11 +118,30 @@ __device__ __forceinline__ void mma6(const Planes& x0, const Planes& x1, const b
 #ifndef XDEPTH
 #define XDEPTH 3
 #endif
+#if ISK_ABLATE == 5
+#define XCH 512          // ablation: pretend the samples are stored fragment-linear per (unit, chunk)
+#else
+#define XCH 32
+#endif
+
+#ifndef ISK_STAMP
+#define ISK_STAMP 0
+#endif
+#if ISK_STAMP
+#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
+                      g_ph[k] += tn_ - g_t; g_t = tn_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
 template <int NT, bool TWO, int NTHR>
 __device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __restrict__ W16, uint4* wbuf0, uint4* wbuf1,
                                             const float* x0, const float* x1, int nch, int lane, f32x4 (&acc0)[NT],
-                                            f32x4 (&acc1)[NT], bool active) {
+                                            f32x4 (&acc1)[NT], bool active
+#if ISK_STAMP
+                                            , unsigned long long (&g_ph)[8], unsigned long long& g_t
+#endif
+                                            ) {
     constexpr int STAGE16 = 3 * NT * 64;                 // 16-byte units staged per chunk (this block's tiles)
     constexpr int PER_T = (STAGE16 + NTHR - 1) / NTHR;
     const int tid = threadIdx.x;
@@ -158,27 +180,31 @@ __device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __
 #pragma unroll
     for (int i = 0; i < XDEPTH; ++i) {
         const int ci = i < last ? i : last;
-        xr0[i] = *(const f32x8*)(x0 + ci * 32);
-        if (TWO) xr1[i] = *(const f32x8*)(x1 + ci * 32);
+        xr0[i] = *(const f32x8*)(x0 + ci * XCH);
+        if (TWO) xr1[i] = *(const f32x8*)(x1 + ci * XCH);
     }
     for (int c0 = 0; c0 < nch; c0 += XDEPTH + 1) {
 #pragma unroll
         for (int s = 0; s <= XDEPTH; ++s) {
             const int c = c0 + s;
             if (c < nch) {                                            // workgroup-uniform
+                STAMP(5);
                 {
                     const int cp = c + XDEPTH < last ? c + XDEPTH : last;
-                    xr0[(s + XDEPTH) % (XDEPTH + 1)] = *(const f32x8*)(x0 + cp * 32);
-                    if (TWO) xr1[(s + XDEPTH) % (XDEPTH + 1)] = *(const f32x8*)(x1 + cp * 32);
+                    xr0[(s + XDEPTH) % (XDEPTH + 1)] = *(const f32x8*)(x0 + cp * XCH);
+                    if (TWO) xr1[(s + XDEPTH) % (XDEPTH + 1)] = *(const f32x8*)(x1 + cp * XCH);
                 }
                 const uint4* cur = (c & 1) ? wbuf1 : wbuf0;
                 uint4* nxt = (c & 1) ? wbuf0 : wbuf1;
+                STAMP(0);
                 if (active) {
                     const Planes p0 = split3(xr0[s]);
                     Planes p1 = p0;
                     if (TWO) p1 = split3(xr1[s]);
+                    STAMP(1);
                     mma6<NT, TWO>(p0, p1, (const bf16x8*)cur, lane, acc0, acc1);
                 }
+                STAMP(2);
                 if (c + 1 < nch) {
 #pragma unroll
                     for (int i = 0; i < PER_T; ++i) {
@@ -186,7 +212,9 @@ __device__ __forceinline__ void layer1_pass(const MlpFwdArgs& a, const uint4* __
                         if (idx < STAGE16) nxt[idx] = wreg[i];
                     }
                 }
+                STAMP(3);
                 __syncthreads();
+                STAMP(4);
                 if (c + 2 < nch) {
 #pragma unroll
                     for (int i = 0; i < PER_T; ++i) {
@@ -220,6 +248,10 @@ __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3_kernel(MlpFwdArgs a, 
     long long uend = ustart + units_per_wave;
     if (uend > units) uend = units;
     const long long npass = (units_per_wave + 1) / 2;              // identical for every wave: barriers inside
+#if ISK_STAMP
+    unsigned long long g_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g_t = 0;
+    const unsigned long long g_t0 = __builtin_amdgcn_s_memtime(), g_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (long long p = 0; p < npass; ++p) {
         const long long u = ustart + 2 * p;
         const bool active = u < uend;                              // wave-uniform
@@ -229,16 +261,38 @@ __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3_kernel(MlpFwdArgs a, 
         if (r1 > a.S - 1) r1 = a.S - 1;
         if (r0 < 0) r0 = 0;
         if (a.rows) { r0 = a.rows[r0]; r1 = a.rows[r1]; }
+#if ISK_ABLATE == 5
+        long long ub = u < units - 2 ? u : units - 2; if (ub < 0) ub = 0;
+        const float* x0 = a.X + ub * 16 * (long long)a.Fp + lane * 8;
+        const float* x1 = x0 + 16 * (long long)a.Fp;
+#else
         const float* x0 = a.X + r0 * (long long)a.Fp + lq * 8;
         const float* x1 = a.X + r1 * (long long)a.Fp + lq * 8;
+#endif
         f32x4 acc0[NT], acc1[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) { acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#if ISK_STAMP
+        g_t = __builtin_amdgcn_s_memtime();
+        if (two) layer1_pass<NT, true, NWV * 64>(a, W16, wbuf0, wbuf1, x0, x1, nch, lane, acc0, acc1, active, g_ph, g_t);
+        else layer1_pass<NT, false, NWV * 64>(a, W16, wbuf0, wbuf1, x0, x1, nch, lane, acc0, acc1, active, g_ph, g_t);
+        STAMP(6);
+#else
         if (two) layer1_pass<NT, true, NWV * 64>(a, W16, wbuf0, wbuf1, x0, x1, nch, lane, acc0, acc1, active);
         else layer1_pass<NT, false, NWV * 64>(a, W16, wbuf0, wbuf1, x0, x1, nch, lane, acc0, acc1, active);
+#endif
         if (active) unit_tail<NT>(a, acc0, u * 16, scrA, scrB, smem, lane);
         if (two) unit_tail<NT>(a, acc1, (u + 1) * 16, scrA, scrB, smem, lane);
+        STAMP(7);
     }
+#if ISK_STAMP
+    if (a.dbg && lane == 0) {
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* d = a.dbg + ((long long)blockIdx.x * NWV + wave) * 12;
+        for (int k = 0; k < 8; ++k) d[k] = g_ph[k];
+        d[8] = __builtin_amdgcn_s_memtime() - g_t0; d[9] = rt1 - g_rt0;
+    }
+#endif
 }
 
 template <int NT, int NWV>
@@ -272,10 +326,329 @@ static int launch_bf16_nt(const MlpFwdArgs& a, const void* W16, hipStream_t st) 
     return ISK_EUNSUPPORTED;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Software-pipelined variant (default).  In-kernel cycle stamps of the kernel above (diagnostic build,
+// -DISK_STAMP) showed where a wave's time goes: 35 % issuing MFMAs, 24 % blocked ISSUING the eight global
+// loads every wave fires at once right after the barrier (the CU's vector-memory front end drains 64 B/clk),
+// 15 % in the barrier, 13 % converting samples to planes before the first MFMA of a stage.  Both waves of a
+// SIMD are phase-locked by the barrier, so none of that hides behind the other wave's MFMAs.  Here a stage is
+// scheduled by hand, tile by tile (one tile = 16 outputs = 6 MFMAs per unit):
+//   * the sample loads of chunk c+2, the LDS writes of weight chunk c+1, the global loads of weight chunk
+//     c+2 and the f32 -> 3 x bf16 conversion of sample chunk c+1 are spread over the tiles of stage c, one or
+//     two per tile, pinned with sched_barrier so the compiler cannot cluster them again;
+//   * weight fragments are double-buffered in registers one tile ahead;
+//   * the loop body is branch-free (vector-memory loads retire in order; with conditional loads in the body
+//     hipcc falls back to s_waitcnt vmcnt(0) at the loop header): the chunk count is padded to an even number
+//     (zero weight planes; sample loads clamped to the last real chunk), staging loads are clamped instead
+//     of predicated and the clamped duplicates land in an LDS pad.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT, int U, int NTHR>
+struct PipeGeom {
+    static constexpr int STAGE16 = 3 * NT * 64;                         // 16-byte units staged per chunk
+    static constexpr int PER_T = (STAGE16 + NTHR - 1) / NTHR;
+    static constexpr int SLOTS = PER_T * NTHR;                          // LDS slots per buffer (>= STAGE16)
+    static constexpr int NX = 2 * U;                                    // 16-byte sample loads / half-unit splits per chunk
+    static constexpr int H = NT / 2;
+    static constexpr int clampt(int t) { return t < NT ? t : NT - 1; }
+    static constexpr int tile_x(int i) { return clampt((i * NT) / (2 * NX)); }                         // first half
+    static constexpr int tile_dw(int i) { return clampt(((i + 1) * NT) / (2 * (PER_T + 1))); }          // first half
+    static constexpr int tile_wl(int i) { return clampt(H + (i * (NT - H)) / PER_T); }                  // second half
+    static constexpr int tile_sp(int i) { return clampt(H + ((i + 1) * (NT - H)) / (NX + 1)); }         // second half
+};
+
+// half h (4 features) of a sample fragment -> the three plane halves
+template <int HALF>
+__device__ __forceinline__ void split_half(Planes& d, const f32x4v v) {
+    const bf16x4 a0 = __builtin_convertvector(v, bf16x4);
+    const f32x4v r1 = v - __builtin_convertvector(a0, f32x4v);
+    const bf16x4 a1 = __builtin_convertvector(r1, bf16x4);
+    const f32x4v r2 = r1 - __builtin_convertvector(a1, f32x4v);
+    const bf16x4 a2 = __builtin_convertvector(r2, bf16x4);
+    if (HALF == 0) {
+        d.p0 = __builtin_shufflevector(a0, __builtin_shufflevector(d.p0, d.p0, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7);
+        d.p1 = __builtin_shufflevector(a1, __builtin_shufflevector(d.p1, d.p1, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7);
+        d.p2 = __builtin_shufflevector(a2, __builtin_shufflevector(d.p2, d.p2, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7);
+    } else {
+        d.p0 = __builtin_shufflevector(__builtin_shufflevector(d.p0, d.p0, 0, 1, 2, 3), a0, 0, 1, 2, 3, 4, 5, 6, 7);
+        d.p1 = __builtin_shufflevector(__builtin_shufflevector(d.p1, d.p1, 0, 1, 2, 3), a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        d.p2 = __builtin_shufflevector(__builtin_shufflevector(d.p2, d.p2, 0, 1, 2, 3), a2, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+
+template <int NT, int U, int NTHR>
+__device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __restrict__ W16, u32x4* wbuf, const float* const (&xp)[U],
+                                          int nch, int lane, f32x4 (&acc)[U][NT]
+#if ISK_STAMP
+                                          , unsigned long long (&g_ph)[8], unsigned long long& g_t
+#endif
+                                          ) {
+    typedef PipeGeom<NT, U, NTHR> G;
+    constexpr int STAGE16 = G::STAGE16, PER_T = G::PER_T, NX = G::NX, SLOTS = G::SLOTS;
+    constexpr int TBAR = G::tile_dw(PER_T - 1);          // the stage's barrier follows the tile with the last LDS write
+    constexpr bool XPF = TBAR < NT - 1;                  // next stage's first fragments can be fetched before this stage ends
+    const int tid = threadIdx.x;
+    const int last = nch - 1;
+    const int nchp = (nch + 1) & ~1;
+    // global image: [chunk][plane][nt_total tiles][64]; the block stages tiles [tile0, tile0 + NT) of each plane
+    const int ntt = a.dense_mode ? a.w_nt_total : NT;
+    const int gchunk = 3 * ntt * 64;
+    int goff[PER_T];
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+        int idx = i * NTHR + tid;
+        if (idx > STAGE16 - 1) idx = STAGE16 - 1;                     // clamped duplicate, lands in the LDS pad
+        const int p = idx / (NT * 64), rem = idx - p * (NT * 64);
+        goff[i] = (p * ntt + (a.dense_mode ? a.w_tile0 : 0)) * 64 + rem;
+    }
+    u32x4 wreg[PER_T];
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) wreg[i] = W16[goff[i]];
+    f32x4v xr[2][U][2];                                              // [ring slot = chunk & 1][unit][half]
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            xr[0][u][h] = *(const f32x4v*)(xp[u] + 4 * h);
+            xr[1][u][h] = *(const f32x4v*)(xp[u] + (last > 0 ? 32 : 0) + 4 * h);
+        }
+    __syncthreads();                                     // the previous pass's epilogue scratch aliases the buffers
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) wbuf[i * NTHR + tid] = wreg[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) wreg[i] = W16[gchunk + goff[i]];  // nchp >= 2
+    Planes cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        split_half<0>(cur[u], xr[0][u][0]);
+        split_half<1>(cur[u], xr[0][u][1]);
+        nxt[u] = cur[u];
+    }
+    // consume every prologue load here, so the loop is entered with a clean vmcnt state and the waits inside
+    // are the counted ones of the back edge
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" :: "v"(xr[1][u][0]), "v"(xr[1][u][1]));
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) asm volatile("" :: "v"(wreg[i]));
+    // three weight buffers in a ring: stage c reads ring[c % 3] and fills ring[(c + 1) % 3]; ONE barrier per
+    // stage, in the middle (after the last LDS write), so a stage boundary has no barrier and the first
+    // fragments of the next stage are prefetched across it
+    int rdi = 0;                                                     // c % 3
+    bf16x8 wf[2][3];
+    {
+        const bf16x8* wl = (const bf16x8*)wbuf;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wf[0][pl] = wl[(pl * NT) * 64 + lane];
+    }
+    STAMP(0);
+    for (int c0 = 0; c0 < nchp; c0 += 2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int c = c0 + s;
+            const int cx = c + 2 < last ? c + 2 : last;             // sample chunk fetched in this stage -> slot s
+            const int cw = c + 2 < nchp - 1 ? c + 2 : nchp - 1;     // weight chunk fetched in this stage
+            const u32x4* wc = W16 + (long long)cw * gchunk;
+            const int wri = rdi == 2 ? 0 : rdi + 1;
+            const bf16x8* wl = (const bf16x8*)(wbuf + rdi * SLOTS);
+            const bf16x8* wln = (const bf16x8*)(wbuf + wri * SLOTS);
+            u32x4* wr = wbuf + wri * SLOTS;
+            if (!XPF) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wf[(s * NT) & 1][pl] = wl[(pl * NT) * 64 + lane];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int fb = (s * NT + t) & 1;
+                if (t + 1 < NT) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) wf[fb ^ 1][pl] = wl[(pl * NT + t + 1) * 64 + lane];
+                } else if (XPF) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) wf[fb ^ 1][pl] = wln[(pl * NT) * 64 + lane];
+                }
+                const bf16x8 w0 = wf[fb][0], w1 = wf[fb][1], w2 = wf[fb][2];
+                // smallest terms first
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p1, w1, acc[u][t], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p2, w0, acc[u][t], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, w2, acc[u][t], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p1, w0, acc[u][t], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, w1, acc[u][t], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, w0, acc[u][t], 0, 0, 0);
+                // ---- this tile's share of the stage's side work
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+                    if (G::tile_x(i) == t) xr[s][i >> 1][i & 1] = *(const f32x4v*)(xp[i >> 1] + cx * 32 + 4 * (i & 1));
+#pragma unroll
+                for (int i = 0; i < PER_T; ++i)
+                    if (G::tile_dw(i) == t) wr[i * NTHR + tid] = wreg[i];
+#pragma unroll
+                for (int i = 0; i < PER_T; ++i)
+                    if (G::tile_wl(i) == t) wreg[i] = wc[goff[i]];
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+                    if (G::tile_sp(i) == t) {
+                        if (i & 1) split_half<1>(nxt[i >> 1], xr[s ^ 1][i >> 1][1]);
+                        else split_half<0>(nxt[i >> 1], xr[s ^ 1][i >> 1][0]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == TBAR) {
+                    STAMP(1);
+                    __syncthreads();
+                    STAMP(2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+            rdi = wri;
+        }
+    }
+    STAMP(3);
+    __syncthreads();                                     // every wave is done reading before the epilogue scratch overwrites the ring
+    STAMP(4);
+}
+
+template <int NT, int U, int NWV>
+__device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __restrict__ W16, float* smem, long long u0, int nact
+#if ISK_STAMP
+                                         , unsigned long long (&g_ph)[8], unsigned long long& g_t
+#endif
+                                         ) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    u32x4* wbuf = (u32x4*)(smem + a.tailw_floats);                  // ring of three chunk buffers
+    // the per-wave epilogue scratch ALIASES the weight buffers: it is only used between the last barrier
+    // of a pass and the first barrier of the next one
+    float* scrA = smem + a.tailw_floats + (size_t)wave * 16 * (a.stride_a + a.stride_b);
+    float* scrB = scrA + 16 * a.stride_a;
+    const float* xp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        long long r = (u0 + u) * 16 + li;
+        if (r > a.S - 1) r = a.S - 1;
+        if (r < 0) r = 0;
+        if (a.rows) r = a.rows[r];
+        xp[u] = a.X + r * (long long)a.Fp + lq * 8;
+    }
+    f32x4 acc[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // a wave without a unit in this pass computes on clamped rows and discards the result
+#if ISK_STAMP
+    pipe_pass<NT, U, NWV * 64>(a, (const u32x4*)W16, wbuf, xp, a.Fp / 32, lane, acc, g_ph, g_t);
+#else
+    pipe_pass<NT, U, NWV * 64>(a, (const u32x4*)W16, wbuf, xp, a.Fp / 32, lane, acc);
+#endif
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (u < nact) unit_tail<NT>(a, acc[u], (u0 + u) * 16, scrA, scrB, smem, lane);
+    STAMP(5);
+}
+
+template <int NT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3p_kernel(MlpFwdArgs a, const uint4* __restrict__ W16, long long units,
+                                                                   long long units_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    stage_tail_weights(a, smem);
+    __syncthreads();
+    const long long gw = (long long)blockIdx.x * NWV + (threadIdx.x >> 6);
+    const long long ustart = gw * units_per_wave;
+    long long uend = ustart + units_per_wave;
+    if (uend > units) uend = units;
+    const long long npass = (units_per_wave + 1) / 2;              // identical for every wave: barriers inside
+#if ISK_STAMP
+    unsigned long long g_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long g_t0 = __builtin_amdgcn_s_memtime(), g_rt0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long g_t = g_t0;
+    for (long long p = 0; p < npass; ++p) {
+        const long long u = ustart + 2 * p;
+        if (u + 1 < uend) pipe_run<NT, 2, NWV>(a, W16, smem, u, 2, g_ph, g_t);
+        else pipe_run<NT, 1, NWV>(a, W16, smem, u, u < uend ? 1 : 0, g_ph, g_t);
+    }
+    if (a.dbg && (threadIdx.x & 63) == 0) {
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* d = a.dbg + gw * 12;
+        for (int k = 0; k < 8; ++k) d[k] = g_ph[k];
+        d[8] = __builtin_amdgcn_s_memtime() - g_t0; d[9] = rt1 - g_rt0;
+    }
+#else
+    for (long long p = 0; p < npass; ++p) {
+        const long long u = ustart + 2 * p;
+        if (u + 1 < uend) pipe_run<NT, 2, NWV>(a, W16, smem, u, 2);                    // wave-uniform
+        else pipe_run<NT, 1, NWV>(a, W16, smem, u, u < uend ? 1 : 0);
+    }
+#endif
+}
+
+template <int NT, int NWV>
+static size_t pipe_lds_bytes(const MlpFwdArgs& a) {
+    const size_t wb = (size_t)3 * PipeGeom<NT, 2, NWV * 64>::SLOTS * 4, scr = (size_t)NWV * 16 * (a.stride_a + a.stride_b);
+    return ((size_t)a.tailw_floats + (wb > scr ? wb : scr)) * sizeof(float);
+}
+
+template <int NT, int NWV>
+static void launch_pipe_nw(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
+    const long long units = (a.S + 15) / 16;
+    const long long waves_max = (long long)ISK_NUM_CU * NWV;
+    long long upw = (units + waves_max - 1) / waves_max;
+    if (upw < 1) upw = 1;
+    const long long nwaves = (units + upw - 1) / upw;
+    const long long blocks = (nwaves + NWV - 1) / NWV;
+    const size_t lds = pipe_lds_bytes<NT, NWV>(a);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16x3p_kernel<NT, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mlp_fwd_bf16x3p_kernel<NT, NWV>), dim3((unsigned)blocks), dim3(NWV * 64), lds, st, a, (const uint4*)W16, units, upw);
+}
+
+template <int NT>
+static int launch_pipe_nt(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
+    const size_t cap = 158 * 1024;
+    if (pipe_lds_bytes<NT, 8>(a) <= cap) { launch_pipe_nw<NT, 8>(a, W16, st); return 0; }
+    if (pipe_lds_bytes<NT, 4>(a) <= cap) { launch_pipe_nw<NT, 4>(a, W16, st); return 0; }
+    return ISK_EUNSUPPORTED;
+}
+
+static int launch_pipe(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
+    switch (a.nt1) {
+#ifndef ISK_DEV_NT9
+        case 1: return launch_pipe_nt<1>(a, W16, st);
+        case 2: return launch_pipe_nt<2>(a, W16, st);
+        case 3: return launch_pipe_nt<3>(a, W16, st);
+        case 4: return launch_pipe_nt<4>(a, W16, st);
+        case 5: return launch_pipe_nt<5>(a, W16, st);
+        case 6: return launch_pipe_nt<6>(a, W16, st);
+        case 7: return launch_pipe_nt<7>(a, W16, st);
+        case 8: return launch_pipe_nt<8>(a, W16, st);
+#endif
+        case 9: return launch_pipe_nt<9>(a, W16, st);
+#ifndef ISK_DEV_NT9
+        case 10: return launch_pipe_nt<10>(a, W16, st);
+#endif
+        default: return ISK_EUNSUPPORTED;
+    }
+}
+
 int isk_launch_mlp_fwd_bf16x3(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
     if (a.S <= 0) return 0;
     if (a.Fp % 32 != 0) return ISK_EUNSUPPORTED;
+    static const int pipe = [] { const char* v = getenv("ISK_BF16_PIPE"); return v ? atoi(v) : 1; }();
+    if (pipe) {
+        const int r = launch_pipe(a, W16, st);
+        if (r != ISK_EUNSUPPORTED) return r;
+    }
     switch (a.nt1) {
+#ifndef ISK_DEV_NT9
         case 1: return launch_bf16_nt<1>(a, W16, st);
         case 2: return launch_bf16_nt<2>(a, W16, st);
         case 3: return launch_bf16_nt<3>(a, W16, st);
@@ -284,8 +657,11 @@ int isk_launch_mlp_fwd_bf16x3(const MlpFwdArgs& a, const void* W16, hipStream_t 
         case 6: return launch_bf16_nt<6>(a, W16, st);
         case 7: return launch_bf16_nt<7>(a, W16, st);
         case 8: return launch_bf16_nt<8>(a, W16, st);
+#endif
         case 9: return launch_bf16_nt<9>(a, W16, st);
+#ifndef ISK_DEV_NT9
         case 10: return launch_bf16_nt<10>(a, W16, st);
+#endif
         default: return ISK_EUNSUPPORTED;
     }
     return 0;
