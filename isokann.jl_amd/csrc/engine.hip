@@ -254,6 +254,8 @@ static MlpFwdArgs fwd_args(const isk_engine* e, const float* X, long long S, flo
     a.stride_a = std::max(sa, 4); a.stride_b = std::max(sb, 4);
     a.out = out; a.nout = e->nout;
     isk_fwd_layout_biases(a);
+    static const int skew = [] { const char* v = getenv("ISK_BF16_SKEW"); return v ? atoi(v) : 1; }();
+    a.sched_skew = skew;
     return a;
 }
 

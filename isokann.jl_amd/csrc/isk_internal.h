@@ -59,6 +59,7 @@ struct MlpFwdArgs {
     int tailw_floats;       // total floats staged in LDS per workgroup: tail weights, then the bias block
     int bias_lds0;          // float offset of the bias block: [bias1: nt1*16][tail 0 bias: ntiles*16]...
     int stride_a, stride_b; // floats per row of the two per-wave LDS ping-pong buffers (padded width + 4)
+    int sched_skew;            // bf16x3 pipelined kernel: second wave of each SIMD converts early (0 = same schedule)
     unsigned long long* dbg;   // diagnostic builds only (-DISK_STAMP): per-wave phase cycle sums, else nullptr
 };
 // append the bias block to the LDS image (call once nt1 / ntail / tail[] / tailw_floats are final)

@@ -17,6 +17,7 @@
 // ahead, split into planes in registers right before use.  Tail layers, bias and activation are the f32
 // code shared with the f32 kernel (fwd_common.hpp).
 #include <cstdlib>
+#include <utility>
 #include "fwd_common.hpp"
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -345,7 +346,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NT, int U, int NTHR>
+template <int NT, int U, int NTHR, bool EARLY = false>
 struct PipeGeom {
     static constexpr int STAGE16 = 3 * NT * 64;                         // 16-byte units staged per chunk
     static constexpr int PER_T = (STAGE16 + NTHR - 1) / NTHR;
@@ -356,7 +357,9 @@ struct PipeGeom {
     static constexpr int tile_x(int i) { return clampt((i * NT) / (2 * NX)); }                         // first half
     static constexpr int tile_dw(int i) { return clampt(((i + 1) * NT) / (2 * (PER_T + 1))); }          // first half
     static constexpr int tile_wl(int i) { return clampt(H + (i * (NT - H)) / PER_T); }                  // second half
-    static constexpr int tile_sp(int i) { return clampt(H + ((i + 1) * (NT - H)) / (NX + 1)); }         // second half
+    // sample conversion: second half of the stage; first half for the SIMD's other wave (EARLY), so that the
+    // two waves' VALU bursts do not coincide and each runs under the other's MFMAs
+    static constexpr int tile_sp(int i) { return EARLY ? clampt(((i + 1) * H) / (NX + 1)) : clampt(H + ((i + 1) * (NT - H)) / (NX + 1)); }
 };
 
 // half h (4 features) of a sample fragment -> the three plane halves
@@ -378,14 +381,19 @@ __device__ __forceinline__ void split_half(Planes& d, const f32x4v v) {
     }
 }
 
-template <int NT, int U, int NTHR>
+template <int... Ts, class F>
+__device__ __forceinline__ void static_for_tiles(std::integer_sequence<int, Ts...>, F&& f) {
+    (f(std::integral_constant<int, Ts>{}), ...);
+}
+
+template <int NT, int U, int NTHR, bool EARLY>
 __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __restrict__ W16, u32x4* wbuf, const float* const (&xp)[U],
                                           int nch, int lane, f32x4 (&acc)[U][NT]
 #if ISK_STAMP
                                           , unsigned long long (&g_ph)[8], unsigned long long& g_t
 #endif
                                           ) {
-    typedef PipeGeom<NT, U, NTHR> G;
+    typedef PipeGeom<NT, U, NTHR, EARLY> G;
     constexpr int STAGE16 = G::STAGE16, PER_T = G::PER_T, NX = G::NX, SLOTS = G::SLOTS;
     constexpr int TBAR = G::tile_dw(PER_T - 1);          // the stage's barrier follows the tile with the last LDS write
     constexpr bool XPF = TBAR < NT - 1;                  // next stage's first fragments can be fetched before this stage ends
@@ -459,8 +467,8 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) wf[(s * NT) & 1][pl] = wl[(pl * NT) * 64 + lane];
             }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            static_for_tiles(std::make_integer_sequence<int, NT>{}, [&](auto tc) __attribute__((always_inline)) {
+                constexpr int t = decltype(tc)::value;
                 const int fb = (s * NT + t) & 1;
                 if (t + 1 < NT) {
 #pragma unroll
@@ -506,7 +514,7 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
                     STAMP(2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            }
+            });
 #pragma unroll
             for (int u = 0; u < U; ++u) cur[u] = nxt[u];
             rdi = wri;
@@ -517,7 +525,7 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
     STAMP(4);
 }
 
-template <int NT, int U, int NWV>
+template <int NT, int U, int NWV, bool EARLY>
 __device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __restrict__ W16, float* smem, long long u0, int nact
 #if ISK_STAMP
                                          , unsigned long long (&g_ph)[8], unsigned long long& g_t
@@ -546,9 +554,9 @@ __device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __res
         for (int t = 0; t < NT; ++t) acc[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // a wave without a unit in this pass computes on clamped rows and discards the result
 #if ISK_STAMP
-    pipe_pass<NT, U, NWV * 64>(a, (const u32x4*)W16, wbuf, xp, a.Fp / 32, lane, acc, g_ph, g_t);
+    pipe_pass<NT, U, NWV * 64, EARLY>(a, (const u32x4*)W16, wbuf, xp, a.Fp / 32, lane, acc, g_ph, g_t);
 #else
-    pipe_pass<NT, U, NWV * 64>(a, (const u32x4*)W16, wbuf, xp, a.Fp / 32, lane, acc);
+    pipe_pass<NT, U, NWV * 64, EARLY>(a, (const u32x4*)W16, wbuf, xp, a.Fp / 32, lane, acc);
 #endif
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -567,14 +575,19 @@ __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3p_kernel(MlpFwdArgs a,
     long long uend = ustart + units_per_wave;
     if (uend > units) uend = units;
     const long long npass = (units_per_wave + 1) / 2;              // identical for every wave: barriers inside
+    // a workgroup's waves go to the SIMDs cyclically, so waves w and w + 4 share one: give them different schedules
+    static_assert(NWV == 4 || NWV == 8, "wave count");
+    const bool early = NWV == 8 && (threadIdx.x >> 8) != 0 && a.sched_skew;
 #if ISK_STAMP
     unsigned long long g_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long g_t0 = __builtin_amdgcn_s_memtime(), g_rt0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long g_t = g_t0;
     for (long long p = 0; p < npass; ++p) {
         const long long u = ustart + 2 * p;
-        if (u + 1 < uend) pipe_run<NT, 2, NWV>(a, W16, smem, u, 2, g_ph, g_t);
-        else pipe_run<NT, 1, NWV>(a, W16, smem, u, u < uend ? 1 : 0, g_ph, g_t);
+        if (u + 1 < uend) {
+            if (early) pipe_run<NT, 2, NWV, true>(a, W16, smem, u, 2, g_ph, g_t);
+            else pipe_run<NT, 2, NWV, false>(a, W16, smem, u, 2, g_ph, g_t);
+        } else pipe_run<NT, 1, NWV, false>(a, W16, smem, u, u < uend ? 1 : 0, g_ph, g_t);
     }
     if (a.dbg && (threadIdx.x & 63) == 0) {
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
@@ -585,8 +598,10 @@ __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3p_kernel(MlpFwdArgs a,
 #else
     for (long long p = 0; p < npass; ++p) {
         const long long u = ustart + 2 * p;
-        if (u + 1 < uend) pipe_run<NT, 2, NWV>(a, W16, smem, u, 2);                    // wave-uniform
-        else pipe_run<NT, 1, NWV>(a, W16, smem, u, u < uend ? 1 : 0);
+        if (u + 1 < uend) {                                                            // wave-uniform
+            if (early) pipe_run<NT, 2, NWV, true>(a, W16, smem, u, 2);
+            else pipe_run<NT, 2, NWV, false>(a, W16, smem, u, 2);
+        } else pipe_run<NT, 1, NWV, false>(a, W16, smem, u, u < uend ? 1 : 0);
     }
 #endif
 }
