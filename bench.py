@@ -216,7 +216,7 @@ def main():
                 exec_flops = (N * K + (N if widths[-1] > 1 else 0)) * (6 * l1 + (ffwd - 2 * widths[0] * widths[1]))
                 ach = exec_flops / (avg * 1e-3) / 1e12
                 roof = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": traffic,
-                        "kernel": f"mlp_fwd_bf16x3_kernel<{nt1},8>", "dtype": "bf16x3 split (3 bf16 planes per f32 operand, f32 accumulate)",
+                        "kernel": f"mlp_fwd_bf16x3p_kernel<{nt1},8>", "dtype": "bf16x3 split (3 bf16 planes per f32 operand, f32 accumulate)",
                         "executed_flops_per_launch": exec_flops,
                         "algorithmic": {"flops_per_launch": fwd_flops, "tflops": alg_tf, "vs_f32_mfma_peak_157.3": alg_tf / 157.3}}
             else:
