@@ -137,6 +137,9 @@ struct isk_engine {
     // training workspace
     float *d_z1 = nullptr, *d_delta1 = nullptr, *d_part = nullptr;
     int* d_perm = nullptr;
+    hipEvent_t ev_perm = nullptr;   // the shuffle order of the coming epoch was uploaded on the side stream (isk_run)
+    double* h_res = nullptr;     // pinned: [loss sum, collapsed flag] + status word read back once per epoch
+    int* h_perm = nullptr;       // pinned staging for the shuffle order: an async copy from pageable memory waits for the stream
     float* d_At = nullptr;
     int* d_rowperm = nullptr;
     double* d_isa_work = nullptr;
@@ -171,6 +174,7 @@ static void free_data(isk_engine* e) {
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_lz[l]); free_dev(e->d_la[l]); free_dev(e->d_ld[l]); e->d_lz[l] = e->d_la[l] = e->d_ld[l] = nullptr; }
     e->d_in_xs = e->d_in_ys = e->d_xhat = e->d_xhat_alt = e->d_out = e->d_ks = e->d_target = e->d_z1 = e->d_delta1 = e->d_part = nullptr;
     e->d_perm = nullptr;
+    if (e->h_perm) { (void)hipHostFree(e->h_perm); e->h_perm = nullptr; }
     e->N = e->K = e->D = 0;
     e->have_target = e->have_ks = false;
 }
@@ -388,10 +392,12 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     e->own_stream = true;
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fwd_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_ys_ready, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_ys_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_perm, hipEventDisableTiming) != hipSuccess) {
         isk_destroy(e);
         return fail(ISK_EHIP, "side stream / event creation failed");
     }
+    if (hipHostMalloc((void**)&e->h_res, 4 * sizeof(double), hipHostMallocDefault) != hipSuccess) { isk_destroy(e); return fail(ISK_ENOMEM, "hipHostMalloc"); }
     const size_t pb = (size_t)(e->nparams + 2) * sizeof(float);
     ALLOC(e->d_theta, pb); ALLOC(e->d_grad, pb * ISK_MAX_SLABS); ALLOC(e->d_m, pb); ALLOC(e->d_v, pb);
     ALLOC(e->d_loss_acc, 2 * sizeof(double)); ALLOC(e->d_status, sizeof(int)); ALLOC(e->d_mm, 2 * sizeof(float));
@@ -453,6 +459,8 @@ extern "C" void isk_destroy(isk_engine* e) {
     for (auto& ep : e->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (e->ev_fwd_done) (void)hipEventDestroy(e->ev_fwd_done);
     if (e->ev_ys_ready) (void)hipEventDestroy(e->ev_ys_ready);
+    if (e->ev_perm) (void)hipEventDestroy(e->ev_perm);
+    if (e->h_res) (void)hipHostFree(e->h_res);
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -626,6 +634,7 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
     const TrainShape ts = train_shape(e);
     HIPCHK(hipMalloc((void**)&e->d_part, (size_t)isk_train_part_floats(ts, (int)N) * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_perm, (size_t)N * sizeof(int)));
+    HIPCHK(hipHostMalloc((void**)&e->h_perm, (size_t)N * sizeof(int), hipHostMallocDefault));
     if (e->cfg.target_kind == ISK_TARGET_ISA) HIPCHK(hipMalloc((void**)&e->d_isa_work, (size_t)isk_isa_work_doubles(N, e->nout) * sizeof(double)));
     if (e->layered) {
         int mh = 32;
@@ -1349,21 +1358,45 @@ static int upload_target(isk_engine* e, const float* target) {
 }
 
 // one epoch on the device-resident target; perm on host or nullptr (engine shuffle)
-static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, double* loss) {
+// isk_run uploads the first epoch's shuffle order on the side stream while the forward runs: a host->device copy
+// in front of the first training kernel costs ~20 us of idle GPU (SDMA latency) on the main stream
+static int stage_perm_ahead(isk_engine* e, const int32_t* perm) {
+    const long long N = e->N;
+    if (perm) {
+        for (long long i = 0; i < N; ++i)
+            if (perm[i] < 0 || perm[i] >= N) return fail(ISK_EINVAL, "permutation entry out of range");
+        std::memcpy(e->h_perm, perm, (size_t)N * sizeof(int));
+    } else {
+        std::vector<int32_t> p(N);
+        shuffle_perm(e, p);
+        std::memcpy(e->h_perm, p.data(), (size_t)N * sizeof(int));
+    }
+    HIPCHK(hipMemcpyAsync(e->d_perm, e->h_perm, (size_t)N * sizeof(int), hipMemcpyHostToDevice, e->side));
+    HIPCHK(hipEventRecord(e->ev_perm, e->side));
+    return ISK_OK;
+}
+
+static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, double* loss, int* status_word = nullptr,
+                       bool perm_staged = false) {
     const long long N = e->N;
     const int mb = minibatch < 0 ? e->cfg.minibatch : minibatch;
     const long long bs = (mb == 0 || N < mb) ? N : mb;          // src/iso.jl:180
     const long long nb = N / bs;                                 // partial=false drops the tail
     std::vector<int32_t> p;
-    if (perm) {
-        for (long long i = 0; i < N; ++i)
-            if (perm[i] < 0 || perm[i] >= N) return fail(ISK_EINVAL, "permutation entry out of range");
+    if (perm_staged) {
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_perm, 0));
     } else {
-        p.resize(N);
-        shuffle_perm(e, p);
-        perm = p.data();
+        if (perm) {
+            for (long long i = 0; i < N; ++i)
+                if (perm[i] < 0 || perm[i] >= N) return fail(ISK_EINVAL, "permutation entry out of range");
+        } else {
+            p.resize(N);
+            shuffle_perm(e, p);
+            perm = p.data();
+        }
+        std::memcpy(e->h_perm, perm, (size_t)N * sizeof(int));      // the previous epoch's copy completed before its final sync
+        HIPCHK(hipMemcpyAsync(e->d_perm, e->h_perm, (size_t)N * sizeof(int), hipMemcpyHostToDevice, e->stream));
     }
-    HIPCHK(hipMemcpyAsync(e->d_perm, perm, (size_t)N * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemsetAsync(e->d_loss_acc, 0, 2 * sizeof(double), e->stream));
     {
         ScopedTimer t(e, ISK_T_TRAIN);
@@ -1372,10 +1405,13 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
             launch_opt(e, 1.0f);
         }
     }
-    double acc[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(acc, e->d_loss_acc, sizeof(acc), hipMemcpyDeviceToHost, e->stream));
+    // one round trip per epoch: loss, collapse flag and (for isk_run) the target's status word, into pinned memory
+    double* acc = e->h_res;
+    HIPCHK(hipMemcpyAsync(acc, e->d_loss_acc, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (status_word) HIPCHK(hipMemcpyAsync(acc + 2, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));                     // also keeps `p` alive until the copy is done
     HIPCHK(hipGetLastError());
+    if (status_word) std::memcpy(status_word, acc + 2, sizeof(int));
     if (acc[1] != 0.0) return fail(ISK_ECOLLAPSED, isk_status_string(ISK_ECOLLAPSED));
     if (loss) *loss = acc[0] / (double)N;                        // src/iso.jl:193
     return ISK_OK;
@@ -1411,6 +1447,7 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
     if (n < 0 || epochs < 0) return fail(ISK_EINVAL, "negative iteration count");
     long long k = 0;
     for (int it = 0; it < n; ++it) {
+        if (epochs > 0) CHK(stage_perm_ahead(e, perms ? perms + k * e->N : nullptr));
         if (e->cfg.featurize_every_iteration) featurize_resident(e);
         // the constant-chi check needs the device status word; it is read together with the loss
         CHK(compute_target(e, false, e->cfg.featurize_every_iteration != 0));
@@ -1422,8 +1459,9 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
         for (int ep = 0; ep < epochs; ++ep) {
             double l = 0;
             const int32_t* p = perms ? perms + k * e->N : nullptr;
-            int r = train_epoch(e, -1, p, &l);
-            {   // the target's DomainError (constant chi / singular simplex) outranks the loss check
+            int st = 0;
+            int r = train_epoch(e, -1, p, &l, &st, ep == 0);
+            if (st) {   // the target's DomainError (constant chi / singular simplex) outranks the loss check
                 const int sr = check_status(e);
                 if (sr != ISK_OK) return sr;
             }
