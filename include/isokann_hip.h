@@ -52,7 +52,10 @@ typedef enum isk_status {
 typedef enum { ISK_ACT_IDENTITY = 0, ISK_ACT_SIGMOID = 1, ISK_ACT_TANH = 2, ISK_ACT_RELU = 3, ISK_ACT_SWISH = 4 } isk_act;
 typedef enum { ISK_FEAT_IDENTITY = 0, ISK_FEAT_ALLPAIRS = 1, ISK_FEAT_PAIRLIST = 2 } isk_featurizer;
 typedef enum { ISK_OPT_ADAM = 0, ISK_OPT_NESTEROV = 1 } isk_opt;
-typedef enum { ISK_TARGET_SHIFTSCALE = 0, ISK_TARGET_ISA = 1 } isk_target_kind;
+/* ISK_TARGET_HOST: the host computes the target from isk_chis / isk_koopman and passes it to isk_train_batch
+ * (the reference's experimental transforms, e.g. TransformPseudoInv src/isotarget.jl:145-179, whose small d x d
+ * LAPACK steps run on the CPU in the reference as well); isk_target / isk_run then return ISK_EINVAL */
+typedef enum { ISK_TARGET_SHIFTSCALE = 0, ISK_TARGET_ISA = 1, ISK_TARGET_HOST = 2 } isk_target_kind;
 /* Flux `normalise` epsilon placement: 0 = (x-mu)/sqrt(var+eps^2) [Flux >= 0.14, default],
  * 1 = (x-mu)/(std+eps) [Flux <= 0.13], 2 = (x-mu)/sqrt(var+eps) [PyTorch] */
 typedef enum { ISK_LN_VAR_EPS2 = 0, ISK_LN_STD_EPS = 1, ISK_LN_VAR_EPS = 2 } isk_ln_mode;

@@ -179,6 +179,56 @@ class TransformISA:
     whitening: bool = False
 
 
+@dataclass
+class TransformPseudoInv:
+    """src/isotarget.jl:145-150 (experimental transform, exercised by test/runtests.jl:59).
+    The d x d steps (pinv, Schur vectors, inverse) run on the host in the reference too (`|> cpu`); here chi and
+    K chi come from the HIP forward (isk_chis / isk_koopman) and the target goes back through isk_train_batch."""
+    normalize: bool = True
+    direct: bool = True
+    eigenvecs: bool = True
+    permute: bool = True
+
+
+def _fixperm_rows(new: np.ndarray, old: np.ndarray) -> np.ndarray:
+    """fixperm (src/isotarget.jl:120-127): the row permutation of `new` closest to `old` in the entrywise 1-norm;
+    ties go to the lexicographically first permutation (Combinatorics.permutations order, argmin)."""
+    import itertools
+    d = new.shape[0]
+    best, bestp = None, None
+    for p in itertools.permutations(range(d)):
+        c = np.abs(new[list(p), :] - old).sum()          # norm(new[p, :] - old, 1), evaluated as the reference does:
+        if best is None or c < best:                       # well separated rows make permutations tie to rounding
+            best, bestp = c, p
+    return new[list(bestp), :]
+
+
+def _pseudoinv_target(t: TransformPseudoInv, chi: np.ndarray, kchi: np.ndarray) -> np.ndarray:
+    """isotarget(::TransformPseudoInv, ...) (src/isotarget.jl:152-179) from chi = model(xs), kchi = E[model(ys)]"""
+    import scipy.linalg                                                     # LAPACK gees, as Julia's schur
+    chi64, k64 = chi.astype(np.float64), kchi.astype(np.float64)
+    d, n = chi64.shape
+    if d < 2:
+        raise ValueError("TransformPseudoInv does not work with one dimensional chi functions")
+    try:
+        kinv = np.linalg.pinv(k64)
+    except np.linalg.LinAlgError as err:
+        raise capi.DomainError(capi.ESINGULAR, "Could not compute the pseudoinverse. The subspace might be singular/collapsed") from err
+    if t.direct:
+        m = chi64 @ kinv
+        z = scipy.linalg.schur(m, output="real")[1] if t.eigenvecs else np.eye(d)
+        target = z @ m @ k64
+    else:
+        m = k64 @ kinv
+        z = scipy.linalg.schur(m, output="real")[1] if t.eigenvecs else np.eye(d)
+        target = z @ np.linalg.inv(m) @ k64
+    if t.normalize:
+        target = target / np.abs(target).sum(axis=1, keepdims=True) * n
+    if t.permute:
+        target = _fixperm_rows(target, chi64)
+    return np.asfortranarray(target.astype(np.float32))
+
+
 # ------------------------------------------------------------------------------- data --
 class SimulationData:
     """SimulationData(xs, ys; featurizer) (src/simulation.jl:100-114): coords = (xs, ys).
@@ -266,6 +316,10 @@ def _make_config(data: SimulationData, model: ModelSpec, opt: OptSpec, target, m
         cfg.isa_whitening = int(target.whitening)
     elif isinstance(target, TransformShiftscale):
         cfg.target_kind = capi.TARGET_SHIFTSCALE
+    elif isinstance(target, TransformPseudoInv):
+        if outputdim(model) < 2:
+            raise ValueError("TransformPseudoInv does not work with one dimensional chi functions")
+        cfg.target_kind = capi.TARGET_HOST
     else:
         raise TypeError(f"unsupported target transform {target!r}")
     cfg.minibatch = int(minibatch)
@@ -392,6 +446,16 @@ def run(iso: Iso, n: int = 1, epochs: int = 1, perms=None, showprogress: bool = 
     p = _perm_array(perms, N)
     if p is not None and p.size != n * epochs * N:
         raise ValueError("need one permutation per (iteration, epoch)")
+    if isinstance(iso.target, TransformPseudoInv):
+        # host-side transform: forward passes and training on the GPU, the d x d algebra here (src/iso.jl:72-94)
+        pr = None if p is None else p.reshape(n, epochs, N)
+        for it in range(n):
+            target = isotarget(iso)
+            for ep in range(epochs):
+                iso.losses.append(train_batch(iso, target, perm=None if pr is None else pr[it, ep]))
+            for logger in iso.loggers:
+                logger(iso=iso)
+        return iso
     if not iso.loggers:
         losses = np.zeros(n * epochs, np.float64)
         capi.check(iso._lib.isk_run(iso._h, n, epochs, capi.ptr_i32(p) if p is not None else None, capi.ptr_f64(losses)))
@@ -411,6 +475,8 @@ def run(iso: Iso, n: int = 1, epochs: int = 1, perms=None, showprogress: bool = 
 
 def isotarget(iso: Iso) -> np.ndarray:
     """isotarget(iso) (src/isotarget.jl:10-12) -> (nout, N)"""
+    if isinstance(iso.target, TransformPseudoInv):
+        return _pseudoinv_target(iso.target, chis(iso), koopman(iso))
     out = np.empty((iso.nout, len(iso.data)), np.float32, order="F")
     capi.check(iso._lib.isk_target(iso._h, capi.ptr_f32(out)))
     return out
@@ -582,7 +648,9 @@ def save(path: str, iso: Iso) -> None:
              opt_m=m, opt_v=v, opt_bt=bt,
              xs=iso.data.coords[0], ys=iso.data.coords[1], featurizer_kind=fk,
              featurizer_arg=np.zeros(0) if fv is None else fv,
-             target_kind=type(t).__name__, target_args=np.asarray([getattr(t, "permute", True), getattr(t, "whitening", False)]),
+             target_kind=type(t).__name__,
+             target_args=np.asarray([getattr(t, "permute", True), getattr(t, "whitening", False), getattr(t, "normalize", True),
+                                     getattr(t, "direct", True), getattr(t, "eigenvecs", True)]),
              minibatch=iso.minibatch, losses=np.asarray(iso.losses, np.float64))
 
 
@@ -597,7 +665,12 @@ def load(path: str, **iso_kwargs) -> Iso:
     h = z["opt_hyper"]
     opt = OptSpec(str(z["opt_kind"]), *[float(x) for x in h])
     tk, ta = str(z["target_kind"]), z["target_args"]
-    target = TransformISA(bool(ta[0]), bool(ta[1])) if tk == "TransformISA" else TransformShiftscale()
+    if tk == "TransformISA":
+        target = TransformISA(bool(ta[0]), bool(ta[1]))
+    elif tk == "TransformPseudoInv":
+        target = TransformPseudoInv(bool(ta[2]), bool(ta[3]), bool(ta[4]), bool(ta[0]))
+    else:
+        target = TransformShiftscale()
     iso = Iso(SimulationData(z["xs"], z["ys"], feat), opt=opt, model=model, target=target, minibatch=int(z["minibatch"]), **iso_kwargs)
     iso.set_opt_state(z["opt_m"], z["opt_v"], z["opt_bt"])
     iso.losses = [float(l) for l in z["losses"]]

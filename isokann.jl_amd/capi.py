@@ -19,7 +19,7 @@ OK, EINVAL, EHIP, ENOMEM, ECONSTANT_CHI, ECOLLAPSED, ESINGULAR, EUNSUPPORTED, ES
 ACT = {"identity": 0, "sigmoid": 1, "tanh": 2, "relu": 3, "swish": 4}
 FEAT_IDENTITY, FEAT_ALLPAIRS, FEAT_PAIRLIST = 0, 1, 2
 OPT = {"adam": 0, "nesterov": 1}
-TARGET_SHIFTSCALE, TARGET_ISA = 0, 1
+TARGET_SHIFTSCALE, TARGET_ISA, TARGET_HOST = 0, 1, 2
 LN_MODE = {"var_eps2": 0, "std_eps": 1, "var_eps": 2}
 T_FEATURIZE, T_FWD_YS, T_FWD_XS, T_TARGET, T_TRAIN, T_COUNT = 0, 1, 2, 3, 4, 5
 TIMER_NAMES = ("featurize", "fwd_ys", "fwd_xs", "target", "train")

@@ -316,6 +316,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
         return fail(ISK_EINVAL, "unknown activation");
     if (cfg->opt_kind != ISK_OPT_ADAM && cfg->opt_kind != ISK_OPT_NESTEROV) return fail(ISK_EINVAL, "unknown optimizer");
     const int nout = cfg->widths[cfg->n_layers];
+    if (cfg->target_kind < ISK_TARGET_SHIFTSCALE || cfg->target_kind > ISK_TARGET_HOST) return fail(ISK_EINVAL, "unknown target kind");
     if (cfg->target_kind == ISK_TARGET_SHIFTSCALE && nout != 1)
         return fail(ISK_EINVAL, "TransformShiftscale only works with one dimensional chi functions");
     if (cfg->target_kind == ISK_TARGET_ISA && nout < 2)
@@ -1123,6 +1124,8 @@ static int check_status(isk_engine* e) {
 // computes the target on the device-resident data; leaves target + loss weights on the device
 static int compute_target(isk_engine* e, bool check, bool ahead = false) {
     const int d = e->nout;
+    if (e->cfg.target_kind == ISK_TARGET_HOST)
+        return fail(ISK_EINVAL, "host-side target transform: compute it from isk_chis / isk_koopman and pass it to isk_train_batch");
     if (e->cfg.target_kind == ISK_TARGET_SHIFTSCALE) {
         CHK(forward_resident(e, 1, ahead));
         ScopedTimer t(e, ISK_T_TARGET);

@@ -421,6 +421,44 @@ class TransformISA:
     whitening: bool = False
 
 
+@dataclass
+class TransformPseudoInv:
+    """src/isotarget.jl:145-150 (experimental; exercised by test/runtests.jl:59)"""
+    normalize: bool = True
+    direct: bool = True
+    eigenvecs: bool = True
+    permute: bool = True
+
+
+def pseudoinv_target(t: "TransformPseudoInv", chi: np.ndarray, kchi: np.ndarray) -> np.ndarray:
+    """src/isotarget.jl:152-179 from chi = model(xs) and kchi = E[model(ys)], both (d, N).
+    The reference works in the model's Float32 here; the oracle keeps its fp64 convention.
+    `schur(M).vectors` is LAPACK gees' Z (real Schur form) -- scipy.linalg.schur(output="real") calls the same routine."""
+    import scipy.linalg
+    chi = np.asarray(chi, np.float64)
+    kchi = np.asarray(kchi, np.float64)
+    if not chi.shape[0] > 1:
+        raise AssertionError("TransformPseudoInv does not work with one dimensional chi functions")
+    try:
+        kchi_inv = np.linalg.pinv(kchi)                                    # :159-163
+    except np.linalg.LinAlgError as err:
+        raise DomainError("Could not compute the pseudoinverse. The subspace might be singular/collapsed") from err
+    d = chi.shape[0]
+    if t.direct:                                                           # :165-168
+        Kinv = chi @ kchi_inv
+        T = scipy.linalg.schur(Kinv, output="real")[1] if t.eigenvecs else np.eye(d)
+        target = T @ Kinv @ kchi
+    else:                                                                  # :169-173 ("this does not work at all!")
+        K = kchi @ kchi_inv
+        T = scipy.linalg.schur(K, output="real")[1] if t.eigenvecs else np.eye(d)
+        target = T @ np.linalg.inv(K) @ kchi
+    if t.normalize:                                                        # :175  rows ./ L1 norm .* N
+        target = target / np.abs(target).sum(axis=1, keepdims=True) * target.shape[1]
+    if t.permute:                                                          # :176
+        target = fixperm(target, chi)
+    return target
+
+
 def isotarget(target, model: Model, xs: np.ndarray, ys: np.ndarray) -> np.ndarray:
     """src/isotarget.jl:12 dispatching to :34 (1-D) or :100-107 (ISA).
     xs/ys are FEATURES here (the reference passes features(data)/propfeatures(data))."""
@@ -436,6 +474,8 @@ def isotarget(target, model: Model, xs: np.ndarray, ys: np.ndarray) -> np.ndarra
         if target.permute:
             t = fixperm(t, chi)
         return t.astype(xs.dtype)            # T(target): back to the feature eltype
+    if isinstance(target, TransformPseudoInv):
+        return pseudoinv_target(target, model(xs), expectation(model, ys)).astype(xs.dtype)
     raise TypeError(target)
 
 

@@ -581,3 +581,49 @@ def test_wide_networks_layered_path(gpu_pkg, widths, ln, act, fmode):
     np.testing.assert_allclose(iso.losses, oiso.losses, rtol=2e-3 if nout > 1 else 2e-4)
     np.testing.assert_allclose(pkg.chis(iso), O.chis(oiso), atol=1e-4 if nout > 1 else 3e-5)
     iso.close()
+
+
+# --------------------------------------------------------------- TransformPseudoInv ----
+@pytest.mark.parametrize("eigenvecs", [False, True])
+def test_pseudoinv_target_and_run_match_oracle(gpu_pkg, eigenvecs):
+    """isotarget(::TransformPseudoInv) (src/isotarget.jl:152-179): chi and K chi from the HIP forward, the d x d
+    algebra on the host (as in the reference); three run! iterations against the oracle."""
+    pkg = gpu_pkg
+    A, F, N, K, nout = 14, 40, 320, 5, 3
+    data, odata, om = _coords_case(pkg, A, F, N, K, nout, seed=23)
+    # permute only together with eigenvecs: with well separated rows two permutations tie to rounding in fixperm's
+    # L1 cost, so the end-to-end comparison against the oracle's own forward is done without it
+    tr = O.TransformPseudoInv(eigenvecs=eigenvecs, permute=eigenvecs)
+    oiso = O.Iso(odata, om, O.setup(O.AdamRegularized(), om), target=tr, minibatch=0)
+    iso = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(),
+                  target=pkg.TransformPseudoInv(eigenvecs=eigenvecs, permute=eigenvecs), minibatch=0)
+    t_gpu = pkg.isotarget(iso)
+    assert t_gpu.shape == (nout, N)
+    # rows have L1 norm N (src/isotarget.jl:175)
+    np.testing.assert_allclose(np.abs(t_gpu.astype(np.float64)).sum(axis=1), N, rtol=1e-5)
+    # the host algebra against the oracle's on the SAME chi / K chi (LAPACK's Schur vectors are only defined up to
+    # sign, and the sign can flip under the 1e-6 difference between the f32 GPU forward and the fp64 oracle forward)
+    t_same = O.pseudoinv_target(tr, pkg.chis(iso), pkg.koopman(iso))
+    assert np.abs(t_gpu - t_same).max() <= 1e-5 * max(1.0, np.abs(t_same).max())
+    perms = np.stack([np.arange(N)] * 3)
+    if not eigenvecs:
+        t_ref = O.isotarget(tr, om, *odata.features)
+        assert np.abs(t_gpu - t_ref).max() <= 5e-4 * max(1.0, np.abs(t_ref).max())
+        pkg.run(iso, 3, 1, perms=perms)
+        O.run(oiso, 3, 1, perms=list(perms))
+        np.testing.assert_allclose(iso.losses, oiso.losses, rtol=2e-3)
+        assert np.abs(pkg.chis(iso) - O.chis(oiso)).max() <= 2e-4
+    else:
+        pkg.run(iso, 2, 1, perms=perms[:2])
+        assert len(iso.losses) == 2 and np.isfinite(iso.losses).all()
+    with pytest.raises(Exception):      # the engine itself has no device-side version of this transform
+        out = np.empty((nout, N), np.float32, order="F")
+        pkg.capi.check(iso._lib.isk_target(iso._h, pkg.capi.ptr_f32(out)))
+    iso.close()
+
+
+def test_pseudoinv_needs_multidimensional_chi(gpu_pkg):
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 10, 20, 64, 3, 1, seed=5)
+    with pytest.raises(ValueError):
+        pkg.Iso(data, model=_mk_model(pkg, om), target=pkg.TransformPseudoInv(), minibatch=0)
