@@ -16,5 +16,5 @@ from .api import (  # noqa: F401
     coords, densenet, featuredim, features, halfinds, identity, inputdim, isotarget, koopman, outputdim, pairnet,
     pairnet_widths, propcoords, propfeatures, run, train_batch, koopman_coords, chi_kchi, validationloss,
     ValidationLossLogger, koopman_variance, lastcat, mergedata, set_data, save, load, chicoords_pullback, dchidx, data_from_trajectory, data_from_trajectories,
-    WeightedSamples, set_koopman_weights,
+    WeightedSamples, set_koopman_weights, rates,
 )

@@ -598,6 +598,24 @@ def koopman_variance(iso: Iso, ys=None) -> float:
     return float(np.sum((chi - chi.sum(axis=1, keepdims=True) / k) ** 2) / i / n)
 
 
+def rates(iso_or_x, y=None, lagtime: float = 1.0) -> np.ndarray:
+    """rates(iso) / rates(x, y) (src/iso.jl:339-351): the coarse-grained rate matrix Q with K chi = exp(tau Q) chi,
+    log(y / x) (Julia's right division: least squares) divided by the lag time; the 1-D case is extended by 1 - chi.
+    chi and K chi come from the HIP forward; the d x d matrix logarithm runs on the host as in the reference (`cpu`)."""
+    import scipy.linalg
+    if y is None:
+        x, y = chis(iso_or_x), koopman(iso_or_x)
+    else:
+        x = np.asarray(iso_or_x)
+    x = np.asarray(x, np.float64)
+    y = np.asarray(y, np.float64)
+    if x.shape[0] == 1:
+        x = np.concatenate([x, 1 - x], axis=0)
+        y = np.concatenate([y, 1 - y], axis=0)
+    q = np.linalg.lstsq(x.T, y.T, rcond=None)[0].T                      # y / x
+    return scipy.linalg.logm(q) / lagtime
+
+
 # ------------------------------------- checkpoint / data growth (SURVEY 8f rank 3) --
 def lastcat(a, b):
     """lastcat(x, y) (src/data.jl:59-62): concatenate along the last (sample) axis"""

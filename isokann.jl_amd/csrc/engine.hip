@@ -1223,7 +1223,6 @@ extern "C" int isk_chicoords_pullback(isk_engine* e, const float* coords, int64_
     HIPCHK(hipSetDevice(e->cfg.device));
     const bool is_coords = e->cfg.featurizer != ISK_FEAT_IDENTITY;
     if (is_coords && !e->d_packed) return fail(ISK_EUNSUPPORTED, "pullback needs the register featurizer (<= 65535 atoms)");
-    if (e->layered) return fail(ISK_EUNSUPPORTED, "pullback is not implemented for the layered (wide-network) path yet");
     if (e->Fp > 2048 || D > 2048) return fail(ISK_EUNSUPPORTED, "pullback covers <= 2048 features / coordinates per sample");
     const int H1p = isk_pad16(e->cfg.widths[1]);
     const TrainShape ts = train_shape(e);
@@ -1238,7 +1237,7 @@ extern "C" int isk_chicoords_pullback(isk_engine* e, const float* coords, int64_
         HIPCHK(hipMalloc(&st.p, (size_t)n * 2 * sizeof(float)));
         HIPCHK(hipMalloc(&z1.p, (size_t)npad * H1p * sizeof(float)));
         HIPCHK(hipMalloc(&d1.p, (size_t)npad * H1p * sizeof(float)));
-        HIPCHK(hipMalloc(&part.p, (size_t)isk_train_part_floats(ts, (int)n) * sizeof(float)));
+        if (!e->layered) HIPCHK(hipMalloc(&part.p, (size_t)isk_train_part_floats(ts, (int)n) * sizeof(float)));
         HIPCHK(hipMalloc(&ct.p, (size_t)n * e->nout * sizeof(float)));
         HIPCHK(hipMalloc(&gr.p, (size_t)n * D * sizeof(float)));
         HIPCHK(hipMemcpyAsync(in.p, coords + c0 * D, (size_t)n * D * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -1249,13 +1248,43 @@ extern "C" int isk_chicoords_pullback(isk_engine* e, const float* coords, int64_
         a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
         a.raw = (float*)raw.p; a.stats = (float*)st.p;
         isk_launch_featurize(a, e->stream);
-        TrainBuffers tb = train_buffers(e);
-        tb.xhat_xs = (const float*)xh.p; tb.target = (const float*)ct.p; tb.a1 = (float*)z1.p; tb.delta1 = (float*)d1.p;
-        tb.part = (float*)part.p; tb.cot_mode = 1;
-        isk_launch_train_fwd1(ts, tb, nullptr, (int)n, e->stream);
-        isk_launch_train_tail(ts, tb, nullptr, (int)n, 1.0f, e->stream);
+        const float* delta1 = (const float*)d1.p;
+        TmpBuf lz[ISK_MAX_LAYERS], la[ISK_MAX_LAYERS], ldl[ISK_MAX_LAYERS];
+        if (e->layered) {
+            // layer by layer with the row-GEMM kernels: forward, cotangent seed at the last layer, delta back to layer 0
+            const int L = e->L;
+            hipStream_t st = e->stream;
+            for (int l = 0; l < L; ++l) {
+                const size_t w = (size_t)npad * isk_pad16(e->cfg.widths[l + 1]) * sizeof(float);
+                HIPCHK(hipMalloc(&lz[l].p, w));
+                HIPCHK(hipMalloc(&la[l].p, w));
+                HIPCHK(hipMalloc(&ldl[l].p, w));
+            }
+            for (int l = 0; l < L; ++l) {
+                const int N = e->cfg.widths[l + 1], Np = isk_pad16(N);
+                const float* X = (l == 0) ? (const float*)xh.p : (const float*)la[l - 1].p;
+                const int ldx = (l == 0) ? e->Fp : isk_pad16(e->cfg.widths[l]);
+                isk_launch_gemm_rows(X, ldx, e->d_Wt[l], e->d_bias[l], Np / 16, nullptr, (int)n, (float*)lz[l].p, st);
+                if (l < L - 1) isk_launch_act((const float*)lz[l].p, (float*)la[l].p, npad, Np, N, act_of_layer(e, l), st);
+            }
+            const int nop = isk_pad16(e->nout);
+            isk_launch_cot_delta((const float*)lz[L - 1].p, nop, (const float*)ct.p, n, e->nout, e->cfg.lastactivation, (float*)ldl[L - 1].p, nop, st);
+            for (int l = L - 1; l >= 1; --l) {
+                const int K = e->cfg.widths[l], Np = isk_pad16(e->cfg.widths[l + 1]);
+                isk_launch_gemm_rows((const float*)ldl[l].p, Np, e->d_WtT[l], e->d_zero, isk_pad16(K) / 16, nullptr, (int)n, (float*)la[l - 1].p, st);
+                isk_launch_dact_mul((const float*)la[l - 1].p, (const float*)lz[l - 1].p, (float*)ldl[l - 1].p, npad, isk_pad16(K), K,
+                                    act_of_layer(e, l - 1), st);
+            }
+            delta1 = (const float*)ldl[0].p;
+        } else {
+            TrainBuffers tb = train_buffers(e);
+            tb.xhat_xs = (const float*)xh.p; tb.target = (const float*)ct.p; tb.a1 = (float*)z1.p; tb.delta1 = (float*)d1.p;
+            tb.part = (float*)part.p; tb.cot_mode = 1;
+            isk_launch_train_fwd1(ts, tb, nullptr, (int)n, e->stream);
+            isk_launch_train_tail(ts, tb, nullptr, (int)n, 1.0f, e->stream);
+        }
         VjpArgs v = {};
-        v.delta1 = (const float*)d1.p; v.xhat = (const float*)xh.p; v.raw = (const float*)raw.p; v.stats = (const float*)st.p;
+        v.delta1 = delta1; v.xhat = (const float*)xh.p; v.raw = (const float*)raw.p; v.stats = (const float*)st.p;
         v.coords = (const float*)in.p; v.pairs = is_coords ? e->d_pairs : nullptr; v.theta = e->d_theta;
         v.off_W0 = e->off_W[0]; v.off_lns = e->cfg.layernorm ? e->off_lns : -1;
         v.grad = (float*)gr.p; v.S = n; v.D = (int)D; v.F = e->F; v.Fp = e->Fp; v.H1 = e->cfg.widths[1]; v.H1p = H1p;

@@ -80,6 +80,9 @@ void isk_launch_act(const float* z, float* a, long long rows, int ld, int width,
 // delta_L and the batch loss (written to *loss_slot) from the last layer's pre-activations
 void isk_launch_loss_delta(const float* z, int ld, const float* target, const float* lossw, const int* perm, int B, int nout,
                            float inv_div, int lastact, float* delta, int delta_ld, float* loss_slot, hipStream_t st);
+// cotangent seed of the coordinate pullback on the layered path: delta_L = cot .* lastact'(z_L), zero padded rows / columns
+void isk_launch_cot_delta(const float* z, int ld, const float* cot, long long B, int nout, int lastact, float* delta, int delta_ld,
+                          hipStream_t st);
 // G[k][o] = sum_n x[row(n)][k] * delta[n][o] written in Flux layout gW[o + k*N] (or to a temporary for the LayerNorm unfold);
 // db[o] = sum_n delta[n][o]
 void isk_launch_dense_dw(const float* x, int x_ld, const int* perm, const float* delta, int delta_ld, int B, int K, int N,

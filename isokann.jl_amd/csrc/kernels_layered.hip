@@ -103,6 +103,24 @@ void isk_launch_loss_delta(const float* z, int ld, const float* target, const fl
                        delta, delta_ld, loss_slot);
 }
 
+// cotangent seed of the coordinate pullback: delta_L[n][o] = cot[n][o] * lastact'(z_L[n][o]), zero padded
+__global__ __launch_bounds__(256) void cot_delta_kernel(const float* __restrict__ z, int ld, const float* __restrict__ cot, long long B,
+                                                        long long Bpad, int nout, int lastact, float* __restrict__ delta, int delta_ld) {
+    const long long tot = Bpad * delta_ld;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+        const long long n = e / delta_ld;
+        const int o = (int)(e % delta_ld);
+        delta[e] = (n < B && o < nout) ? cot[n * nout + o] * l_dact(lastact, z[n * ld + o]) : 0.f;
+    }
+}
+void isk_launch_cot_delta(const float* z, int ld, const float* cot, long long B, int nout, int lastact, float* delta, int delta_ld,
+                          hipStream_t st) {
+    const long long Bpad = ((B + 15) / 16) * 16;
+    long long blocks = (Bpad * delta_ld + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cot_delta_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, ld, cot, B, Bpad, nout, lastact, delta, delta_ld);
+}
+
 // dW tile: block = (16-feature tile kt, 16-output tile ot), 4 waves split the batch rows, f32 MFMA,
 // LDS combine.  D[k_local][o_local] = sum_n x[n][k] * delta[n][o];  stored gW[o + k*N].
 // Blocks with kt == 0 also produce db[o] = sum_n delta[n][o] from the delta fragments they already hold.

@@ -369,6 +369,10 @@ def test_evaluation_callers(gpu_pkg):
     np.testing.assert_allclose(pkg.koopman_coords(iso, vys), O.expectation(om, oval.features[1]), atol=2e-5)
     assert pkg.validationloss(iso, val) == pytest.approx(O.validationloss(oiso, oval), rel=2e-4, abs=1e-9)
     assert pkg.koopman_variance(iso) == pytest.approx(O.koopman_variance(oiso), rel=1e-3)
+    # rates(iso) (src/iso.jl:339-351): 1-D chi extended by 1 - chi, matrix logarithm of K chi / chi
+    q_ref = O.rates(O.chis(oiso), O.koopman(oiso))
+    np.testing.assert_allclose(pkg.rates(iso), q_ref, atol=2e-3 * max(1.0, np.abs(q_ref).max()))
+    np.testing.assert_allclose(pkg.rates(iso, lagtime=2.0), pkg.rates(iso) / 2.0, rtol=1e-12)
     perms = np.stack([np.arange(120)] * 4)
     pkg.run(iso, 4, 1, perms=perms)
     O.run(oiso, 4, 1, perms=list(perms))
@@ -483,13 +487,12 @@ def _torch_chi_of_coords(om, pairs, x):
     return a
 
 
-@pytest.mark.parametrize("nout,mode,act,pdist", [(1, "var_eps2", "sigmoid", True), (3, "std_eps", "tanh", True),
-                                                   (2, "var_eps2", "swish", False)])
-def test_chicoords_pullback_matches_torch_autograd(gpu_pkg, nout, mode, act, pdist):
+@pytest.mark.parametrize("nout,mode,act,pdist,hidden", [(1, "var_eps2", "sigmoid", True, (11, 5)), (3, "std_eps", "tanh", True, (11, 5)),
+                                                          (2, "var_eps2", "swish", False, (11, 5)),
+                                                          (2, "var_eps2", "sigmoid", True, (176, 20))])     # wide: layered path
+def test_chicoords_pullback_matches_torch_autograd(gpu_pkg, nout, mode, act, pdist, hidden):
     """d chi / d coords through MLP, LayerNorm and pairwise distances"""
     import torch
-    if os.environ.get("ISK_FORCE_LAYERED"):
-        pytest.skip("pullback is not implemented on the layered path")
     pkg = gpu_pkg
     A, F, N = 15, 40, 24
     rng = np.random.default_rng(60 + nout)
@@ -497,12 +500,12 @@ def test_chicoords_pullback_matches_torch_autograd(gpu_pkg, nout, mode, act, pdi
         xs, ys = O.synthetic_coords(A, N, 2, seed=61)
         pairs = O.random_pairs(A, F, seed=62)
         feat = pkg.FeaturesPairs(pairs)
-        widths = [F, 11, 5, nout]
+        widths = [F, *hidden, nout]
     else:
         xs = rng.normal(size=(F, N)) + 1
         ys = rng.normal(size=(F, 2, N)) + 1
         pairs, feat = None, pkg.identity
-        widths = [F, 11, 5, nout]
+        widths = [F, *hidden, nout]
     om = _rand_model(widths, seed=63, act=act)
     om.ln_mode = mode
     tr = pkg.TransformShiftscale() if nout == 1 else pkg.TransformISA()
