@@ -163,9 +163,10 @@ def main():
         local = dp.HipLocal(iso)
         rng = np.random.default_rng(1000 + rank)
         gmb = 0 if args.minibatch == 0 else args.minibatch * world       # fixed per-rank batch
+        counts = dp.shard_counts(local, comm)
 
         def step():
-            iso.losses.extend(dp.dp_run(local, comm, 1, 1, gmb, rng))
+            iso.losses.extend(dp.dp_run(local, comm, 1, 1, gmb, rng, counts=counts))
 
         def sync():
             torch.cuda.synchronize()

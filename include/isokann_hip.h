@@ -224,6 +224,24 @@ int  isk_dp_local_grads(isk_engine* e, int32_t first, int32_t nidx, int64_t glob
 int  isk_dp_apply(isk_engine* e);
 int  isk_dp_epoch_end(isk_engine* e, double* loss_sum);
 
+/* Native collectives: the same data-parallel run! with RCCL called from the engine on its own stream, so an
+ * iteration has no host code between the kernels of a step (run! src/iso.jl:72-94 across ranks; the hooks above
+ * remain for hosts that bring their own collectives, e.g. MPI.jl or a CPU gloo group).
+ *   isk_dp_comm_id(id)                     rank 0: ncclGetUniqueId; the host broadcasts the 128 bytes
+ *   isk_dp_comm_init(e, id, rank, world)   every rank: ncclCommInitRank (librccl.so is loaded on first use)
+ *   isk_dp_run(e, n, epochs, local_batch, nbatches, global_batch, perms, losses)
+ *       per iteration: K-mean forward on the shard; 1-D target: ONE all-reduce(max) of [-min, max];
+ *       ISA: all-gather of the ks / chi slices, every rank runs the Float64 simplex kernels on the gathered arrays;
+ *       per optimizer step: ONE in-place all-reduce(sum) of the flat [gradient slabs | batch loss] buffer.
+ *       Shards must be equal (N the same on every rank).  perms: (n*epochs, N) shuffles of the LOCAL shard, of
+ *       which the first nbatches*local_batch entries are used; losses[k] = sum of the reduced batch losses of
+ *       epoch k (divide by the global N for train_batch!'s return value, src/iso.jl:193).
+ * Without isk_dp_comm_init (or with world == 1) isk_dp_run runs the same code without collectives. */
+int  isk_dp_comm_id(uint8_t id[128]);
+int  isk_dp_comm_init(isk_engine* e, const uint8_t id[128], int32_t rank, int32_t world);
+int  isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t local_batch, int32_t nbatches, int64_t global_batch,
+                const int32_t* perms, double* losses);
+
 /* ---- instrumentation -------------------------------------------------------------- */
 typedef enum { ISK_T_FEATURIZE = 0, ISK_T_FWD_YS = 1, ISK_T_FWD_XS = 2, ISK_T_TARGET = 3,
                ISK_T_TRAIN = 4, ISK_T_COUNT = 5 } isk_timer_id;

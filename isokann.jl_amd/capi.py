@@ -113,6 +113,9 @@ PROTOTYPES = {
     "isk_dp_local_grads": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int64]),
     "isk_dp_apply": (C.c_int, [_H]),
     "isk_dp_epoch_end": (C.c_int, [_H, _f64p]),
+    "isk_dp_comm_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "isk_dp_comm_init": (C.c_int, [_H, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),
+    "isk_dp_run": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _i32p, _f64p]),
     "isk_timers_enable": (C.c_int, [_H, C.c_int32]),
     "isk_timers_read": (C.c_int, [_H, _f64p, _i64p]),
     "isk_timers_reset": (C.c_int, [_H]),

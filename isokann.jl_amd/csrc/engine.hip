@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include "isk_internal.h"
 
 // ---------------------------------------------------------------------------------------
@@ -143,6 +145,12 @@ struct isk_engine {
     float* d_At = nullptr;
     int* d_rowperm = nullptr;
     double* d_isa_work = nullptr;
+    // native data-parallel run (isk_dp_run): RCCL communicator + gathered ks / chi
+    ncclComm_t comm = nullptr;
+    int dp_rank = 0, dp_world = 1;
+    float* d_gks = nullptr;
+    float* d_gchi = nullptr;
+    long long gather_rows = 0;
     double* d_isa_work_dp = nullptr;
     long long isa_work_dp_rows = 0;
     uint64_t rng[4];
@@ -443,6 +451,8 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     return ISK_OK;
 }
 
+static void dp_comm_release(isk_engine* e);
+
 extern "C" void isk_destroy(isk_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
@@ -456,6 +466,8 @@ extern "C" void isk_destroy(isk_engine* e) {
     free_dev(e->d_W16);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_W16L[l]); free_dev(e->d_WtT[l]); }
     free_dev(e->d_G0); free_dev(e->d_D0); free_dev(e->d_zero);
+    dp_comm_release(e);
+    free_dev(e->d_gks); free_dev(e->d_gchi);
     drain_timers(e);
     for (auto& ep : e->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (e->ev_fwd_done) (void)hipEventDestroy(e->ev_fwd_done);
@@ -1676,6 +1688,196 @@ extern "C" int isk_dp_epoch_end(isk_engine* e, double* loss_sum) {
     e->dp_perm_len = 0;
     if (acc[1] != 0.0) return fail(ISK_ECOLLAPSED, isk_status_string(ISK_ECOLLAPSED));
     if (loss_sum) *loss_sum = acc[0];
+    return ISK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// native collectives (RCCL, loaded lazily so the library has no link-time dependency on it)
+// ---------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load() {
+    if (g_rccl.lib) return ISK_OK;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(ISK_EUNSUPPORTED, std::string("cannot load librccl.so: ") + dlerror());
+    RcclApi a;
+    a.lib = h;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+    a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.AllGather || !a.GetErrorString)
+        return fail(ISK_EUNSUPPORTED, "librccl.so lacks a required symbol");
+    g_rccl = a;
+    return ISK_OK;
+}
+}  // namespace
+
+#define RCCLCHK(call)                                                                              \
+    do {                                                                                           \
+        ncclResult_t _r = (call);                                                                  \
+        if (_r != ncclSuccess) return fail(ISK_EHIP, std::string("rccl: ") + g_rccl.GetErrorString(_r)); \
+    } while (0)
+
+static void dp_comm_release(isk_engine* e) {
+    if (e->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(e->stream); (void)g_rccl.CommDestroy(e->comm); }
+    e->comm = nullptr;
+    e->dp_rank = 0; e->dp_world = 1;
+}
+
+extern "C" int isk_dp_comm_id(uint8_t id[128]) {
+    if (!id) return fail(ISK_EINVAL, "null argument");
+    CHK(rccl_load());
+    ncclUniqueId u;
+    RCCLCHK(g_rccl.GetUniqueId(&u));
+    static_assert(sizeof(u) == 128, "ncclUniqueId");
+    std::memcpy(id, &u, 128);
+    return ISK_OK;
+}
+
+extern "C" int isk_dp_comm_init(isk_engine* e, const uint8_t id[128], int32_t rank, int32_t world) {
+    if (!e || !id || world < 1 || rank < 0 || rank >= world) return fail(ISK_EINVAL, "bad communicator arguments");
+    CHK(rccl_load());
+    HIPCHK(hipSetDevice(e->cfg.device));
+    dp_comm_release(e);
+    ncclUniqueId u;
+    std::memcpy(&u, id, 128);
+    RCCLCHK(g_rccl.CommInitRank(&e->comm, world, u, rank));
+    e->dp_rank = rank; e->dp_world = world;
+    return ISK_OK;
+}
+
+// mm[0] <- -mm[0]: with [-min, max] ONE all-reduce(max) yields the global range
+__global__ void negate_first_kernel(float* mm) { if (threadIdx.x == 0 && blockIdx.x == 0) mm[0] = -mm[0]; }
+
+// collectives run when there is more than one rank (ISK_DP_FORCE_COLL=1: also on a single-rank communicator, for tests)
+static bool dp_collectives(const isk_engine* e) {
+    static const bool force = [] { const char* v = getenv("ISK_DP_FORCE_COLL"); return v && atoi(v) != 0; }();
+    return e->comm != nullptr && (e->dp_world > 1 || force);
+}
+
+static int dp_target_native(isk_engine* e) {
+    const int d = e->nout;
+    const bool coll = dp_collectives(e);
+    if (e->cfg.featurize_every_iteration) featurize_resident(e);
+    if (e->cfg.target_kind == ISK_TARGET_SHIFTSCALE) {
+        CHK(forward_resident(e, 1, e->cfg.featurize_every_iteration != 0));
+        ScopedTimer t(e, ISK_T_TARGET);
+        launch_kmean(e);
+        isk_launch_minmax(e->d_ks, e->N, e->d_mm, e->stream);
+        if (coll) {
+            hipLaunchKernelGGL(negate_first_kernel, dim3(1), dim3(64), 0, e->stream, e->d_mm);
+            RCCLCHK(g_rccl.AllReduce(e->d_mm, e->d_mm, 2, ncclFloat, ncclMax, e->comm, e->stream));
+            hipLaunchKernelGGL(negate_first_kernel, dim3(1), dim3(64), 0, e->stream, e->d_mm);
+        }
+        isk_launch_shiftscale(e->d_ks, e->d_mm, e->d_target, e->N, e->d_status, e->stream);   // flags max <= min (also NaN)
+        e->have_target = true;
+        return ISK_OK;
+    }
+    if (e->cfg.target_kind != ISK_TARGET_ISA) return fail(ISK_EINVAL, "host-side target transform: no native data-parallel run");
+    CHK(forward_resident(e, 3, e->cfg.featurize_every_iteration != 0));
+    ScopedTimer t(e, ISK_T_TARGET);
+    launch_kmean(e);
+    const float* ks = e->d_ks;
+    const float* chi = e->d_out + e->N * e->K * d;
+    long long n_global = e->N, first = 0;
+    if (coll) {
+        n_global = e->N * e->dp_world; first = e->N * e->dp_rank;
+        if (e->gather_rows < n_global) {
+            HIPCHK(hipStreamSynchronize(e->stream));
+            free_dev(e->d_gks); free_dev(e->d_gchi);
+            e->d_gks = e->d_gchi = nullptr;
+            HIPCHK(hipMalloc((void**)&e->d_gks, (size_t)n_global * d * sizeof(float)));
+            HIPCHK(hipMalloc((void**)&e->d_gchi, (size_t)n_global * d * sizeof(float)));
+            e->gather_rows = n_global;
+        }
+        RCCLCHK(g_rccl.AllGather(ks, e->d_gks, (size_t)e->N * d, ncclFloat, e->comm, e->stream));
+        RCCLCHK(g_rccl.AllGather(chi, e->d_gchi, (size_t)e->N * d, ncclFloat, e->comm, e->stream));
+        ks = e->d_gks; chi = e->d_gchi;
+    }
+    return isk_dp_isa_dev(e, ks, chi, n_global, first);
+}
+
+extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t local_batch, int32_t nbatches, int64_t global_batch,
+                          const int32_t* perms, double* losses) {
+    CHK(need_data(e));
+    if (n < 0 || epochs < 0) return fail(ISK_EINVAL, "negative iteration count");
+    if (local_batch < 1 || nbatches < 1 || (long long)local_batch * nbatches > e->N || global_batch < local_batch)
+        return fail(ISK_EINVAL, "bad batch decomposition");
+    if (!perms && epochs > 0 && n > 0) return fail(ISK_EINVAL, "the data-parallel run takes the shuffle orders from the host");
+    const bool coll = dp_collectives(e);
+    if (coll) {          // equal shards: the gathered ISA arrays and the step count assume it
+        long long* d_n = nullptr;
+        HIPCHK(hipMalloc((void**)&d_n, 2 * sizeof(long long)));
+        const long long hn[2] = {e->N, -e->N};
+        HIPCHK(hipMemcpyAsync(d_n, hn, sizeof(hn), hipMemcpyHostToDevice, e->stream));
+        ncclResult_t r = g_rccl.AllReduce(d_n, d_n, 2, ncclInt64, ncclMax, e->comm, e->stream);
+        long long gn[2] = {0, 0};
+        if (r == ncclSuccess) (void)hipMemcpyAsync(gn, d_n, sizeof(gn), hipMemcpyDeviceToHost, e->stream);
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipFree(d_n);
+        if (r != ncclSuccess) return fail(ISK_EHIP, std::string("rccl: ") + g_rccl.GetErrorString(r));
+        if (gn[0] != e->N || gn[1] != -e->N) return fail(ISK_EINVAL, "isk_dp_run needs equal shards on every rank");
+    }
+    // with real collectives keep ONE gradient slab: the all-reduce is latency/link-bound, half the bytes beat the
+    // few microseconds the second row slab saves in train_grad1
+    const int nslab = coll ? 1 : pick_slabs(local_batch);
+    const size_t red_count = (size_t)(nslab - 1) * (e->nparams + 2) + (size_t)e->nparams + 1;
+    long long k = 0;
+    for (int it = 0; it < n; ++it) {
+        if (epochs > 0) CHK(stage_perm_ahead(e, perms + k * e->N));
+        CHK(dp_target_native(e));
+        featurize_ys_beside_training(e, (long long)nbatches * epochs);
+        for (int ep = 0; ep < epochs; ++ep) {
+            if (ep == 0) {
+                HIPCHK(hipStreamWaitEvent(e->stream, e->ev_perm, 0));
+            } else {
+                const int32_t* p = perms + k * e->N;
+                for (long long i = 0; i < e->N; ++i)
+                    if (p[i] < 0 || p[i] >= e->N) return fail(ISK_EINVAL, "permutation entry out of range");
+                std::memcpy(e->h_perm, p, (size_t)e->N * sizeof(int));
+                HIPCHK(hipMemcpyAsync(e->d_perm, e->h_perm, (size_t)e->N * sizeof(int), hipMemcpyHostToDevice, e->stream));
+            }
+            HIPCHK(hipMemsetAsync(e->d_loss_acc, 0, 2 * sizeof(double), e->stream));
+            {
+                ScopedTimer t(e, ISK_T_TRAIN);
+                for (int b = 0; b < nbatches; ++b) {
+                    launch_grads(e, e->d_perm + (long long)b * local_batch, local_batch, 1.0f / (float)global_batch, nslab);
+                    if (coll) RCCLCHK(g_rccl.AllReduce(e->d_grad, e->d_grad, red_count, ncclFloat, ncclSum, e->comm, e->stream));
+                    launch_opt(e, 1.0f);
+                }
+            }
+            double* acc = e->h_res;
+            HIPCHK(hipMemcpyAsync(acc, e->d_loss_acc, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipMemcpyAsync(acc + 2, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+            HIPCHK(hipGetLastError());
+            int st = 0;
+            std::memcpy(&st, acc + 2, sizeof(int));
+            if (st) {   // the target's DomainError outranks the loss check; every rank sees the same status (same gathered data)
+                const int sr = check_status(e);
+                if (sr != ISK_OK) return sr;
+            }
+            if (acc[1] != 0.0) return fail(ISK_ECOLLAPSED, isk_status_string(ISK_ECOLLAPSED));
+            if (losses) losses[k] = acc[0];
+            ++k;
+        }
+        if (epochs == 0) CHK(check_status(e));
+    }
     return ISK_OK;
 }
 

@@ -171,6 +171,36 @@ class HipLocal:
         w = np.ascontiguousarray(w, np.float32)
         capi.check(self.lib.isk_dp_set_loss_weights(self.h, capi.ptr_f32(w)))
 
+    # ---- native collectives: RCCL called by the engine on its own stream (isk_dp_run) --------------------
+    def comm_init_native(self, comm) -> bool:
+        """hand the engine a communicator of its own: rank 0 draws the ncclUniqueId, torch.distributed carries the 128
+        bytes.  False when the process group is not RCCL-backed (gloo tests) -- the host-driven hooks remain."""
+        if getattr(self, "_native", None) is not None:
+            return self._native
+        self._native = False
+        if not comm.on:
+            self._native = True                       # single rank: isk_dp_run runs without collectives
+            return True
+        if comm.dist.get_backend() != "nccl" or comm.device.type != "cuda":
+            return False
+        ident = np.zeros(128, np.uint8)
+        if comm.rank == 0:
+            capi.check(self.lib.isk_dp_comm_id(ident.ctypes.data_as(C.POINTER(C.c_uint8))))
+        t = comm.torch.from_numpy(ident).to(comm.device)
+        comm.dist.broadcast(t, src=0)
+        ident = np.ascontiguousarray(t.cpu().numpy())
+        capi.check(self.lib.isk_dp_comm_init(self.h, ident.ctypes.data_as(C.POINTER(C.c_uint8)), comm.rank, comm.world))
+        self._native = True
+        return True
+
+    def run_native(self, n: int, epochs: int, local_batch: int, nbatches: int, global_batch: int, perms: np.ndarray) -> np.ndarray:
+        """perms: (n*epochs, N_local) int32 -> per-epoch sums of the reduced batch losses"""
+        perms = np.ascontiguousarray(perms, np.int32)
+        losses = np.zeros(n * epochs, np.float64)
+        capi.check(self.lib.isk_dp_run(self.h, n, epochs, int(local_batch), int(nbatches), int(global_batch),
+                                       capi.ptr_i32(perms), capi.ptr_f64(losses)))
+        return losses
+
     def epoch_begin(self, perm):
         perm = np.ascontiguousarray(perm, np.int32)
         capi.check(self.lib.isk_dp_epoch_begin(self.h, capi.ptr_i32(perm), perm.size))
@@ -212,19 +242,22 @@ def dp_target(local, comm: Comm, counts: List[int]) -> None:
     local.set_loss_weights(1.0 / np.sqrt(var))
 
 
-def dp_train_epoch(local, comm: Comm, minibatch: int, counts: List[int], perm: np.ndarray) -> float:
-    """train_batch! (src/iso.jl:179-194) across ranks.  perm: this rank's shuffle of its own shard."""
+def batch_plan(minibatch: int, counts: List[int], world: int, n_local: int) -> Tuple[int, int, int]:
+    """(local batch, batches per epoch, global batch) of train_batch! (src/iso.jl:180-181) on the sharded data"""
     n_global = int(sum(counts))
     bs = n_global if (minibatch == 0 or n_global < minibatch) else minibatch      # src/iso.jl:180
     if bs == n_global:
-        bl, nb = local.n_local, 1                       # full batch: every rank contributes its whole shard
-        gb = n_global
-    else:
-        bl = bs // comm.world
-        if bl < 1:
-            raise ValueError("global minibatch smaller than the number of ranks")
-        gb = bl * comm.world
-        nb = min(c // bl for c in counts)               # partial=false: the ragged tail is dropped
+        return n_local, 1, n_global                     # full batch: every rank contributes its whole shard
+    bl = bs // world
+    if bl < 1:
+        raise ValueError("global minibatch smaller than the number of ranks")
+    return bl, min(c // bl for c in counts), bl * world  # partial=false: the ragged tail is dropped
+
+
+def dp_train_epoch(local, comm: Comm, minibatch: int, counts: List[int], perm: np.ndarray) -> float:
+    """train_batch! (src/iso.jl:179-194) across ranks.  perm: this rank's shuffle of its own shard."""
+    n_global = int(sum(counts))
+    bl, nb, gb = batch_plan(minibatch, counts, comm.world, local.n_local)
     local.epoch_begin(perm[:nb * bl])
     for b in range(nb):                                 # enqueue only: no host synchronisation per step
         local.local_grads(b * bl, bl, gb)
@@ -233,10 +266,24 @@ def dp_train_epoch(local, comm: Comm, minibatch: int, counts: List[int], perm: n
     return local.epoch_end() / n_global                 # one sync; DomainError on a non-finite global loss; src/iso.jl:193
 
 
+def shard_counts(local, comm: Comm) -> List[int]:
+    """start points per rank (one small all-reduce; callers that loop over dp_run pass the result back in)"""
+    return [int(c) for c in comm.allreduce_np(np.eye(comm.world, dtype=np.int64)[comm.rank] * local.n_local, "sum")]
+
+
 def dp_run(local, comm: Comm, n: int, epochs: int, minibatch: int, rng: np.random.Generator,
-           perms: Optional[List[np.ndarray]] = None) -> List[float]:
+           perms: Optional[List[np.ndarray]] = None, counts: Optional[List[int]] = None) -> List[float]:
     """run!(iso, n, epochs) (src/iso.jl:72-94) across ranks; returns the per-epoch losses"""
-    counts = [int(c) for c in comm.allreduce_np(np.eye(comm.world, dtype=np.int64)[comm.rank] * local.n_local, "sum")]
+    if counts is None:
+        counts = shard_counts(local, comm)
+    import os
+    if (hasattr(local, "comm_init_native") and len(set(counts)) == 1 and os.environ.get("ISK_DP_HOST", "0") != "1"
+            and (minibatch == 0 or comm.world == 1 or local.n_local * comm.world >= minibatch) and n * epochs > 0
+            and local.comm_init_native(comm)):
+        # equal shards on an RCCL group: the whole run inside the engine, collectives on its stream
+        bl, nb, gb = batch_plan(minibatch, counts, comm.world, local.n_local)
+        ps = np.stack([np.asarray(perms[i] if perms is not None else rng.permutation(local.n_local), np.int32) for i in range(n * epochs)])
+        return [float(l) / sum(counts) for l in local.run_native(n, epochs, bl, nb, gb, ps)]
     losses, k = [], 0
     for _ in range(n):
         dp_target(local, comm, counts)

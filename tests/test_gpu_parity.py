@@ -355,6 +355,45 @@ def test_dp_driver_single_rank_matches_run(gpu_pkg, nout, minibatch):
     b.close()
 
 
+@pytest.mark.parametrize("nout", [1, 3])
+def test_dp_native_rccl_single_rank_group(gpu_pkg, nout, monkeypatch):
+    """isk_dp_run with a real RCCL communicator (one rank; ISK_DP_FORCE_COLL makes it issue every collective:
+    all-reduce(max) / all-gather for the target, all-reduce(sum) of the gradient slabs per step) against isk_run,
+    and against the host-driven hook path (ISK_DP_HOST=1)"""
+    import importlib
+    import torch
+    import torch.distributed as dist
+    pkg = gpu_pkg
+    dp = importlib.import_module("isokann_jl_amd.dp")
+    monkeypatch.setenv("ISK_DP_FORCE_COLL", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29571")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        N, mb = 160, 32
+        data, odata, om = _coords_case(pkg, 16, 40, N, 3, nout, seed=50 + nout)
+        rng = np.random.default_rng(6)
+        perms = [rng.permutation(N) for _ in range(4)]
+        isos = [pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(1e-2, 1e-3), minibatch=mb) for _ in range(3)]
+        pkg.run(isos[0], 2, 2, perms=np.stack(perms))
+        comm = dp.Comm(device=torch.device("cuda", 0))
+        assert comm.on and comm.world == 1
+        local = dp.HipLocal(isos[1])
+        assert local.comm_init_native(comm)
+        native = dp.dp_run(local, comm, 2, 2, mb, rng, perms=perms)
+        monkeypatch.setenv("ISK_DP_HOST", "1")
+        hosted = dp.dp_run(dp.HipLocal(isos[2]), comm, 2, 2, mb, rng, perms=perms)
+        np.testing.assert_allclose(native, isos[0].losses, rtol=2e-5)
+        np.testing.assert_allclose(hosted, isos[0].losses, rtol=2e-5)
+        for b in isos[1:]:
+            np.testing.assert_allclose(b.model.get_params(), isos[0].model.get_params(), atol=2e-6, rtol=2e-4)
+        for b in isos:
+            b.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_evaluation_callers(gpu_pkg):
     """koopman on foreign data, validation loss (+ logger), Koopman variance"""
     pkg = gpu_pkg
