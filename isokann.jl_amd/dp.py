@@ -266,6 +266,22 @@ def dp_train_epoch(local, comm: Comm, minibatch: int, counts: List[int], perm: n
     return local.epoch_end() / n_global                 # one sync; DomainError on a non-finite global loss; src/iso.jl:193
 
 
+def _native_ready(local, comm: Comm) -> bool:
+    """communicator for the engine's own collectives; any failure to set it up (no librccl, init error) selects the
+    host-driven hooks instead -- on every rank alike, since the outcome is agreed with one all-reduce"""
+    agreed = getattr(local, "_native_agreed", None)
+    if agreed is not None:
+        return agreed
+    try:
+        ok = bool(local.comm_init_native(comm))
+    except Exception:                                   # noqa: BLE001 - the fallback path is always available
+        ok = False
+    if comm.on:
+        ok = bool(comm.allreduce_np(np.array([0.0 if ok else 1.0]), "sum")[0] == 0.0)
+    local._native_agreed = ok
+    return ok
+
+
 def shard_counts(local, comm: Comm) -> List[int]:
     """start points per rank (one small all-reduce; callers that loop over dp_run pass the result back in)"""
     return [int(c) for c in comm.allreduce_np(np.eye(comm.world, dtype=np.int64)[comm.rank] * local.n_local, "sum")]
@@ -279,7 +295,7 @@ def dp_run(local, comm: Comm, n: int, epochs: int, minibatch: int, rng: np.rando
     import os
     if (hasattr(local, "comm_init_native") and len(set(counts)) == 1 and os.environ.get("ISK_DP_HOST", "0") != "1"
             and (minibatch == 0 or comm.world == 1 or local.n_local * comm.world >= minibatch) and n * epochs > 0
-            and local.comm_init_native(comm)):
+            and _native_ready(local, comm)):
         # equal shards on an RCCL group: the whole run inside the engine, collectives on its stream
         bl, nb, gb = batch_plan(minibatch, counts, comm.world, local.n_local)
         ps = np.stack([np.asarray(perms[i] if perms is not None else rng.permutation(local.n_local), np.int32) for i in range(n * epochs)])
