@@ -205,7 +205,9 @@ static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream
         if (fit < wg_per_cu) wg_per_cu = fit < 1 ? 1 : fit;
     }
     long long blocks = (a.S + 3) / 4;
-    const long long cap = (long long)ISK_NUM_CU * wg_per_cu;
+    long long cap = (long long)ISK_NUM_CU * wg_per_cu;
+    static const int bg_total = [] { const char* v = getenv("ISK_FEAT_BG_WGS"); return v ? atoi(v) : 0; }();
+    if (a.background && bg_total > 0) cap = bg_total;          // tuning knob: background workgroups in total
     if (blocks > cap) blocks = cap;
     if (pd) {
         if (lds > 64 * 1024)
