@@ -386,6 +386,13 @@ __device__ __forceinline__ void static_for_tiles(std::integer_sequence<int, Ts..
     (f(std::integral_constant<int, Ts>{}), ...);
 }
 
+#if ISK_ABLATE == 15
+#define PX_CH 512
+#define PX_H 256
+#else
+#define PX_CH 32
+#define PX_H 4
+#endif
 template <int NT, int U, int NTHR, bool EARLY>
 __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __restrict__ W16, u32x4* wbuf, const float* const (&xp)[U],
                                           int nch, int lane, f32x4 (&acc)[U][NT]
@@ -419,8 +426,8 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            xr[0][u][h] = *(const f32x4v*)(xp[u] + 4 * h);
-            xr[1][u][h] = *(const f32x4v*)(xp[u] + (last > 0 ? 32 : 0) + 4 * h);
+            xr[0][u][h] = *(const f32x4v*)(xp[u] + PX_H * h);
+            xr[1][u][h] = *(const f32x4v*)(xp[u] + (last > 0 ? PX_CH : 0) + PX_H * h);
         }
     __syncthreads();                                     // the previous pass's epilogue scratch aliases the buffers
 #pragma unroll
@@ -494,23 +501,23 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
                 // ---- this tile's share of the stage's side work
 #pragma unroll
                 for (int i = 0; i < NX; ++i)
-                    if (G::tile_x(i) == t) xr[s][i >> 1][i & 1] = *(const f32x4v*)(xp[i >> 1] + cx * 32 + 4 * (i & 1));
+                    if (G::tile_x(i) == t && ISK_ABLATE != 12) xr[s][i >> 1][i & 1] = *(const f32x4v*)(xp[i >> 1] + cx * PX_CH + PX_H * (i & 1));
 #pragma unroll
                 for (int i = 0; i < PER_T; ++i)
-                    if (G::tile_dw(i) == t) wr[i * NTHR + tid] = wreg[i];
+                    if (G::tile_dw(i) == t && ISK_ABLATE != 14) wr[i * NTHR + tid] = wreg[i];
 #pragma unroll
                 for (int i = 0; i < PER_T; ++i)
-                    if (G::tile_wl(i) == t) wreg[i] = wc[goff[i]];
+                    if (G::tile_wl(i) == t && ISK_ABLATE != 14) wreg[i] = wc[goff[i]];
 #pragma unroll
                 for (int i = 0; i < NX; ++i)
-                    if (G::tile_sp(i) == t) {
+                    if (G::tile_sp(i) == t && ISK_ABLATE != 13) {
                         if (i & 1) split_half<1>(nxt[i >> 1], xr[s ^ 1][i >> 1][1]);
                         else split_half<0>(nxt[i >> 1], xr[s ^ 1][i >> 1][0]);
                     }
                 __builtin_amdgcn_sched_barrier(0);
                 if (t == TBAR) {
                     STAMP(1);
-                    __syncthreads();
+                    if (ISK_ABLATE != 11) __syncthreads();
                     STAMP(2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -545,7 +552,17 @@ __device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __res
         if (r > a.S - 1) r = a.S - 1;
         if (r < 0) r = 0;
         if (a.rows) r = a.rows[r];
+#if ISK_ABLATE == 15
+        {   // ablation: pretend the samples are stored fragment-linear (1 KiB per unit, chunk and half)
+            long long ub = u0 + u;
+            const long long umax = (a.S + 15) / 16 - 1;
+            if (ub > umax) ub = umax;
+            if (ub < 0) ub = 0;
+            xp[u] = a.X + ub * 16 * (long long)a.Fp + lane * 4;
+        }
+#else
         xp[u] = a.X + r * (long long)a.Fp + lq * 8;
+#endif
     }
     f32x4 acc[U][NT];
 #pragma unroll
