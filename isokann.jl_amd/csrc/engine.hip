@@ -892,11 +892,7 @@ static int forward_resident(isk_engine* e, int which, bool ahead = false) {
             if (nw) {
                 fprintf(stderr, "[stamps] waves %d  total cyc %.0f  realtime(100MHz ticks) %.0f -> clock %.2f GHz\n", nw, sum[8] / nw, sum[9] / nw,
                         sum[8] / sum[9] * 0.1);
-                const char* pipe_env = getenv("ISK_BF16_PIPE");
-                const bool oldk = pipe_env && atoi(pipe_env) == 0;
-                const char* nm_old[8] = {"xload-issue", "split(+x wait)", "mfma+ldsread", "w ds_write(+w wait)", "barrier", "w load issue", "pass tail", "epilogue"};
-                const char* nm_new[8] = {"pass prologue", "stage: up to barrier", "barrier", "stage: after barrier", "end-of-pass barrier", "epilogue", "-", "-"};
-                const char* const* nm = oldk ? nm_old : nm_new;
+                const char* nm[8] = {"pass prologue", "stage: up to barrier", "barrier", "stage: after barrier", "end-of-pass barrier", "epilogue", "-", "-"};
                 for (int k = 0; k < 8; ++k) fprintf(stderr, "[stamps]   %-20s %6.1f %%\n", nm[k], 100.0 * sum[k] / sum[8]);
             }
         }
