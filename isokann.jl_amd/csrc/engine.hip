@@ -565,9 +565,16 @@ static void featurize_rows(isk_engine* e, const float* in, long long S, float* x
 // running; then the main stream only waits for it and swaps buffers.
 static void featurize_resident(isk_engine* e) {
     if (e->ys_ahead) {
-        (void)hipStreamWaitEvent(e->stream, e->ev_ys_ready, 0);
+        // the xs rows of the other buffer do not depend on the side stream: featurize them BEFORE waiting for it, so
+        // the (un-throttled) xs launch runs under the tail of the throttled ys featurization instead of after it
         std::swap(e->d_xhat, e->d_xhat_alt);
         e->ys_ahead = false;
+        {
+            ScopedTimer t(e, ISK_T_FEATURIZE);
+            featurize_rows(e, e->d_in_xs, e->N, e->d_xhat + (long long)e->N * e->K * e->Fp);
+        }
+        (void)hipStreamWaitEvent(e->stream, e->ev_ys_ready, 0);
+        return;
     } else {
         ScopedTimer t(e, ISK_T_FEATURIZE);
         featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat);
