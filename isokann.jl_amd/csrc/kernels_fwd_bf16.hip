@@ -152,6 +152,16 @@ __device__ __forceinline__ void static_for_tiles(std::integer_sequence<int, Ts..
 #define PX_CH 32
 #define PX_H 4
 #endif
+// the sample stream is read once per launch (1.45 GB): non-temporal loads keep it from evicting the weight planes and
+// the training working set (measured: step 1.647 -> 1.628 ms, cached-features mode 1.191 -> 1.163 ms)
+#ifndef ISK_X_NT
+#define ISK_X_NT 1
+#endif
+#if ISK_X_NT
+#define X_LD(p) __builtin_nontemporal_load(p)
+#else
+#define X_LD(p) (*(p))
+#endif
 template <int NT, int U, int NTHR, bool EARLY>
 __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __restrict__ W16, u32x4* wbuf, const float* const (&xp)[U],
                                           int nch, int lane, f32x4 (&acc)[U][NT]
@@ -260,7 +270,7 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
                 // ---- this tile's share of the stage's side work
 #pragma unroll
                 for (int i = 0; i < NX; ++i)
-                    if (G::tile_x(i) == t && ISK_ABLATE != 12) xr[s][i >> 1][i & 1] = *(const f32x4v*)(xp[i >> 1] + cx * PX_CH + PX_H * (i & 1));
+                    if (G::tile_x(i) == t && ISK_ABLATE != 12) xr[s][i >> 1][i & 1] = X_LD((const f32x4v*)(xp[i >> 1] + cx * PX_CH + PX_H * (i & 1)));
 #pragma unroll
                 for (int i = 0; i < PER_T; ++i)
                     if (G::tile_dw(i) == t && ISK_ABLATE != 14) wr[i * NTHR + tid] = wreg[i];
