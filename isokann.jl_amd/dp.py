@@ -75,7 +75,13 @@ class Comm:
 
     def allreduce_tensor_(self, t):
         if self.on:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            if t.is_cuda and self.dist.get_backend() != "nccl":
+                # a CPU process group driving GPU engines (tests): stage through the host
+                h = t.cpu()
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM)
+                t.copy_(h)
+            else:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
 
     def barrier(self):
@@ -135,7 +141,7 @@ class HipLocal:
     def isa_device(self, comm, counts) -> bool:
         """device-resident path: all-gather the local ks / chi slices with RCCL and run the Float64
         ISA kernel on the gathered arrays on every rank (no host round trip).  Needs equal shards."""
-        if len(set(counts)) != 1:
+        if len(set(counts)) != 1 or (comm.on and comm.dist.get_backend() != "nccl"):
             return False
         torch = comm.torch
         ks_p, chi_p, n = C.c_void_p(), C.c_void_p(), C.c_int64()
