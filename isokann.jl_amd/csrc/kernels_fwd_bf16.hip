@@ -187,9 +187,12 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
         const int p = idx / (NT * 64), rem = idx - p * (NT * 64);
         goff[i] = (p * ntt + (a.dense_mode ? a.w_tile0 : 0)) * 64 + rem;
     }
-    u32x4 wreg[PER_T];
+    // both prologue weight chunks in flight together: one exposed memory round trip per pass instead of two
+    u32x4 wreg[PER_T], wfirst[PER_T];
 #pragma unroll
-    for (int i = 0; i < PER_T; ++i) wreg[i] = W16[goff[i]];
+    for (int i = 0; i < PER_T; ++i) wfirst[i] = W16[goff[i]];
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) wreg[i] = W16[gchunk + goff[i]];  // nchp >= 2
     f32x4v xr[2][U][2];                                              // [ring slot = chunk & 1][unit][half]
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -200,10 +203,8 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
         }
     __syncthreads();                                     // the previous pass's epilogue scratch aliases the buffers
 #pragma unroll
-    for (int i = 0; i < PER_T; ++i) wbuf[i * NTHR + tid] = wreg[i];
+    for (int i = 0; i < PER_T; ++i) wbuf[i * NTHR + tid] = wfirst[i];
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PER_T; ++i) wreg[i] = W16[gchunk + goff[i]];  // nchp >= 2
     Planes cur[U], nxt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
