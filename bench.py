@@ -112,7 +112,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1000)
     ap.add_argument("--profile-steps", type=int, default=5)
-    ap.add_argument("--forward-mode", type=int, default=1, choices=[0, 1], help="0 = f32 MFMA forward, 1 = split-bf16 (bf16x3) forward")
+    ap.add_argument("--forward-mode", type=int, default=1, choices=[0, 1, 2],
+                    help="0 = f32 MFMA forward, 1 = split-bf16 (bf16x3, f32-equivalent) forward, 2 = plain bf16 operands (reduced precision)")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel driver even with one rank (rehearsal)")
     args = ap.parse_args()
 
@@ -210,14 +211,16 @@ def main():
             avg = ms / cnt
             alg_tf = fwd_flops / (avg * 1e-3) / 1e12
             nt1 = (widths[1] + 15) // 16
-            if args.forward_mode == 1:
+            if args.forward_mode in (1, 2):
                 # split-bf16 forward: six bf16 MFMAs per product block are EXECUTED for every algorithmic f32 one;
                 # the bound is the bf16 matrix pipe, so the roofline is priced in executed bf16 flops
                 l1 = 2 * ((widths[0] + 31) // 32 * 32) * (nt1 * 16)
-                exec_flops = (N * K + (N if widths[-1] > 1 else 0)) * (6 * l1 + (ffwd - 2 * widths[0] * widths[1]))
+                nmma = 6 if args.forward_mode == 1 else 1
+                exec_flops = (N * K + (N if widths[-1] > 1 else 0)) * (nmma * l1 + (ffwd - 2 * widths[0] * widths[1]))
                 ach = exec_flops / (avg * 1e-3) / 1e12
                 roof = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": traffic,
-                        "kernel": f"mlp_fwd_bf16x3p_kernel<{nt1},8>", "dtype": "bf16x3 split (3 bf16 planes per f32 operand, f32 accumulate)",
+                        "kernel": f"mlp_fwd_bf16x3p_kernel<{nt1},8,{3 if args.forward_mode == 1 else 1}>",
+                        "dtype": "bf16x3 split (3 bf16 planes per f32 operand, f32 accumulate)" if args.forward_mode == 1 else "bf16 operands, f32 accumulate",
                         "executed_flops_per_launch": exec_flops,
                         "algorithmic": {"flops_per_launch": fwd_flops, "tflops": alg_tf, "vs_f32_mfma_peak_157.3": alg_tf / 157.3}}
             else:
@@ -238,11 +241,13 @@ def main():
             "metric": "ISOKANN train-step Koopman-samples (N*K)/sec", "value": value, "unit": "Koopman-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.forward_mode == 0 else "f32 (Koopman forward GEMM as split-bf16 x3 MFMA, f32 accumulate; training f32)", "data": "synthetic",
+            "dtype": {0: "f32", 1: "f32 (Koopman forward GEMM as split-bf16 x3 MFMA, f32 accumulate; training f32)",
+                      2: "bf16 (Koopman forward GEMM with bf16 operands, f32 accumulate: REDUCED precision, not the headline; training f32)"}[args.forward_mode],
+            "data": "synthetic",
             "config": {"workload": c["label"], "N_per_gpu": N, "K": K, "features": widths[0], "widths": widths,
                        "minibatch_per_gpu": args.minibatch, "optimizer": args.opt + "+weightdecay",
                        "featurize": "cached" if args.cached_features else "every-iteration (fused pdist+LayerNorm kernel)",
-                       "forward_mode": "bf16x3" if args.forward_mode == 1 else "f32",
+                       "forward_mode": {0: "f32", 1: "bf16x3", 2: "bf16"}[args.forward_mode],
                        "parallelism": f"dp{world} over N" if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu,
             "final_loss": iso.losses[-1],

@@ -98,7 +98,10 @@ typedef struct isk_config {
                                             samples: 0 = f32-input MFMA (exact f32 fma chain),
                                             1 = split-bf16: three bf16 planes per operand, six bf16 MFMAs per
                                             product block, f32 accumulate (f32-equivalent accuracy at 2.7x the
-                                            f32 MFMA rate).  Training kernels are f32 in both modes. */
+                                            f32 MFMA rate),
+                                            2 = plain bf16 operands (leading plane only), f32 accumulate: the C5
+                                            configuration of the baseline; outputs agree with f32 to ~1e-2 relative.
+                                            Training kernels are f32 in every mode. */
 } isk_config;
 
 /* ---- library ------------------------------------------------------------------ */

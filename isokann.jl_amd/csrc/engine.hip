@@ -363,7 +363,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     e->cfg.pairs = nullptr;
     e->L = cfg->n_layers; e->F = F; e->Fp = isk_pad32(F); e->Din = Din; e->nout = nout;
     if (const char* fm = getenv("ISK_FWD_MODE")) e->cfg.forward_mode = atoi(fm);
-    if (e->cfg.forward_mode != 0 && e->cfg.forward_mode != 1) { delete e; return fail(ISK_EINVAL, "unknown forward_mode"); }
+    if (e->cfg.forward_mode < 0 || e->cfg.forward_mode > 2) { delete e; return fail(ISK_EINVAL, "unknown forward_mode"); }
     {
         bool fits = isk_pad16(cfg->widths[1]) / 16 <= ISK_MAX_NT;
         size_t tailw = 0, tail_train = 0;
@@ -777,6 +777,9 @@ extern "C" int isk_chicoords(isk_engine* e, const float* coords, int64_t D, int6
 // ---------------------------------------------------------------------------------------
 // resident forward, koopman, target
 // ---------------------------------------------------------------------------------------
+// bf16 planes per f32 operand of the layer-1 / dense-block forward GEMM: 0 = f32 MFMA, 3 = split-bf16, 1 = plain bf16
+static int bf16_planes(const isk_engine* e) { return e->cfg.forward_mode == 1 ? 3 : (e->cfg.forward_mode == 2 ? 1 : 0); }
+
 // layer-by-layer forward: every layer is a sequence of dense-block launches of the same GEMM kernels; hidden
 // activations [S][pad32(H)] ping-pong between actA / actB (zero-initialised: the padding columns stay 0)
 static int forward_layered(isk_engine* e, const float* X, long long S, float* out, float* actA, float* actB) {
@@ -788,10 +791,13 @@ static int forward_layered(isk_engine* e, const float* X, long long S, float* ou
         const int nt_total = isk_pad16(N) / 16;
         float* dst = last ? out : ((l % 2 == 0) ? actA : actB);
         const int out_ld = last ? e->nout : isk_pad32(N);
-        if (e->cfg.forward_mode == 1 && e->w16_dirty)
-            isk_launch_fold_bf16(e->d_Wt[l], e->d_W16L[l], layer_kp(e, l), nt_total, e->stream);
-        for (int t0 = 0; t0 < nt_total; t0 += 8) {
-            const int ntb = std::min(8, nt_total - t0);
+        const int planes = bf16_planes(e);
+        if (planes && e->w16_dirty)
+            isk_launch_fold_bf16(e->d_Wt[l], e->d_W16L[l], layer_kp(e, l), nt_total, planes, e->stream);
+        // plain bf16 keeps 16 output tiles per workgroup (two launches for a 512-wide layer), the others 8
+        const int tb = planes == 1 ? ISK_MAX_NT_BF16 : 8;
+        for (int t0 = 0; t0 < nt_total; t0 += tb) {
+            const int ntb = std::min(tb, nt_total - t0);
             MlpFwdArgs a;
             std::memset(&a, 0, sizeof(a));
             a.X = in; a.S = S; a.Fp = in_ld; a.nchunks = in_ld / 16;
@@ -802,8 +808,8 @@ static int forward_layered(isk_engine* e, const float* X, long long S, float* ou
             a.stride_a = ntb * 16 + 4; a.stride_b = 4;
             isk_fwd_layout_biases(a);
             int r = ISK_EUNSUPPORTED;
-            if (e->cfg.forward_mode == 1) r = isk_launch_mlp_fwd_bf16x3(a, e->d_W16L[l], e->stream);
-            if (r != 0) r = isk_launch_mlp_fwd(a, e->stream);
+            if (planes) r = isk_launch_mlp_fwd_bf16x3(a, e->d_W16L[l], planes, e->stream);
+            if (r != 0 && ntb <= ISK_MAX_NT) r = isk_launch_mlp_fwd(a, e->stream);
             if (r != 0) return r;
         }
         in = dst;
@@ -834,12 +840,12 @@ static int launch_forward(isk_engine* e, const MlpFwdArgs& f) {
         }
         return forward_layered(e, f.X, f.S, f.out, a, b);
     }
-    if (e->cfg.forward_mode == 1) {
+    if (const int planes = bf16_planes(e)) {
         if (e->w16_dirty) {
-            isk_launch_fold_bf16(e->d_Wt[0], e->d_W16, e->Fp, f.nt1, e->stream);
+            isk_launch_fold_bf16(e->d_Wt[0], e->d_W16, e->Fp, f.nt1, planes, e->stream);
             e->w16_dirty = false;
         }
-        if (isk_launch_mlp_fwd_bf16x3(f, e->d_W16, e->stream) == 0) return 0;
+        if (isk_launch_mlp_fwd_bf16x3(f, e->d_W16, planes, e->stream) == 0) return 0;
         // shapes whose LDS footprint does not fit the split-bf16 kernel run on the f32 kernel
     }
     return isk_launch_mlp_fwd(f, e->stream);

@@ -71,8 +71,10 @@ static inline void isk_fwd_layout_biases(MlpFwdArgs& a) {
 }
 int  isk_launch_mlp_fwd(const MlpFwdArgs& a, hipStream_t st);   // returns 0 or ISK_EUNSUPPORTED
 // split-bf16 variant: W16 = three bf16 planes of the layer-1 weights from isk_launch_fold_bf16
-int  isk_launch_mlp_fwd_bf16x3(const MlpFwdArgs& a, const void* W16, hipStream_t st);
-void isk_launch_fold_bf16(const float* Wt, void* out, int Kp, int nt, hipStream_t st);
+// planes: 3 = split-bf16 (f32-equivalent), 1 = plain bf16 operands (forward_mode 2); the image from isk_launch_fold_bf16 must match
+int  isk_launch_mlp_fwd_bf16x3(const MlpFwdArgs& a, const void* W16, int planes, hipStream_t st);
+void isk_launch_fold_bf16(const float* Wt, void* out, int Kp, int nt, int planes, hipStream_t st);
+#define ISK_MAX_NT_BF16 16   // output tiles per workgroup of the plain-bf16 forward
 int  isk_bf16_chunks(int Kp);     // 32-feature chunks in the plane image (padded to the kernel's ring size)
 
 // ---------------------------------------------------------------- layered (wide-network) path ----

@@ -40,7 +40,7 @@ __device__ __forceinline__ Planes split3(const f32x8 v) {
 // fp32 fragment-linear layer-1 weights [chunk16][nt][64][4]  ->  bf16 planes [chunk32][3][nt][64][8]
 // lane = (kq << 4) | o_local holds W[o][k = 32*c + 8*kq + j], j = 0..7: the B operand of v_mfma_f32_16x16x32_bf16
 __global__ __launch_bounds__(256) void fold_bf16_kernel(const float* __restrict__ Wt, __bf16* __restrict__ out, int nchunk32,
-                                                        int nt, int nchunk16) {
+                                                        int nt, int nchunk16, int planes) {
     const long long total = (long long)nchunk32 * nt * 64 * 8;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const int j = e & 7;
@@ -57,22 +57,24 @@ __global__ __launch_bounds__(256) void fold_bf16_kernel(const float* __restrict_
         const float r1 = w - (float)b0;
         const __bf16 b1 = (__bf16)r1;
         const __bf16 b2 = (__bf16)(r1 - (float)b1);
-        const long long base = (long long)c32 * 3 * nt;
+        const long long base = (long long)c32 * planes * nt;
         out[((base + 0 * nt + t) * 64 + lane) * 8 + j] = b0;
-        out[((base + 1 * nt + t) * 64 + lane) * 8 + j] = b1;
-        out[((base + 2 * nt + t) * 64 + lane) * 8 + j] = b2;
+        if (planes == 3) {
+            out[((base + 1 * nt + t) * 64 + lane) * 8 + j] = b1;
+            out[((base + 2 * nt + t) * 64 + lane) * 8 + j] = b2;
+        }
     }
 }
 
 // chunks in the plane image: padded with zero planes (the pipelined kernel runs an even number of stages)
 int isk_bf16_chunks(int Kp) { return ((Kp + 31) / 32 + 5) / 6 * 6; }
 
-void isk_launch_fold_bf16(const float* Wt, void* out, int Kp, int nt, hipStream_t st) {
+void isk_launch_fold_bf16(const float* Wt, void* out, int Kp, int nt, int planes, hipStream_t st) {
     const int nchunk32 = isk_bf16_chunks(Kp), nchunk16 = Kp / 16;
     long long total = (long long)nchunk32 * nt * 64 * 8;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(fold_bf16_kernel, dim3(blocks), dim3(256), 0, st, Wt, (__bf16*)out, nchunk32, nt, nchunk16);
+    hipLaunchKernelGGL(fold_bf16_kernel, dim3(blocks), dim3(256), 0, st, Wt, (__bf16*)out, nchunk32, nt, nchunk16, planes);
 }
 
 #ifndef ISK_STAMP
@@ -105,9 +107,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NT, int U, int NTHR, bool EARLY = false>
+template <int NT, int U, int NTHR, bool EARLY = false, int NPL = 3>
 struct PipeGeom {
-    static constexpr int STAGE16 = 3 * NT * 64;                         // 16-byte units staged per chunk
+    static constexpr int STAGE16 = NPL * NT * 64;                         // 16-byte units staged per chunk
     static constexpr int PER_T = (STAGE16 + NTHR - 1) / NTHR;
     static constexpr int SLOTS = PER_T * NTHR;                          // LDS slots per buffer (>= STAGE16)
     static constexpr int NX = 2 * U;                                    // 16-byte sample loads / half-unit splits per chunk
@@ -122,9 +124,14 @@ struct PipeGeom {
 };
 
 // half h (4 features) of a sample fragment -> the three plane halves
-template <int HALF>
+template <int HALF, int NPL = 3>
 __device__ __forceinline__ void split_half(Planes& d, const f32x4v v) {
     const bf16x4 a0 = __builtin_convertvector(v, bf16x4);
+    if (NPL == 1) {                                      // plain bf16 mode: the leading plane only
+        if (HALF == 0) d.p0 = __builtin_shufflevector(a0, __builtin_shufflevector(d.p0, d.p0, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7);
+        else d.p0 = __builtin_shufflevector(__builtin_shufflevector(d.p0, d.p0, 0, 1, 2, 3), a0, 0, 1, 2, 3, 4, 5, 6, 7);
+        return;
+    }
     const f32x4v r1 = v - __builtin_convertvector(a0, f32x4v);
     const bf16x4 a1 = __builtin_convertvector(r1, bf16x4);
     const f32x4v r2 = r1 - __builtin_convertvector(a1, f32x4v);
@@ -162,14 +169,14 @@ __device__ __forceinline__ void static_for_tiles(std::integer_sequence<int, Ts..
 #else
 #define X_LD(p) (*(p))
 #endif
-template <int NT, int U, int NTHR, bool EARLY>
+template <int NT, int U, int NTHR, bool EARLY, int NPL>
 __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __restrict__ W16, u32x4* wbuf, const float* const (&xp)[U],
                                           int nch, int lane, f32x4 (&acc)[U][NT]
 #if ISK_STAMP
                                           , unsigned long long (&g_ph)[8], unsigned long long& g_t
 #endif
                                           ) {
-    typedef PipeGeom<NT, U, NTHR, EARLY> G;
+    typedef PipeGeom<NT, U, NTHR, EARLY, NPL> G;
     constexpr int STAGE16 = G::STAGE16, PER_T = G::PER_T, NX = G::NX, SLOTS = G::SLOTS;
     constexpr int TBAR = G::tile_dw(PER_T - 1);          // the stage's barrier follows the tile with the last LDS write
     constexpr bool XPF = TBAR < NT - 1;                  // next stage's first fragments can be fetched before this stage ends
@@ -178,7 +185,7 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
     const int nchp = (nch + 1) & ~1;
     // global image: [chunk][plane][nt_total tiles][64]; the block stages tiles [tile0, tile0 + NT) of each plane
     const int ntt = a.dense_mode ? a.w_nt_total : NT;
-    const int gchunk = 3 * ntt * 64;
+    const int gchunk = NPL * ntt * 64;
     int goff[PER_T];
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
@@ -208,8 +215,8 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
     Planes cur[U], nxt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        split_half<0>(cur[u], xr[0][u][0]);
-        split_half<1>(cur[u], xr[0][u][1]);
+        split_half<0, NPL>(cur[u], xr[0][u][0]);
+        split_half<1, NPL>(cur[u], xr[0][u][1]);
         nxt[u] = cur[u];
     }
     // consume every prologue load here, so the loop is entered with a clean vmcnt state and the waits inside
@@ -222,11 +229,11 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
     // stage, in the middle (after the last LDS write), so a stage boundary has no barrier and the first
     // fragments of the next stage are prefetched across it
     int rdi = 0;                                                     // c % 3
-    bf16x8 wf[2][3];
+    bf16x8 wf[2][NPL];
     {
         const bf16x8* wl = (const bf16x8*)wbuf;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) wf[0][pl] = wl[(pl * NT) * 64 + lane];
+        for (int pl = 0; pl < NPL; ++pl) wf[0][pl] = wl[(pl * NT) * 64 + lane];
     }
     STAMP(0);
     for (int c0 = 0; c0 < nchp; c0 += 2) {
@@ -242,32 +249,37 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
             u32x4* wr = wbuf + wri * SLOTS;
             if (!XPF) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wf[(s * NT) & 1][pl] = wl[(pl * NT) * 64 + lane];
+                for (int pl = 0; pl < NPL; ++pl) wf[(s * NT) & 1][pl] = wl[(pl * NT) * 64 + lane];
             }
             static_for_tiles(std::make_integer_sequence<int, NT>{}, [&](auto tc) __attribute__((always_inline)) {
                 constexpr int t = decltype(tc)::value;
                 const int fb = (s * NT + t) & 1;
                 if (t + 1 < NT) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) wf[fb ^ 1][pl] = wl[(pl * NT + t + 1) * 64 + lane];
+                    for (int pl = 0; pl < NPL; ++pl) wf[fb ^ 1][pl] = wl[(pl * NT + t + 1) * 64 + lane];
                 } else if (XPF) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) wf[fb ^ 1][pl] = wln[(pl * NT) * 64 + lane];
+                    for (int pl = 0; pl < NPL; ++pl) wf[fb ^ 1][pl] = wln[(pl * NT) * 64 + lane];
                 }
-                const bf16x8 w0 = wf[fb][0], w1 = wf[fb][1], w2 = wf[fb][2];
-                // smallest terms first
+                if (NPL == 1) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p1, w1, acc[u][t], 0, 0, 0);
+                    for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, wf[fb][0], acc[u][t], 0, 0, 0);
+                } else {
+                    const bf16x8 w0 = wf[fb][0], w1 = wf[fb][NPL > 1 ? 1 : 0], w2 = wf[fb][NPL > 2 ? 2 : 0];
+                    // smallest terms first
 #pragma unroll
-                for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p2, w0, acc[u][t], 0, 0, 0);
+                    for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p1, w1, acc[u][t], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, w2, acc[u][t], 0, 0, 0);
+                    for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p2, w0, acc[u][t], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p1, w0, acc[u][t], 0, 0, 0);
+                    for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, w2, acc[u][t], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, w1, acc[u][t], 0, 0, 0);
+                    for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p1, w0, acc[u][t], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, w0, acc[u][t], 0, 0, 0);
+                    for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, w1, acc[u][t], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, w0, acc[u][t], 0, 0, 0);
+                }
                 // ---- this tile's share of the stage's side work
 #pragma unroll
                 for (int i = 0; i < NX; ++i)
@@ -281,8 +293,8 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
 #pragma unroll
                 for (int i = 0; i < NX; ++i)
                     if (G::tile_sp(i) == t && ISK_ABLATE != 13) {
-                        if (i & 1) split_half<1>(nxt[i >> 1], xr[s ^ 1][i >> 1][1]);
-                        else split_half<0>(nxt[i >> 1], xr[s ^ 1][i >> 1][0]);
+                        if (i & 1) split_half<1, NPL>(nxt[i >> 1], xr[s ^ 1][i >> 1][1]);
+                        else split_half<0, NPL>(nxt[i >> 1], xr[s ^ 1][i >> 1][0]);
                     }
                 __builtin_amdgcn_sched_barrier(0);
                 if (t == TBAR) {
@@ -302,7 +314,7 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
     STAMP(4);
 }
 
-template <int NT, int U, int NWV, bool EARLY>
+template <int NT, int U, int NWV, bool EARLY, int NPL>
 __device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __restrict__ W16, float* smem, long long u0, int nact
 #if ISK_STAMP
                                          , unsigned long long (&g_ph)[8], unsigned long long& g_t
@@ -341,9 +353,9 @@ __device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __res
         for (int t = 0; t < NT; ++t) acc[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // a wave without a unit in this pass computes on clamped rows and discards the result
 #if ISK_STAMP
-    pipe_pass<NT, U, NWV * 64, EARLY>(a, (const u32x4*)W16, wbuf, xp, a.Fp / 32, lane, acc, g_ph, g_t);
+    pipe_pass<NT, U, NWV * 64, EARLY, NPL>(a, (const u32x4*)W16, wbuf, xp, a.Fp / 32, lane, acc, g_ph, g_t);
 #else
-    pipe_pass<NT, U, NWV * 64, EARLY>(a, (const u32x4*)W16, wbuf, xp, a.Fp / 32, lane, acc);
+    pipe_pass<NT, U, NWV * 64, EARLY, NPL>(a, (const u32x4*)W16, wbuf, xp, a.Fp / 32, lane, acc);
 #endif
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -351,7 +363,7 @@ __device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __res
     STAMP(5);
 }
 
-template <int NT, int NWV>
+template <int NT, int NWV, int NPL>
 __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3p_kernel(MlpFwdArgs a, const uint4* __restrict__ W16, long long units,
                                                                    long long units_per_wave) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -372,9 +384,9 @@ __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3p_kernel(MlpFwdArgs a,
     for (long long p = 0; p < npass; ++p) {
         const long long u = ustart + 2 * p;
         if (u + 1 < uend) {
-            if (early) pipe_run<NT, 2, NWV, true>(a, W16, smem, u, 2, g_ph, g_t);
-            else pipe_run<NT, 2, NWV, false>(a, W16, smem, u, 2, g_ph, g_t);
-        } else pipe_run<NT, 1, NWV, false>(a, W16, smem, u, u < uend ? 1 : 0, g_ph, g_t);
+            if (early) pipe_run<NT, 2, NWV, true, NPL>(a, W16, smem, u, 2, g_ph, g_t);
+            else pipe_run<NT, 2, NWV, false, NPL>(a, W16, smem, u, 2, g_ph, g_t);
+        } else pipe_run<NT, 1, NWV, false, NPL>(a, W16, smem, u, u < uend ? 1 : 0, g_ph, g_t);
     }
     if (a.dbg && (threadIdx.x & 63) == 0) {
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
@@ -386,20 +398,20 @@ __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3p_kernel(MlpFwdArgs a,
     for (long long p = 0; p < npass; ++p) {
         const long long u = ustart + 2 * p;
         if (u + 1 < uend) {                                                            // wave-uniform
-            if (early) pipe_run<NT, 2, NWV, true>(a, W16, smem, u, 2);
-            else pipe_run<NT, 2, NWV, false>(a, W16, smem, u, 2);
-        } else pipe_run<NT, 1, NWV, false>(a, W16, smem, u, u < uend ? 1 : 0);
+            if (early) pipe_run<NT, 2, NWV, true, NPL>(a, W16, smem, u, 2);
+            else pipe_run<NT, 2, NWV, false, NPL>(a, W16, smem, u, 2);
+        } else pipe_run<NT, 1, NWV, false, NPL>(a, W16, smem, u, u < uend ? 1 : 0);
     }
 #endif
 }
 
-template <int NT, int NWV>
+template <int NT, int NWV, int NPL>
 static size_t pipe_lds_bytes(const MlpFwdArgs& a) {
-    const size_t wb = (size_t)3 * PipeGeom<NT, 2, NWV * 64>::SLOTS * 4, scr = (size_t)NWV * 16 * (a.stride_a + a.stride_b);
+    const size_t wb = (size_t)3 * PipeGeom<NT, 2, NWV * 64, false, NPL>::SLOTS * 4, scr = (size_t)NWV * 16 * (a.stride_a + a.stride_b);
     return ((size_t)a.tailw_floats + (wb > scr ? wb : scr)) * sizeof(float);
 }
 
-template <int NT, int NWV>
+template <int NT, int NWV, int NPL>
 static void launch_pipe_nw(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
     const long long units = (a.S + 15) / 16;
     const long long waves_max = (long long)ISK_NUM_CU * NWV;
@@ -407,42 +419,73 @@ static void launch_pipe_nw(const MlpFwdArgs& a, const void* W16, hipStream_t st)
     if (upw < 1) upw = 1;
     const long long nwaves = (units + upw - 1) / upw;
     const long long blocks = (nwaves + NWV - 1) / NWV;
-    const size_t lds = pipe_lds_bytes<NT, NWV>(a);
+    const size_t lds = pipe_lds_bytes<NT, NWV, NPL>(a);
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16x3p_kernel<NT, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((mlp_fwd_bf16x3p_kernel<NT, NWV>), dim3((unsigned)blocks), dim3(NWV * 64), lds, st, a, (const uint4*)W16, units, upw);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16x3p_kernel<NT, NWV, NPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mlp_fwd_bf16x3p_kernel<NT, NWV, NPL>), dim3((unsigned)blocks), dim3(NWV * 64), lds, st, a, (const uint4*)W16, units, upw);
 }
 
-template <int NT>
+template <int NT, int NPL>
 static int launch_pipe_nt(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
     const size_t cap = 158 * 1024;
-    if (pipe_lds_bytes<NT, 8>(a) <= cap) { launch_pipe_nw<NT, 8>(a, W16, st); return 0; }
-    if (pipe_lds_bytes<NT, 4>(a) <= cap) { launch_pipe_nw<NT, 4>(a, W16, st); return 0; }
+    if (pipe_lds_bytes<NT, 8, NPL>(a) <= cap) { launch_pipe_nw<NT, 8, NPL>(a, W16, st); return 0; }
+    if (NPL == 3) {     // the split kernel's per-wave epilogue scratch can outgrow the ring with 8 waves; the plain one never does
+        if (pipe_lds_bytes<NT, 4, 3>(a) <= cap) { launch_pipe_nw<NT, 4, 3>(a, W16, st); return 0; }
+    }
     return ISK_EUNSUPPORTED;
 }
 
-static int launch_pipe(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
+// split-bf16 (three planes): up to ISK_MAX_NT output tiles per workgroup
+static int launch_pipe3(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
     switch (a.nt1) {
 #ifndef ISK_DEV_NT9
-        case 1: return launch_pipe_nt<1>(a, W16, st);
-        case 2: return launch_pipe_nt<2>(a, W16, st);
-        case 3: return launch_pipe_nt<3>(a, W16, st);
-        case 4: return launch_pipe_nt<4>(a, W16, st);
-        case 5: return launch_pipe_nt<5>(a, W16, st);
-        case 6: return launch_pipe_nt<6>(a, W16, st);
-        case 7: return launch_pipe_nt<7>(a, W16, st);
-        case 8: return launch_pipe_nt<8>(a, W16, st);
+        case 1: return launch_pipe_nt<1, 3>(a, W16, st);
+        case 2: return launch_pipe_nt<2, 3>(a, W16, st);
+        case 3: return launch_pipe_nt<3, 3>(a, W16, st);
+        case 4: return launch_pipe_nt<4, 3>(a, W16, st);
+        case 5: return launch_pipe_nt<5, 3>(a, W16, st);
+        case 6: return launch_pipe_nt<6, 3>(a, W16, st);
+        case 7: return launch_pipe_nt<7, 3>(a, W16, st);
+        case 8: return launch_pipe_nt<8, 3>(a, W16, st);
 #endif
-        case 9: return launch_pipe_nt<9>(a, W16, st);
+        case 9: return launch_pipe_nt<9, 3>(a, W16, st);
 #ifndef ISK_DEV_NT9
-        case 10: return launch_pipe_nt<10>(a, W16, st);
+        case 10: return launch_pipe_nt<10, 3>(a, W16, st);
 #endif
         default: return ISK_EUNSUPPORTED;
     }
 }
 
-int isk_launch_mlp_fwd_bf16x3(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
+// plain bf16 (one plane, forward_mode 2): a third of the registers and LDS per tile, so up to 16 tiles per workgroup --
+// the layered path then covers a 512-wide layer in two launches instead of four
+static int launch_pipe1(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
+    switch (a.nt1) {
+#ifndef ISK_DEV_NT9
+        case 1: return launch_pipe_nt<1, 1>(a, W16, st);
+        case 2: return launch_pipe_nt<2, 1>(a, W16, st);
+        case 3: return launch_pipe_nt<3, 1>(a, W16, st);
+        case 4: return launch_pipe_nt<4, 1>(a, W16, st);
+        case 5: return launch_pipe_nt<5, 1>(a, W16, st);
+        case 6: return launch_pipe_nt<6, 1>(a, W16, st);
+        case 7: return launch_pipe_nt<7, 1>(a, W16, st);
+        case 8: return launch_pipe_nt<8, 1>(a, W16, st);
+#endif
+        case 9: return launch_pipe_nt<9, 1>(a, W16, st);
+#ifndef ISK_DEV_NT9
+        case 10: return launch_pipe_nt<10, 1>(a, W16, st);
+        case 11: return launch_pipe_nt<11, 1>(a, W16, st);
+        case 12: return launch_pipe_nt<12, 1>(a, W16, st);
+        case 13: return launch_pipe_nt<13, 1>(a, W16, st);
+        case 14: return launch_pipe_nt<14, 1>(a, W16, st);
+        case 15: return launch_pipe_nt<15, 1>(a, W16, st);
+        case 16: return launch_pipe_nt<16, 1>(a, W16, st);
+#endif
+        default: return ISK_EUNSUPPORTED;
+    }
+}
+
+int isk_launch_mlp_fwd_bf16x3(const MlpFwdArgs& a, const void* W16, int planes, hipStream_t st) {
     if (a.S <= 0) return 0;
     if (a.Fp % 32 != 0) return ISK_EUNSUPPORTED;
-    return launch_pipe(a, W16, st);
+    return planes == 1 ? launch_pipe1(a, W16, st) : launch_pipe3(a, W16, st);
 }

@@ -13,6 +13,8 @@ b c3_mb100_nesterov --minibatch 100 --opt nesterov
 b c2 --workload c2
 b c5shard --workload c5shard --no-cpu-baseline
 b c5shard_f32fwd --workload c5shard --forward-mode 0 --no-cpu-baseline
+b c5shard_bf16fwd --workload c5shard --forward-mode 2 --no-cpu-baseline
+b c3_bf16fwd --forward-mode 2 --no-cpu-baseline
 bash scripts/prof_bench.sh c3stats > gpurun_out/ref/prof.txt 2>&1 || true
 cp gpurun_out/prof_c3stats/c3stats_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c3.csv
 bash scripts/pmc.sh > gpurun_out/ref/pmc.txt 2>&1 || true

@@ -669,3 +669,46 @@ def test_pseudoinv_needs_multidimensional_chi(gpu_pkg):
     data, odata, om = _coords_case(pkg, 10, 20, 64, 3, 1, seed=5)
     with pytest.raises(ValueError):
         pkg.Iso(data, model=_mk_model(pkg, om), target=pkg.TransformPseudoInv(), minibatch=0)
+
+
+# --------------------------------------------------------------- plain bf16 forward (forward_mode 2, C5's arithmetic) ----
+@pytest.mark.parametrize("widths,ln", [([231, 38, 6, 1], True), ([100, 150, 20, 3], True), ([64, 96, 300, 300, 2], False),
+                                       ([40, 512, 40, 1], False)])
+def test_forward_plain_bf16_within_1e2(gpu_pkg, widths, ln, monkeypatch):
+    """forward_mode 2: bf16 operands (leading plane only), f32 accumulate -- SURVEY 8d: 'bf16 path: stated separately
+    (expected ~1e-2)'.  Covers the fused kernel, the layered dense-block path and a 512-wide layer (two 16-tile launches)."""
+    monkeypatch.delenv("ISK_FWD_MODE", raising=False)
+    pkg = gpu_pkg
+    om = _rand_model(widths, seed=sum(widths) + 1, ln=ln)
+    rng = np.random.default_rng(8)
+    N, K = 96, 3
+    xs = rng.normal(size=(widths[0], N)) + 1
+    ys = rng.normal(size=(widths[0], K, N)) + 1
+    tr = pkg.TransformShiftscale() if widths[-1] == 1 else pkg.TransformISA()
+    out = {}
+    for mode in (0, 2):
+        iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.identity), model=_mk_model(pkg, om), target=tr, minibatch=0, forward_mode=mode)
+        out[mode] = (pkg.chis(iso), pkg.koopman(iso))
+        iso.close()
+    want = om(np.asarray(xs, np.float32).astype(np.float64))
+    scale = max(1.0, np.abs(want).max())
+    assert np.abs(out[0][0] - want).max() <= 2e-5 * scale                 # the f32 path, for reference
+    assert np.abs(out[2][0] - want).max() <= 1e-2 * scale                 # bf16 operands
+    assert np.abs(out[2][0] - want).max() > 1e-6 * scale                  # ... and it really is the reduced-precision path
+    assert np.abs(out[2][1] - out[0][1]).max() <= 1e-2 * scale
+
+
+def test_run_plain_bf16_forward_tracks_f32(gpu_pkg, monkeypatch):
+    """three iterations with the plain-bf16 Koopman forward (training stays f32) stay close to the f32 run"""
+    monkeypatch.delenv("ISK_FWD_MODE", raising=False)
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 18, 60, 200, 4, 1, seed=77)
+    perms = np.stack([np.arange(200)] * 3)
+    res = {}
+    for mode in (0, 2):
+        iso = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(), minibatch=0, forward_mode=mode)
+        pkg.run(iso, 3, 1, perms=perms)
+        res[mode] = (np.asarray(iso.losses), pkg.chis(iso))
+        iso.close()
+    np.testing.assert_allclose(res[2][0], res[0][0], rtol=0.1)
+    assert np.abs(res[2][1] - res[0][1]).max() <= 2e-2
