@@ -13,6 +13,7 @@
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <rocblas/rocblas.h>
 #include "isk_internal.h"
 
 // ---------------------------------------------------------------------------------------
@@ -120,6 +121,9 @@ struct isk_engine {
     float* d_la[ISK_MAX_LAYERS] = {nullptr};      //           activations
     float* d_ld[ISK_MAX_LAYERS] = {nullptr};      //           deltas
     float *d_G0 = nullptr, *d_D0 = nullptr;       // raw layer-0 gradient for the LayerNorm unfold
+    float* d_xb = nullptr;                        // rocBLAS training path: the batch rows of layer 0, gathered contiguous
+    float* d_W0g = nullptr;                       //                        layer-0 weights with the LayerNorm scale folded in (Flux layout)
+    rocblas_handle blas = nullptr;
     float* d_zero = nullptr;                      // zero bias for the transposed GEMMs
     double* d_loss_acc = nullptr;
     int* d_status = nullptr;
@@ -179,6 +183,7 @@ static void free_data(isk_engine* e) {
     free_dev(e->d_target); free_dev(e->d_kw); e->d_kw = nullptr; free_dev(e->d_z1); free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm); free_dev(e->d_isa_work);
     e->d_isa_work = nullptr;
     free_dev(e->d_actA); free_dev(e->d_actB); e->d_actA = e->d_actB = nullptr;
+    free_dev(e->d_xb); e->d_xb = nullptr;
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_lz[l]); free_dev(e->d_la[l]); free_dev(e->d_ld[l]); e->d_lz[l] = e->d_la[l] = e->d_ld[l] = nullptr; }
     e->d_in_xs = e->d_in_ys = e->d_xhat = e->d_xhat_alt = e->d_out = e->d_ks = e->d_target = e->d_z1 = e->d_delta1 = e->d_part = nullptr;
     e->d_perm = nullptr;
@@ -436,6 +441,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
             ALLOC(e->d_W16L[l], (size_t)isk_bf16_chunks(layer_kp(e, l)) * 32 * isk_pad16(cfg->widths[l + 1]) * 3 * sizeof(uint16_t));
         ALLOC(e->d_G0, (size_t)F * cfg->widths[1] * sizeof(float));
         ALLOC(e->d_D0, (size_t)cfg->widths[1] * sizeof(float));
+        ALLOC(e->d_W0g, (size_t)F * cfg->widths[1] * sizeof(float));
         ALLOC(e->d_zero, (size_t)4096 * sizeof(float));
         (void)hipMemset(e->d_zero, 0, (size_t)4096 * sizeof(float));
     }
@@ -452,6 +458,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
 }
 
 static void dp_comm_release(isk_engine* e);
+static void blas_release(isk_engine* e);
 
 extern "C" void isk_destroy(isk_engine* e) {
     if (!e) return;
@@ -465,7 +472,8 @@ extern "C" void isk_destroy(isk_engine* e) {
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_Wt[l]); free_dev(e->d_bias[l]); }
     free_dev(e->d_W16);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_W16L[l]); free_dev(e->d_WtT[l]); }
-    free_dev(e->d_G0); free_dev(e->d_D0); free_dev(e->d_zero);
+    free_dev(e->d_G0); free_dev(e->d_D0); free_dev(e->d_zero); free_dev(e->d_W0g);
+    blas_release(e);
     dp_comm_release(e);
     free_dev(e->d_gks); free_dev(e->d_gchi);
     drain_timers(e);
@@ -668,7 +676,11 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
             HIPCHK(hipMalloc((void**)&e->d_lz[l], nb));
             HIPCHK(hipMalloc((void**)&e->d_la[l], nb));
             HIPCHK(hipMalloc((void**)&e->d_ld[l], nb));
+            HIPCHK(hipMemsetAsync(e->d_lz[l], 0, nb, e->stream));
+            HIPCHK(hipMemsetAsync(e->d_la[l], 0, nb, e->stream));
+            HIPCHK(hipMemsetAsync(e->d_ld[l], 0, nb, e->stream));
         }
+        HIPCHK(hipMalloc((void**)&e->d_xb, (size_t)Bpad * e->Fp * sizeof(float)));
     }
     HIPCHK(hipMemcpyAsync(e->d_in_xs, xs, (size_t)N * D * sizeof(float), kind, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_in_ys, ys, (size_t)N * K * D * sizeof(float), kind, e->stream));
@@ -1341,8 +1353,115 @@ static int pick_slabs(int B) {
     return s < 1 ? 1 : (s > ISK_MAX_SLABS ? ISK_MAX_SLABS : s);
 }
 
+// ---------------------------------------------------------------------------------------
+// rocBLAS for the PLAIN GEMMs of the layered (wide-network) training path, loaded lazily.  The fused kernels
+// cover the networks whose layers fit a workgroup; 512-wide layers at a 1000-row batch are ordinary
+// [1000 x 2016] x [2016 x 512] products, where a tiled library GEMM moves 4-8x fewer bytes through L2 than
+// the one-tile-per-workgroup row GEMM used before (C5 shard: 0.47 -> ~0.2 ms per optimizer step).
+// ISK_LAYERED_BLAS=0 keeps the in-house kernels (also the fallback when librocblas.so cannot be loaded).
+// ---------------------------------------------------------------------------------------
+namespace {
+struct BlasApi {
+    void* lib = nullptr;
+    rocblas_status (*create)(rocblas_handle*) = nullptr;
+    rocblas_status (*destroy)(rocblas_handle) = nullptr;
+    rocblas_status (*set_stream)(rocblas_handle, hipStream_t) = nullptr;
+    rocblas_status (*sgemm)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const float*,
+                            const float*, rocblas_int, const float*, rocblas_int, const float*, float*, rocblas_int) = nullptr;
+    bool failed = false;
+};
+BlasApi g_blas;
+
+bool blas_load() {
+    if (g_blas.lib) return true;
+    if (g_blas.failed) return false;
+    void* h = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (h) {
+        g_blas.create = (decltype(g_blas.create))dlsym(h, "rocblas_create_handle");
+        g_blas.destroy = (decltype(g_blas.destroy))dlsym(h, "rocblas_destroy_handle");
+        g_blas.set_stream = (decltype(g_blas.set_stream))dlsym(h, "rocblas_set_stream");
+        g_blas.sgemm = (decltype(g_blas.sgemm))dlsym(h, "rocblas_sgemm");
+    }
+    if (!h || !g_blas.create || !g_blas.destroy || !g_blas.set_stream || !g_blas.sgemm) { g_blas.failed = true; return false; }
+    g_blas.lib = h;
+    return true;
+}
+}  // namespace
+
+static void blas_release(isk_engine* e) {
+    if (e->blas && g_blas.destroy) (void)g_blas.destroy(e->blas);
+    e->blas = nullptr;
+}
+
+static bool blas_ready(isk_engine* e) {
+    static const int on = [] { const char* v = getenv("ISK_LAYERED_BLAS"); return v ? atoi(v) : 1; }();
+    if (!on || !e->layered || !e->d_xb) return false;
+    if (!blas_load()) return false;
+    if (!e->blas && g_blas.create(&e->blas) != rocblas_status_success) { e->blas = nullptr; g_blas.failed = true; return false; }
+    return g_blas.set_stream(e->blas, e->stream) == rocblas_status_success;
+}
+
+// one optimizer step's gradient on the layered path with library GEMMs.  All matrices are viewed column-major:
+// a row-major [rows][ld] activation buffer is the (ld x rows) matrix X', Flux's W (out, in) is the (N x K) matrix W.
+//   forward   Z' (N x B) = W (N x K) * X' (K x B)
+//   dW        G  (N x K) = D' (N x B) * X'^T          -> written in Flux layout directly
+//   dX        R' (K x B) = W^T (K x N) * D' (N x B)   -> no transposed weight image needed
+static bool launch_grads_layered_blas(isk_engine* e, const int* d_idx, int B, float inv_div) {
+    if (!blas_ready(e)) return false;
+    const int L = e->L;
+    const long long Bpad = ((B + 15) / 16) * 16;
+    const float* xs = e->d_xhat + (long long)e->N * e->K * e->Fp;
+    hipStream_t st = e->stream;
+    const float one = 1.f, zero = 0.f;
+    const float* X0 = xs;
+    if (d_idx) { isk_launch_gather_rows(xs, e->Fp, d_idx, B, e->d_xb, st); X0 = e->d_xb; }
+    const float* W0 = e->d_theta + e->off_W[0];
+    if (e->cfg.layernorm) {
+        isk_launch_scale_cols(e->d_theta + e->off_W[0], e->d_theta + e->off_lns, e->d_W0g, e->cfg.widths[1], e->F, st);
+        W0 = e->d_W0g;
+    }
+    bool ok = true;
+    for (int l = 0; l < L && ok; ++l) {
+        const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1], Np = isk_pad16(N);
+        const float* X = (l == 0) ? X0 : e->d_la[l - 1];
+        const int ldx = (l == 0) ? e->Fp : isk_pad16(K);
+        const float* W = (l == 0) ? W0 : e->d_theta + e->off_W[l];
+        ok = g_blas.sgemm(e->blas, rocblas_operation_none, rocblas_operation_none, N, B, K, &one, W, N, X, ldx, &zero, e->d_lz[l], Np) ==
+             rocblas_status_success;
+        // layer 0 with LayerNorm: the folded bias image (b1 + W1*beta); otherwise the bias straight from theta
+        const float* bias = (l == 0 && e->cfg.layernorm) ? e->d_bias[0] : e->d_theta + e->off_b[l];
+        isk_launch_bias_act(e->d_lz[l], bias, l < L - 1 ? e->d_la[l] : nullptr, B, Np, N, act_of_layer(e, l), st);
+    }
+    if (!ok) return false;
+    const int nop = isk_pad16(e->nout);
+    isk_launch_loss_delta(e->d_lz[L - 1], nop, e->d_target, e->d_lossw, d_idx, B, e->nout, inv_div, e->cfg.lastactivation,
+                          e->d_ld[L - 1], nop, e->d_grad + e->nparams, st);
+    for (int l = L - 1; l >= 0 && ok; --l) {
+        const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1], Np = isk_pad16(N);
+        const float* X = (l == 0) ? X0 : e->d_la[l - 1];
+        const int ldx = (l == 0) ? e->Fp : isk_pad16(K);
+        const bool ln0 = (l == 0 && e->cfg.layernorm);
+        float* gW = ln0 ? e->d_G0 : e->d_grad + e->off_W[l];
+        ok = g_blas.sgemm(e->blas, rocblas_operation_none, rocblas_operation_transpose, N, K, B, &one, e->d_ld[l], Np, X, ldx, &zero, gW, N) ==
+             rocblas_status_success;
+        isk_launch_colsum(e->d_ld[l], Np, B, N, e->d_grad + e->off_b[l], st);
+        if (ln0)
+            isk_launch_ln_unfold(e->d_G0, e->d_grad + e->off_b[0], e->d_theta, e->off_W[0], e->off_lns, e->off_lnb, e->F, N, e->d_grad, st);
+        if (l > 0 && ok) {
+            // delta_{l-1} = (delta_l W_l) .* act'(z_{l-1});  a_{l-1} is dead after dW_l and receives the raw product
+            ok = g_blas.sgemm(e->blas, rocblas_operation_transpose, rocblas_operation_none, K, B, N, &one, e->d_theta + e->off_W[l], N,
+                              e->d_ld[l], Np, &zero, e->d_la[l - 1], isk_pad16(K)) == rocblas_status_success;
+            isk_launch_dact_mul(e->d_la[l - 1], e->d_lz[l - 1], e->d_ld[l - 1], Bpad, isk_pad16(K), K, act_of_layer(e, l - 1), st);
+        }
+    }
+    e->last_nslab = 1;
+    return ok;
+}
+
 // layered path: one optimizer step's gradient, layer by layer (see kernels_layered.hip)
 static void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float inv_div) {
+    if (launch_grads_layered_blas(e, d_idx, B, inv_div)) return;
     const int L = e->L;
     const long long Bpad = ((B + 15) / 16) * 16;
     const float* xs = e->d_xhat + (long long)e->N * e->K * e->Fp;

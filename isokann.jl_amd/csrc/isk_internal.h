@@ -79,6 +79,11 @@ int  isk_bf16_chunks(int Kp);     // 32-feature chunks in the plane image (padde
 
 // ---------------------------------------------------------------- layered (wide-network) path ----
 void isk_launch_act(const float* z, float* a, long long rows, int ld, int width, int act, hipStream_t st);
+// helpers of the rocBLAS variant of the layered training path (the library runs the plain GEMMs)
+void isk_launch_bias_act(float* z, const float* b, float* a /*nullable*/, long long rows, int ld, int width, int act, hipStream_t st);
+void isk_launch_gather_rows(const float* X, int ld, const int* idx, int B, float* out, hipStream_t st);
+void isk_launch_colsum(const float* d, int ld, int B, int N, float* out, hipStream_t st);
+void isk_launch_scale_cols(const float* W, const float* g, float* out, int N, int K, hipStream_t st);
 // delta_L and the batch loss (written to *loss_slot) from the last layer's pre-activations
 void isk_launch_loss_delta(const float* z, int ld, const float* target, const float* lossw, const int* perm, int B, int nout,
                            float inv_div, int lastact, float* delta, int delta_ld, float* loss_slot, hipStream_t st);
