@@ -1505,7 +1505,10 @@ static void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, 
     e->last_nslab = nslab;
 }
 
-static void launch_opt(isk_engine* e, float gscale) {
+// fold: refresh the weight images the forward / training kernels read.  The rocBLAS variant of the layered training
+// path reads theta itself (only layer 0's folded bias comes from an image, and only with LayerNorm), so inside an
+// epoch it skips the refresh and folds once at the end.
+static void launch_opt(isk_engine* e, float gscale, bool fold = true) {
     OptArgs a;
     a.theta = e->d_theta; a.grad = e->d_grad; a.m = e->d_m; a.v = e->d_v; a.n = e->nparams;
     a.kind = e->cfg.opt_kind; a.lr = e->cfg.lr; a.reg = e->cfg.reg; a.beta1 = e->cfg.beta1; a.beta2 = e->cfg.beta2;
@@ -1516,7 +1519,7 @@ static void launch_opt(isk_engine* e, float gscale) {
     a.slab_prefix = (e->cfg.layernorm ? 2LL * e->F : 0LL) + (long long)e->F * e->cfg.widths[1] + e->cfg.widths[1];
     isk_launch_opt_step(a, e->stream);
     e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2;
-    launch_fold(e);
+    if (fold) launch_fold(e);
 }
 
 static int upload_target(isk_engine* e, const float* target) {
@@ -1572,9 +1575,10 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
     HIPCHK(hipMemsetAsync(e->d_loss_acc, 0, 2 * sizeof(double), e->stream));
     {
         ScopedTimer t(e, ISK_T_TRAIN);
+        const bool lazy_fold = e->layered && !e->cfg.layernorm && blas_ready(e);
         for (long long b = 0; b < nb; ++b) {
             launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, pick_slabs((int)bs));
-            launch_opt(e, 1.0f);
+            launch_opt(e, 1.0f, !lazy_fold || b == nb - 1);
         }
     }
     // one round trip per epoch: loss, collapse flag and (for isk_run) the target's status word, into pinned memory
