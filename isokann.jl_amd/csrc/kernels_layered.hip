@@ -151,19 +151,37 @@ __global__ __launch_bounds__(1024) void loss_delta_kernel(const float* __restric
     __shared__ float red[16];
     float ls = 0.f;
     const long long tot = (long long)Bpad * delta_ld;
-    for (long long e = threadIdx.x; e < tot; e += 1024) {
-        const int n = (int)(e / delta_ld), o = (int)(e % delta_ld);
-        float d = 0.f;
-        if (n < B && o < nout) {
-            const long long prow = perm ? perm[n] : n;
-            const float zz = z[(long long)n * ld + o];
-            const float out = l_act(lastact, zz);
-            const float w = lossw[o];
-            const float r = (out - target[prow * nout + o]) * w;
-            ls += r * r;
-            d = 2.f * r * w * inv_div * l_dact(lastact, zz);
+    // four elements per thread in flight: the row index -> target chain is two dependent loads
+    for (long long e0 = threadIdx.x; e0 < tot; e0 += 4 * 1024) {
+        float zz[4], tg[4];
+        bool live[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long e = e0 + u * 1024;
+            const int n = (int)(e / delta_ld), o = (int)(e % delta_ld);
+            live[u] = e < tot && n < B && o < nout;
+            zz[u] = 0.f; tg[u] = 0.f;
+            if (live[u]) {
+                const long long prow = perm ? perm[n] : n;
+                zz[u] = z[(long long)n * ld + o];
+                tg[u] = target[prow * nout + o];
+            }
         }
-        delta[e] = d;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long e = e0 + u * 1024;
+            if (e >= tot) continue;
+            float d = 0.f;
+            if (live[u]) {
+                const int o = (int)(e % delta_ld);
+                const float out = l_act(lastact, zz[u]);
+                const float w = lossw[o];
+                const float r = (out - tg[u]) * w;
+                ls += r * r;
+                d = 2.f * r * w * inv_div * l_dact(lastact, zz[u]);
+            }
+            delta[e] = d;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o, WAVE);
