@@ -219,7 +219,7 @@ def main():
                 exec_flops = (N * K + (N if widths[-1] > 1 else 0)) * (nmma * l1 + (ffwd - 2 * widths[0] * widths[1]))
                 ach = exec_flops / (avg * 1e-3) / 1e12
                 roof = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": traffic,
-                        "kernel": f"mlp_fwd_bf16x3p_kernel<{nt1},8,{3 if args.forward_mode == 1 else 1}>",
+                        "kernel": f"mlp_fwd_bf16x3p_kernel<{nt1},8,{3 if args.forward_mode == 1 else 1},false>",
                         "dtype": "bf16x3 split (3 bf16 planes per f32 operand, f32 accumulate)" if args.forward_mode == 1 else "bf16 operands, f32 accumulate",
                         "executed_flops_per_launch": exec_flops,
                         "algorithmic": {"flops_per_launch": fwd_flops, "tflops": alg_tf, "vs_f32_mfma_peak_157.3": alg_tf / 157.3}}

@@ -33,12 +33,31 @@ __device__ __forceinline__ float act_apply(int act, float z) {
 
 
 // epilogue + tail layers for one 16-row unit whose layer-1 pre-activations sit in acc[NT]
-template <int NT>
+// DENSE (compile time): the dense-block mode of the layered path; kept out of the fused instantiations (and the tail
+// code out of the dense ones) because the split-bf16 kernel sits at the 256-register limit and every extra path spills
+template <int NT, bool DENSE = false>
 __device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT], long long row_base, float* scrA,
                                           float* scrB, const float* tailw, int lane) {
     const int li = lane & 15, lq = lane >> 4;
     int stride = a.stride_a;
-    const bool fast_sig = (a.act1 == ISK_ACT_SIGMOID) && a.ntail > 0 && !a.dense_mode;    // wave-uniform
+    if (DENSE) {
+        // one layer of the layered path: straight from the accumulators (row = 4 lq + r, column = 16 t + li) to global
+        // memory, 64 contiguous bytes per row and instruction -- no LDS transpose.  Every padded column of this block
+        // gets act(z) (finite, so the next layer's zero weight rows annihilate it).
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = t * 16 + li;
+            const float bcol = tailw[a.bias_lds0 + col];
+            const bool colok = a.out_col0 + col < a.out_ld;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long grow = row_base + lq * 4 + r;
+                if (colok && grow < a.S) a.out[grow * a.out_ld + a.out_col0 + col] = act_apply(a.act1, acc[t][r] + bcol);
+            }
+        }
+        return;
+    }
+    const bool fast_sig = (a.act1 == ISK_ACT_SIGMOID) && a.ntail > 0;    // wave-uniform
     // accumulator layout (row = 4*lq + r, col = 16*t + li) -> LDS rows; bias (and, on the common
     // sigmoid path, the activation) applied on the way, in registers
     if (fast_sig) {
@@ -65,19 +84,6 @@ __device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT],
     }
     __builtin_amdgcn_wave_barrier();
     const int H1p = NT * 16;
-    if (a.dense_mode) {
-        // one layer of the layered path: every padded column of this block gets act(z) (finite, so the next
-        // layer's zero weight rows annihilate it)
-        for (int row = 0; row < 16; ++row) {
-            const long long grow = row_base + row;
-            if (grow < a.S)
-                for (int col = lane; col < H1p; col += WAVE)
-                    if (a.out_col0 + col < a.out_ld)
-                        a.out[grow * a.out_ld + a.out_col0 + col] = act_apply(a.act1, scrA[row * stride + col]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        return;
-    }
     if (a.ntail == 0) {
         for (int row = lq; row < 16; row += 4) {
             const long long grow = row_base + row;

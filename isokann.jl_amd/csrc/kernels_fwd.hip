@@ -463,8 +463,13 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a, long long un
         for (int t = 0; t < NT; ++t) { acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         if (two) layer1_gemm<NT, true>(a, x0, x1, lane, acc0, acc1);
         else layer1_gemm<NT, false>(a, x0, x1, lane, acc0, acc1);
-        unit_tail<NT>(a, acc0, u * 16, scrA, scrB, smem, lane);
-        if (two) unit_tail<NT>(a, acc1, (u + 1) * 16, scrA, scrB, smem, lane);
+        if (a.dense_mode) {                                             // wave-uniform
+            unit_tail<NT, true>(a, acc0, u * 16, scrA, scrB, smem, lane);
+            if (two) unit_tail<NT, true>(a, acc1, (u + 1) * 16, scrA, scrB, smem, lane);
+        } else {
+            unit_tail<NT, false>(a, acc0, u * 16, scrA, scrB, smem, lane);
+            if (two) unit_tail<NT, false>(a, acc1, (u + 1) * 16, scrA, scrB, smem, lane);
+        }
     }
 }
 
