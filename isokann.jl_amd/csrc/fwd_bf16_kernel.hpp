@@ -227,19 +227,10 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
                     for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, wf[fb][0], acc[u][t], 0, 0, 0);
                 } else {
                     const bf16x8 w0 = wf[fb][0], w1 = wf[fb][NPL > 1 ? 1 : 0], w2 = wf[fb][NPL > 2 ? 2 : 0];
-                    // smallest terms first
-#pragma unroll
-                    for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p1, w1, acc[u][t], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p2, w0, acc[u][t], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, w2, acc[u][t], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p1, w0, acc[u][t], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, w1, acc[u][t], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, w0, acc[u][t], 0, 0, 0);
+                    // smallest terms first (an order with longer runs of MFMAs sharing the B operand measured the same)
+#define T_(P_, W_) _Pragma("unroll") for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].P_, W_, acc[u][t], 0, 0, 0);
+                    T_(p1, w1) T_(p2, w0) T_(p0, w2) T_(p1, w0) T_(p0, w1) T_(p0, w0)
+#undef T_
                 }
                 // ---- this tile's share of the stage's side work
 #pragma unroll
