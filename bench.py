@@ -189,6 +189,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert os.environ.get("ISK_LIB") or all(np.isfinite(l) for l in iso.losses), "non-finite training loss"
+    if use_dp and world > 1:
+        # every rank applies the same all-reduced gradient: the reduced loss and the replicas must agree exactly
+        import torch
+        chk = torch.tensor([iso.losses[-1], float(np.sum(np.abs(iso.model.get_params()).astype(np.float64)))], dtype=torch.float64,
+                           device=torch.device("cuda", local_rank))
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            same = bool(torch.all(lo == hi).item())
+            print(f"[bench] replicas consistent across {world} ranks: {same} (loss {float(lo[0]):.6g}, |theta|_1 {float(lo[1]):.6g})", file=sys.stderr)
+            assert same, "data-parallel replicas diverged"
 
     # roofline of the dominant kernel (fused MLP forward), HIP events on the engine's stream, outside the timed region
     roof = None
