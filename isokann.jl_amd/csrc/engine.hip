@@ -152,6 +152,7 @@ struct isk_engine {
     // native data-parallel run (isk_dp_run): RCCL communicator + gathered ks / chi
     ncclComm_t comm = nullptr;
     int dp_rank = 0, dp_world = 1;
+    long long dp_checked_N = -1;     // shard size for which the equal-shards check has passed on this communicator
     float* d_gks = nullptr;
     float* d_gchi = nullptr;
     long long gather_rows = 0;
@@ -1868,7 +1869,7 @@ int rccl_load() {
 static void dp_comm_release(isk_engine* e) {
     if (e->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(e->stream); (void)g_rccl.CommDestroy(e->comm); }
     e->comm = nullptr;
-    e->dp_rank = 0; e->dp_world = 1;
+    e->dp_rank = 0; e->dp_world = 1; e->dp_checked_N = -1;
 }
 
 extern "C" int isk_dp_comm_id(uint8_t id[128]) {
@@ -1952,7 +1953,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
         return fail(ISK_EINVAL, "bad batch decomposition");
     if (!perms && epochs > 0 && n > 0) return fail(ISK_EINVAL, "the data-parallel run takes the shuffle orders from the host");
     const bool coll = dp_collectives(e);
-    if (coll) {          // equal shards: the gathered ISA arrays and the step count assume it
+    if (coll && e->dp_checked_N != e->N) {          // equal shards: the gathered ISA arrays and the step count assume it (checked once)
         long long* d_n = nullptr;
         HIPCHK(hipMalloc((void**)&d_n, 2 * sizeof(long long)));
         const long long hn[2] = {e->N, -e->N};
@@ -1964,6 +1965,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
         (void)hipFree(d_n);
         if (r != ncclSuccess) return fail(ISK_EHIP, std::string("rccl: ") + g_rccl.GetErrorString(r));
         if (gn[0] != e->N || gn[1] != -e->N) return fail(ISK_EINVAL, "isk_dp_run needs equal shards on every rank");
+        e->dp_checked_N = e->N;
     }
     // with real collectives keep ONE gradient slab: the all-reduce is latency/link-bound, half the bytes beat the
     // few microseconds the second row slab saves in train_grad1
