@@ -712,3 +712,28 @@ def test_run_plain_bf16_forward_tracks_f32(gpu_pkg, monkeypatch):
         iso.close()
     np.testing.assert_allclose(res[2][0], res[0][0], rtol=0.1)
     assert np.abs(res[2][1] - res[0][1]).max() <= 2e-2
+
+
+# --------------------------------------------------------------- every template instantiation of the bf16 forward ----
+@pytest.mark.parametrize("mode", [1, 2])
+def test_bf16_forward_every_tile_count(gpu_pkg, mode, monkeypatch):
+    """first hidden widths 5, 21, ..., 149 (1..10 output tiles: every instantiation of the fused split-bf16 / plain-bf16
+    kernel) and wide layers whose dense blocks hit every tile count of the layered path (1..8 split, 1..16 plain)"""
+    monkeypatch.delenv("ISK_FWD_MODE", raising=False)
+    pkg = gpu_pkg
+    rng = np.random.default_rng(12)
+    F, N, K = 70, 40, 2
+    xs = rng.normal(size=(F, N)) + 1
+    ys = rng.normal(size=(F, K, N)) + 1
+    tol = 2e-5 if mode == 1 else 1e-2
+    fused = [[F, 16 * k + 5, 7, 1] for k in range(10)]
+    dense = [[F, 160 + 16 * k + 3, 9, 1] for k in range(1, 17)]         # 171..419 wide: blocks of (8|16) tiles + remainder
+    for widths in fused + dense:
+        om = _rand_model(widths, seed=widths[1], ln=True)
+        iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.identity), model=_mk_model(pkg, om), minibatch=0, forward_mode=mode)
+        want = om(np.asarray(xs, np.float32).astype(np.float64))
+        got = pkg.chis(iso)
+        assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max()), widths
+        kw = O.expectation(om, np.asarray(ys, np.float32).astype(np.float64))
+        assert np.abs(pkg.koopman(iso) - kw).max() <= tol * max(1.0, np.abs(kw).max()), widths
+        iso.close()
