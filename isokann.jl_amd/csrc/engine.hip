@@ -105,6 +105,8 @@ struct isk_engine {
     // concurrently with the latency-bound training kernels of the current one
     hipStream_t side = nullptr;
     hipEvent_t ev_fwd_done = nullptr, ev_ys_ready = nullptr;
+    long long side_after_forward = 0;   // isk_run / isk_dp_run: launch the side-stream ys featurization right behind the forward
+                                        // kernel (value = optimizer steps of the coming training phase), not after the target kernels
     bool ys_ahead = false;       // a side-stream featurization of ys is in flight / complete
     // parameters
     float *d_theta = nullptr, *d_grad = nullptr, *d_m = nullptr, *d_v = nullptr;
@@ -639,6 +641,15 @@ static void featurize_ys_beside_training(isk_engine* e, long long train_launch_s
     e->ys_ahead = true;
 }
 
+// The throttled featurizer is the longer branch of [training || featurizer]: start it right behind the forward kernel,
+// beside the (tiny, latency-bound) K-mean / target kernels, instead of after them.
+static void side_featurize_hook(isk_engine* e) {
+    if (e->side_after_forward > 0) {
+        featurize_ys_beside_training(e, e->side_after_forward);
+        e->side_after_forward = 0;
+    }
+}
+
 static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_t D, int64_t K, int64_t N, hipMemcpyKind kind) {
     if (!e || !xs || !ys) return fail(ISK_EINVAL, "null argument");
     if (D != e->Din) return fail(ISK_EINVAL, "coordinate dimension does not match the featurizer / model input");
@@ -1162,6 +1173,7 @@ static int compute_target(isk_engine* e, bool check, bool ahead = false) {
         return fail(ISK_EINVAL, "host-side target transform: compute it from isk_chis / isk_koopman and pass it to isk_train_batch");
     if (e->cfg.target_kind == ISK_TARGET_SHIFTSCALE) {
         CHK(forward_resident(e, 1, ahead));
+        side_featurize_hook(e);
         ScopedTimer t(e, ISK_T_TARGET);
         launch_kmean(e);
         isk_launch_minmax(e->d_ks, e->N, e->d_mm, e->stream);
@@ -1175,6 +1187,7 @@ static int compute_target(isk_engine* e, bool check, bool ahead = false) {
     // iteration never leaves the device (the reference pulls chi and ks to the host here,
     // src/isotarget.jl:101,103)
     CHK(forward_resident(e, 3, ahead));
+    side_featurize_hook(e);
     ScopedTimer t(e, ISK_T_TARGET);
     launch_kmean(e);
     IsaArgs ia;
@@ -1626,12 +1639,20 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
     for (int it = 0; it < n; ++it) {
         if (epochs > 0) CHK(stage_perm_ahead(e, perms ? perms + k * e->N : nullptr));
         if (e->cfg.featurize_every_iteration) featurize_resident(e);
-        // the constant-chi check needs the device status word; it is read together with the loss
-        CHK(compute_target(e, false, e->cfg.featurize_every_iteration != 0));
         {
             const int mb = e->cfg.minibatch;
             const long long bs = (mb == 0 || e->N < mb) ? e->N : mb;
-            featurize_ys_beside_training(e, (e->N / bs) * epochs);
+            static const int early = [] { const char* v = getenv("ISK_SIDE_EARLY"); return v ? atoi(v) : 1; }();
+            e->side_after_forward = early ? (e->N / bs) * epochs : 0;
+        }
+        // the constant-chi check needs the device status word; it is read together with the loss
+        const int tr = compute_target(e, false, e->cfg.featurize_every_iteration != 0);
+        e->side_after_forward = 0;
+        CHK(tr);
+        {
+            const int mb = e->cfg.minibatch;
+            const long long bs = (mb == 0 || e->N < mb) ? e->N : mb;
+            featurize_ys_beside_training(e, (e->N / bs) * epochs);          // no-op when the hook already launched it
         }
         for (int ep = 0; ep < epochs; ++ep) {
             double l = 0;
@@ -1909,6 +1930,7 @@ static int dp_target_native(isk_engine* e) {
     if (e->cfg.featurize_every_iteration) featurize_resident(e);
     if (e->cfg.target_kind == ISK_TARGET_SHIFTSCALE) {
         CHK(forward_resident(e, 1, e->cfg.featurize_every_iteration != 0));
+        side_featurize_hook(e);
         ScopedTimer t(e, ISK_T_TARGET);
         launch_kmean(e);
         isk_launch_minmax(e->d_ks, e->N, e->d_mm, e->stream);
@@ -1923,6 +1945,7 @@ static int dp_target_native(isk_engine* e) {
     }
     if (e->cfg.target_kind != ISK_TARGET_ISA) return fail(ISK_EINVAL, "host-side target transform: no native data-parallel run");
     CHK(forward_resident(e, 3, e->cfg.featurize_every_iteration != 0));
+    side_featurize_hook(e);
     ScopedTimer t(e, ISK_T_TARGET);
     launch_kmean(e);
     const float* ks = e->d_ks;
@@ -1974,7 +1997,10 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
     long long k = 0;
     for (int it = 0; it < n; ++it) {
         if (epochs > 0) CHK(stage_perm_ahead(e, perms + k * e->N));
-        CHK(dp_target_native(e));
+        e->side_after_forward = (long long)nbatches * epochs;
+        const int tr = dp_target_native(e);
+        e->side_after_forward = 0;
+        CHK(tr);
         featurize_ys_beside_training(e, (long long)nbatches * epochs);
         for (int ep = 0; ep < epochs; ++ep) {
             if (ep == 0) {
