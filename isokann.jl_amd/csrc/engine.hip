@@ -1637,8 +1637,10 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
     if (n < 0 || epochs < 0) return fail(ISK_EINVAL, "negative iteration count");
     long long k = 0;
     for (int it = 0; it < n; ++it) {
-        if (epochs > 0) CHK(stage_perm_ahead(e, perms ? perms + k * e->N : nullptr));
+        // launch order = what the GPU can start first: the xs featurization (it runs under the tail of the side-stream ys
+        // featurization) goes out before the host spends ~50 us drawing and staging the epoch's shuffle order
         if (e->cfg.featurize_every_iteration) featurize_resident(e);
+        if (epochs > 0) CHK(stage_perm_ahead(e, perms ? perms + k * e->N : nullptr));
         {
             const int mb = e->cfg.minibatch;
             const long long bs = (mb == 0 || e->N < mb) ? e->N : mb;
@@ -1924,10 +1926,9 @@ static bool dp_collectives(const isk_engine* e) {
     return e->comm != nullptr && (e->dp_world > 1 || force);
 }
 
-static int dp_target_native(isk_engine* e) {
+static int dp_target_native(isk_engine* e) {            // the caller has run featurize_resident
     const int d = e->nout;
     const bool coll = dp_collectives(e);
-    if (e->cfg.featurize_every_iteration) featurize_resident(e);
     if (e->cfg.target_kind == ISK_TARGET_SHIFTSCALE) {
         CHK(forward_resident(e, 1, e->cfg.featurize_every_iteration != 0));
         side_featurize_hook(e);
@@ -1996,6 +1997,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
     const size_t red_count = (size_t)(nslab - 1) * (e->nparams + 2) + (size_t)e->nparams + 1;
     long long k = 0;
     for (int it = 0; it < n; ++it) {
+        if (e->cfg.featurize_every_iteration) featurize_resident(e);      // first: see isk_run
         if (epochs > 0) CHK(stage_perm_ahead(e, perms + k * e->N));
         e->side_after_forward = (long long)nbatches * epochs;
         const int tr = dp_target_native(e);
