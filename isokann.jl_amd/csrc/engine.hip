@@ -574,6 +574,7 @@ static void featurize_rows(isk_engine* e, const float* in, long long S, float* x
 // per-iteration featurization.  ys (the 95 % share) may already have been produced on the side
 // stream, into the other buffer of the pair, while the previous iteration's MFMA-bound forward was
 // running; then the main stream only waits for it and swaps buffers.
+static void fold_ahead(isk_engine* e);
 static void featurize_resident(isk_engine* e) {
     if (e->ys_ahead) {
         // the xs rows of the other buffer do not depend on the side stream: featurize them BEFORE waiting for it, so
@@ -584,6 +585,7 @@ static void featurize_resident(isk_engine* e) {
             ScopedTimer t(e, ISK_T_FEATURIZE);
             featurize_rows(e, e->d_in_xs, e->N, e->d_xhat + (long long)e->N * e->K * e->Fp);
         }
+        fold_ahead(e);                  // the weight planes of the coming forward: also ahead of the wait
         (void)hipStreamWaitEvent(e->stream, e->ev_ys_ready, 0);
         return;
     } else {
@@ -803,6 +805,15 @@ extern "C" int isk_chicoords(isk_engine* e, const float* coords, int64_t D, int6
 // ---------------------------------------------------------------------------------------
 // bf16 planes per f32 operand of the layer-1 / dense-block forward GEMM: 0 = f32 MFMA, 3 = split-bf16, 1 = plain bf16
 static int bf16_planes(const isk_engine* e) { return e->cfg.forward_mode == 1 ? 3 : (e->cfg.forward_mode == 2 ? 1 : 0); }
+
+// fused networks: refresh the bf16 weight planes now (launch_forward would do it lazily, i.e. behind whatever the
+// stream is about to wait for)
+static void fold_ahead(isk_engine* e) {
+    const int planes = bf16_planes(e);
+    if (e->layered || !planes || !e->w16_dirty) return;
+    isk_launch_fold_bf16(e->d_Wt[0], e->d_W16, e->Fp, isk_pad16(e->cfg.widths[1]) / 16, planes, e->stream);
+    e->w16_dirty = false;
+}
 
 // layer-by-layer forward: every layer is a sequence of dense-block launches of the same GEMM kernels; hidden
 // activations [S][pad32(H)] ping-pong between actA / actB (zero-initialised: the padding columns stay 0)

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeatArgs a) {
 #define FEAT_LD(p) (*(p))
 #define FEAT_ST(p, v) (*(p) = (v))
 #endif
-template <int NFL, int NDL, bool PDIST>
+template <int NFL, int NDL, bool PDIST, int PF = 1>
 __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const unsigned* __restrict__ packed_pairs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -122,19 +122,22 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
     const float invF = 1.0f / (float)a.F;
     const long long nw = (long long)gridDim.x * 4;
     long long s = (long long)blockIdx.x * 4 + wave;
-    // software pipeline: the NEXT sample's row (NDL or NFL dwords per lane) is in flight in registers while
+    // software pipeline: the next PF samples' rows (NDL or NFL dwords per lane each) are in flight in registers while
     // the current one is featurized, so a wave keeps HBM busy on its own (needed when the kernel runs
     // throttled beside the training kernels)
-    float nxt[PDIST ? NDL : NFL];
-    if (s < a.S) {
-        const float* row = a.in + s * (long long)a.D;
+    constexpr int NIN = PDIST ? NDL : NFL;
+    float nxt[PF][NIN];
+    auto fetch = [&](float (&buf)[NIN], long long srow) {
+        if (srow < a.S) {                                    // wave-uniform
+            const float* row = a.in + srow * (long long)a.D;
 #pragma unroll
-        for (int u = 0; u < (PDIST ? NDL : NFL); ++u) {
-            const int i = 64 * u + lane;
-            nxt[u] = (i < a.D) ? FEAT_LD(row + i) : 0.f;
+            for (int u = 0; u < NIN; ++u) {
+                const int i = 64 * u + lane;
+                buf[u] = (i < a.D) ? FEAT_LD(row + i) : 0.f;
+            }
         }
-    }
-    for (; s < a.S; s += nw) {
+    };
+    auto one = [&](float (&buf)[NIN], long long srow) {
         float d[NFL];
         if (PDIST) {
 #pragma unroll
@@ -142,21 +145,14 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
                 const int i = 64 * u + lane;
                 if (i < a.D) {
                     const int at = i / 3;
-                    ((float*)cw)[4 * at + (i - 3 * at)] = nxt[u];
+                    ((float*)cw)[4 * at + (i - 3 * at)] = buf[u];
                 }
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NFL; ++i) d[i] = nxt[i];
+            for (int i = 0; i < NFL; ++i) d[i] = buf[i];
         }
-        if (s + nw < a.S) {                                  // wave-uniform: prefetch the next sample
-            const float* row = a.in + (s + nw) * (long long)a.D;
-#pragma unroll
-            for (int u = 0; u < (PDIST ? NDL : NFL); ++u) {
-                const int i = 64 * u + lane;
-                nxt[u] = (i < a.D) ? FEAT_LD(row + i) : 0.f;
-            }
-        }
+        fetch(buf, srow + PF * nw);                          // refill this slot: the sample PF trips ahead
         if (PDIST) {
             __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes have landed
             __builtin_amdgcn_wave_barrier();
@@ -186,21 +182,28 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
             else if (a.ln_mode == ISK_LN_STD_EPS) rstd = 1.0f / (sqrtf(var) + a.eps);
             else rstd = 1.0f / sqrtf(var + a.eps);
         }
-        float* orow = a.xhat + s * (long long)a.Fp;
+        float* orow = a.xhat + srow * (long long)a.Fp;
 #pragma unroll
         for (int i = 0; i < NFL; ++i) {
             const int f = lane + 64 * i;
             if (f < a.Fp) FEAT_ST(orow + f, (f < a.F) ? (d[i] - mu) * rstd : 0.f);
         }
         if (a.raw) {                                         // wave-uniform: kept for the coordinate pullback
-            float* rrow = a.raw + s * (long long)a.Fp;
+            float* rrow = a.raw + srow * (long long)a.Fp;
 #pragma unroll
             for (int i = 0; i < NFL; ++i) {
                 const int f = lane + 64 * i;
                 if (f < a.Fp) rrow[f] = (f < a.F) ? d[i] : 0.f;
             }
         }
-        if (a.stats && lane == 0) { a.stats[2 * s] = mu; a.stats[2 * s + 1] = rstd; }
+        if (a.stats && lane == 0) { a.stats[2 * srow] = mu; a.stats[2 * srow + 1] = rstd; }
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) fetch(nxt[p], s + p * nw);
+    for (; s < a.S; s += PF * nw) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+            if (s + p * nw < a.S) one(nxt[p], s + p * nw);
     }
 }
 
@@ -223,9 +226,14 @@ static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream
     if (a.background && bg_total > 0) cap = bg_total;          // tuning knob: background workgroups in total
     if (blocks > cap) blocks = cap;
     if (pd) {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)featurize_reg_kernel<NFL, NDL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((featurize_reg_kernel<NFL, NDL, true>), dim3((unsigned)blocks), dim3(256), lds, st, a, packed);
+        // background launches keep two samples in flight per wave (ISK_FEAT_PF=1: one).  Measured on C3, same box:
+        // 1.554 -> 1.533 ms/step; three in flight: 1.558
+        static const int pf = [] { const char* v = getenv("ISK_FEAT_PF"); return v ? atoi(v) : 2; }();
+        const void* fn = (const void*)featurize_reg_kernel<NFL, NDL, true, 1>;
+        if (a.background && pf == 2) fn = (const void*)featurize_reg_kernel<NFL, NDL, true, 2>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        void* args[] = {(void*)&a, (void*)&packed};
+        (void)hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), args, lds, st);
     } else {
         hipLaunchKernelGGL((featurize_reg_kernel<NFL, 1, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, packed);
     }
