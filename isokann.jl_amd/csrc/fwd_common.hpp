@@ -12,6 +12,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// the same sum over the 64 lanes without LDS traffic: DPP row shifts (inclusive scan inside each row of 16), then
+// row_bcast:15 / row_bcast:31 carry the row totals up; lane 63 holds the total, read back as a wave-uniform scalar.
+// 8 VALU instructions instead of 6 ds_bpermute round trips (used where a wave runs alone on its SIMD).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define ISK_DPP_ADD(ctrl, rmask)                                                                                   \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+    ISK_DPP_ADD(0x111, 0xf);      // row_shr:1
+    ISK_DPP_ADD(0x112, 0xf);      // row_shr:2
+    ISK_DPP_ADD(0x114, 0xf);      // row_shr:4
+    ISK_DPP_ADD(0x118, 0xf);      // row_shr:8
+    ISK_DPP_ADD(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+    ISK_DPP_ADD(0x143, 0xc);      // row_bcast:31 into rows 2 and 3
+#undef ISK_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ float act_apply(int act, float z) {
     switch (act) {
         case ISK_ACT_SIGMOID: {

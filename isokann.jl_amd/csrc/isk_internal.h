@@ -209,3 +209,10 @@ struct VjpArgs {
     int D, F, Fp, H1, H1p, ln_mode;
 };
 void isk_launch_vjp_back(const VjpArgs& a, hipStream_t st);
+
+// The kernels of the target and of the training steps are short, dependent launches with small grids; the next
+// iteration's featurizer runs beside them (side stream, one workgroup per CU) and its waves are busy with VALU / LDS work
+// nearly every cycle.  Sharing a SIMD with one of them on equal terms doubled the length of a training step (60 -> 112 us
+// on C3), so the latency-chain kernels raise their wave priority: the SIMD's issue arbiter serves them first and the
+// featurizer fills the cycles they leave.
+#define ISK_LATENCY_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)

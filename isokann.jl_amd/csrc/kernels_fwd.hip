@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeatArgs a) {
 // sample per wave per trip, NO workgroup barrier.  Each lane keeps its <= NFL (packed 16-bit)
 // atom pairs and its NFL distances in registers across the whole sample loop; the sample's
 // coordinates are staged in a wave-private LDS region padded to xyzw so a pair costs two
-// ds_read_b128; mean / variance by wavefront shuffles; the standardised row goes out as
-// coalesced 256-B store instructions.
+// ds_read_b96, kept several pairs deep in flight; mean / variance by DPP wavefront reductions; the standardised row
+// goes out as coalesced 256-B buffer stores.
 // -------------------------------------------------------------------------------------
 // the coordinate reads and feature writes are pure streams (1.4 GB each per iteration): non-temporal, so they do not
 // evict what the latency-bound training kernels keep re-reading (xs features, weights) from L2 / MALL -- measured:
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeatArgs a) {
 #ifndef ISK_FEAT_NT
 #define ISK_FEAT_NT 1
 #endif
+#define FEAT_AUX (ISK_FEAT_NT ? 2 : 0)         /* buffer-instruction cache policy: nt */
 #if ISK_FEAT_NT
 #define FEAT_LD(p) __builtin_nontemporal_load(p)
 #define FEAT_ST(p, v) __builtin_nontemporal_store((v), (p))
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeatArgs a) {
 template <int NFL, int NDL, bool PDIST, int PF = 1>
 __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const unsigned* __restrict__ packed_pairs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int natoms = a.D / 3;
     f32x4* cw = (f32x4*)smem + (size_t)wave * natoms;        // wave-private xyzw coordinates
     unsigned pr[NFL];
@@ -127,15 +128,18 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
     // throttled beside the training kernels)
     constexpr int NIN = PDIST ? NDL : NFL;
     float nxt[PF][NIN];
+    // Rows are read and written through BUFFER instructions: a wave-uniform descriptor per row whose size is the
+    // row length (0 for a row past the end), so lanes beyond the row read 0 and their stores are dropped by the
+    // hardware.  That keeps the loop free of branches around memory instructions -- with them hipcc's wait-count
+    // pass can only emit vmcnt(0), which made every wave sit out a full load + store round trip per sample (the
+    // "prefetched" row included).
+    auto row_rsrc = [&](const float* base, long long srow, long long ld, int len) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + srow * ld), 0, srow < a.S ? len * 4 : 0, 0x00020000);
+    };
     auto fetch = [&](float (&buf)[NIN], long long srow) {
-        if (srow < a.S) {                                    // wave-uniform
-            const float* row = a.in + srow * (long long)a.D;
+        const __amdgpu_buffer_rsrc_t r = row_rsrc(a.in, srow, a.D, a.D);
 #pragma unroll
-            for (int u = 0; u < NIN; ++u) {
-                const int i = 64 * u + lane;
-                buf[u] = (i < a.D) ? FEAT_LD(row + i) : 0.f;
-            }
-        }
+        for (int u = 0; u < NIN; ++u) buf[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (64 * u + lane) * 4, 0, FEAT_AUX));
     };
     auto one = [&](float (&buf)[NIN], long long srow) {
         float d[NFL];
@@ -156,13 +160,23 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
         if (PDIST) {
             __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes have landed
             __builtin_amdgcn_wave_barrier();
+            // the gathers are kept GW pairs deep in flight (a rolling register window, order pinned): left to itself
+            // the compiler waits out the full LDS latency of every pair, 28 times per sample
+            constexpr int GW = NFL < 6 ? NFL : 6;
+            typedef float f32x3 __attribute__((ext_vector_type(3)));     // 16-byte cells, xyz read (ds_read_b96)
+            const f32x3* cw3 = (const f32x3*)cw;
+            f32x3 qa[GW], qb[GW];
+#pragma unroll
+            for (int i = 0; i < GW; ++i) { qa[i] = cw3[pr[i] & 0xffffu]; qb[i] = cw3[pr[i] >> 16]; }
 #pragma unroll
             for (int i = 0; i < NFL; ++i) {
-                const f32x4 pa = cw[pr[i] & 0xffffu];
-                const f32x4 pb = cw[pr[i] >> 16];
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x3 pa = qa[i % GW], pb = qb[i % GW];
                 const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+                if (i + GW < NFL) { qa[i % GW] = cw3[pr[i + GW] & 0xffffu]; qb[i % GW] = cw3[pr[i + GW] >> 16]; }
                 d[i] = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
             }
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_wave_barrier();             // all reads issued before the next trip's writes
         }
         float mu = 0.f, rstd = 1.f;
@@ -170,40 +184,39 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < NFL; ++i) sum += (lane + 64 * i < a.F) ? d[i] : 0.f;
-            mu = wave_sum(sum) * invF;
+            mu = wave_sum_dpp(sum) * invF;
             float ss = 0.f;
 #pragma unroll
             for (int i = 0; i < NFL; ++i) {
                 const float t = d[i] - mu;
                 ss += (lane + 64 * i < a.F) ? t * t : 0.f;
             }
-            const float var = wave_sum(ss) * invF;
+            const float var = wave_sum_dpp(ss) * invF;
             if (a.ln_mode == ISK_LN_VAR_EPS2) rstd = 1.0f / sqrtf(var + a.eps * a.eps);
             else if (a.ln_mode == ISK_LN_STD_EPS) rstd = 1.0f / (sqrtf(var) + a.eps);
             else rstd = 1.0f / sqrtf(var + a.eps);
         }
-        float* orow = a.xhat + srow * (long long)a.Fp;
+        const __amdgpu_buffer_rsrc_t ro = row_rsrc(a.xhat, srow, a.Fp, a.Fp);
 #pragma unroll
         for (int i = 0; i < NFL; ++i) {
             const int f = lane + 64 * i;
-            if (f < a.Fp) FEAT_ST(orow + f, (f < a.F) ? (d[i] - mu) * rstd : 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (f < a.F) ? (d[i] - mu) * rstd : 0.f), ro, f * 4, 0, FEAT_AUX);
         }
         if (a.raw) {                                         // wave-uniform: kept for the coordinate pullback
-            float* rrow = a.raw + srow * (long long)a.Fp;
+            const __amdgpu_buffer_rsrc_t rr = row_rsrc(a.raw, srow, a.Fp, a.Fp);
 #pragma unroll
             for (int i = 0; i < NFL; ++i) {
                 const int f = lane + 64 * i;
-                if (f < a.Fp) rrow[f] = (f < a.F) ? d[i] : 0.f;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (f < a.F) ? d[i] : 0.f), rr, f * 4, 0, 0);
             }
         }
-        if (a.stats && lane == 0) { a.stats[2 * srow] = mu; a.stats[2 * srow + 1] = rstd; }
+        if (a.stats && lane == 0 && srow < a.S) { a.stats[2 * srow] = mu; a.stats[2 * srow + 1] = rstd; }
     };
 #pragma unroll
     for (int p = 0; p < PF; ++p) fetch(nxt[p], s + p * nw);
-    for (; s < a.S; s += PF * nw) {
+    for (; s < a.S; s += PF * nw) {              // rows past the end (last trip) run on empty descriptors
 #pragma unroll
-        for (int p = 0; p < PF; ++p)
-            if (s + p * nw < a.S) one(nxt[p], s + p * nw);
+        for (int p = 0; p < PF; ++p) one(nxt[p], s + p * nw);
     }
 }
 
@@ -228,7 +241,7 @@ static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream
     if (pd) {
         // background launches keep two samples in flight per wave (ISK_FEAT_PF=1: one).  Measured on C3, same box:
         // 1.554 -> 1.533 ms/step; three in flight: 1.558
-        static const int pf = [] { const char* v = getenv("ISK_FEAT_PF"); return v ? atoi(v) : 2; }();
+        static const int pf = [] { const char* v = getenv("ISK_FEAT_PF"); return v ? atoi(v) : 1; }();
         const void* fn = (const void*)featurize_reg_kernel<NFL, NDL, true, 1>;
         if (a.background && pf == 2) fn = (const void*)featurize_reg_kernel<NFL, NDL, true, 2>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -285,6 +298,7 @@ void isk_launch_featurize(const FeatArgs& a, hipStream_t st) {
 // standardised rows directly.
 // =====================================================================================
 __global__ __launch_bounds__(256) void fold_kernel(FoldArgs a) {
+    ISK_LATENCY_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float tile[];     // [16][Np + 1]
     const int layer = blockIdx.y;
     if (layer >= a.nlayers) return;
@@ -520,6 +534,7 @@ int isk_launch_mlp_fwd(const MlpFwdArgs& a, hipStream_t st) {
 // start, then a shuffle reduction combines lanes that hold the same output index o.
 // =====================================================================================
 __global__ __launch_bounds__(256) void kmean_kernel(KmeanArgs a) {
+    ISK_LATENCY_CHAIN_PRIO();
     const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (n >= a.N) return;
@@ -548,6 +563,7 @@ void isk_launch_kmean(const KmeanArgs& a, hipStream_t st) {
 
 // min / max over n values: single workgroup, wavefront shuffles + one LDS exchange
 __global__ __launch_bounds__(1024) void minmax_kernel(const float* v, long long n, float* mm) {
+    ISK_LATENCY_CHAIN_PRIO();
     __shared__ float smin[16], smax[16];
     float lo = INFINITY, hi = -INFINITY;
     bool nan = false;
@@ -583,6 +599,7 @@ void isk_launch_minmax(const float* v, long long n, float* mm, hipStream_t st) {
 
 __global__ __launch_bounds__(256) void shiftscale_kernel(const float* ks, const float* mm, float* target, long long n,
                                                          int* status) {
+    ISK_LATENCY_CHAIN_PRIO();
     const float lo = mm[0], hi = mm[1];
     const bool ok = hi > lo;                       // false for NaN too (src/isotarget.jl:39)
     if (!ok && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(status, 1);
@@ -600,6 +617,7 @@ void isk_launch_shiftscale(const float* ks, const float* mm, float* target, long
 
 __global__ __launch_bounds__(256) void isa_apply_kernel(const float* ks, const float* At, const int* rowperm, float* target,
                                                         long long N, int d) {
+    ISK_LATENCY_CHAIN_PRIO();
     const long long tot = N * d;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
         const long long n = e / d;

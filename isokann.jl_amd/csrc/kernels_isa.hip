@@ -102,6 +102,7 @@ __device__ __forceinline__ void write_partial_argmax(double bv, long long bi, co
 // ---- k0: X = Float64(ks'), finiteness; norms -> partial argmax, or whitening moments -------------------
 template <int D>
 __global__ __launch_bounds__(ISA_T) void isa_init_kernel(IsaArgs a, double* __restrict__ P, double* __restrict__ Pm) {
+    ISK_LATENCY_CHAIN_PRIO();
     __shared__ double shd[ISA_MAXD * ISA_MAXD * (ISA_T / 64)];
     __shared__ long long shi[ISA_T / 64];
     const long long N = a.N;
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(ISA_T) void isa_init_kernel(IsaArgs a, double* __re
 template <int D>
 __global__ __launch_bounds__(ISA_T) void isa_whiten_kernel(IsaArgs a, const double* __restrict__ Pm, int G,
                                                            double* __restrict__ P) {
+    ISK_LATENCY_CHAIN_PRIO();
     __shared__ double shd[ISA_MAXD * ISA_MAXD * (ISA_T / 64)];
     __shared__ long long shi[ISA_T / 64];
     __shared__ double Wm[D * D];
@@ -250,6 +252,7 @@ __global__ __launch_bounds__(ISA_T) void isa_whiten_kernel(IsaArgs a, const doub
 template <int D>
 __global__ __launch_bounds__(ISA_T) void isa_step_kernel(IsaArgs a, int j, const double* __restrict__ Pin, int G,
                                                          double* __restrict__ Pout, int* __restrict__ ind) {
+    ISK_LATENCY_CHAIN_PRIO();
     __shared__ double shd[ISA_MAXD * ISA_MAXD * (ISA_T / 64)];
     __shared__ long long shi[ISA_T / 64];
     __shared__ double vrow[D];
@@ -301,6 +304,7 @@ __global__ __launch_bounds__(ISA_T) void isa_step_kernel(IsaArgs a, int j, const
 template <int D>
 __global__ __launch_bounds__(ISA_T) void isa_target_kernel(IsaArgs a, const double* __restrict__ Pin, int G,
                                                            int* __restrict__ ind, double* __restrict__ Pc) {
+    ISK_LATENCY_CHAIN_PRIO();
     __shared__ double shd[ISA_MAXD * ISA_MAXD * (ISA_T / 64)];
     __shared__ long long shi[ISA_T / 64];
     __shared__ double vrow[D];
@@ -398,6 +402,7 @@ __global__ __launch_bounds__(ISA_T) void isa_target_kernel(IsaArgs a, const doub
 template <int D>
 __global__ __launch_bounds__(ISA_T) void isa_perm_kernel(IsaArgs a, const double* __restrict__ Pc, int G,
                                                          double* __restrict__ Pmom) {
+    ISK_LATENCY_CHAIN_PRIO();
     __shared__ double shd[ISA_MAXD * ISA_MAXD * (ISA_T / 64)];
     __shared__ double Cst[D * D];
     __shared__ int rperm[D];
@@ -478,6 +483,7 @@ __global__ __launch_bounds__(ISA_T) void isa_perm_kernel(IsaArgs a, const double
 
 template <int D>
 __global__ __launch_bounds__(64) void isa_weights_kernel(IsaArgs a, const double* __restrict__ Pmom, int G) {
+    ISK_LATENCY_CHAIN_PRIO();
     const int i = threadIdx.x;
     if (i >= D) return;
     double s1 = 0, s2 = 0;

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(FW1_WAVES * 64) void train_fwd1_kernel(const float*
                                                                    const float* __restrict__ bias1, int nt1,
                                                                    const int* __restrict__ perm, int B,
                                                                    float* __restrict__ z1) {
+    ISK_LATENCY_CHAIN_PRIO();
     __shared__ float red[FW1_WAVES][256];
     // blocks are dealt round-robin over the 8 XCDs (b % 8 shares an XCD): give every XCD whole units,
     // so a unit's gathered xhat rows are fetched into ONE L2 and re-read there by its nt1 tile blocks
@@ -154,6 +155,7 @@ __host__ __device__ static inline int tail_off_w(const TrainShape& s, int l) {
 #define TAIL_THREADS 1024
 __global__ __launch_bounds__(TAIL_THREADS) void train_tail_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm,
                                                                   int B, float inv_div) {
+    ISK_LATENCY_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float lred[TAIL_THREADS / 64];
     constexpr int NTH = TAIL_THREADS;
@@ -342,6 +344,7 @@ __device__ __forceinline__ long long part_to_grad(const TrainShape& s, long long
 template <int NT, int NW>
 __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm,
                                                              int B, int nparts) {
+    ISK_LATENCY_CHAIN_PRIO();
     constexpr int NB4 = NT / 4, NR = NT % 4;
     constexpr int CB = 4;                          // chunks per batch: their row indices are fetched together
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -514,6 +517,7 @@ void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const in
 // The batch loss sits in grad[n]; a non-finite loss (or an earlier one in this epoch) skips the
 // update, as the reference throws before update! (src/iso.jl:186-189).
 __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a, double* loss_acc) {
+    ISK_LATENCY_CHAIN_PRIO();
     const float lstep = a.grad[a.n];
     const bool bad = (loss_acc[1] != 0.0) || !isfinite(lstep);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
