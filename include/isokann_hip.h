@@ -237,7 +237,8 @@ int  isk_dp_epoch_end(isk_engine* e, double* loss_sum);
  *       ISA: all-gather of the ks / chi slices, every rank runs the Float64 simplex kernels on the gathered arrays;
  *       per optimizer step: ONE in-place all-reduce(sum) of the flat [gradient slabs | batch loss] buffer.
  *       Shards must be equal (N the same on every rank).  perms: (n*epochs, N) shuffles of the LOCAL shard, of
- *       which the first nbatches*local_batch entries are used; losses[k] = sum of the reduced batch losses of
+ *       which the first nbatches*local_batch entries are used (NULL: the engine draws them from its seeded generator,
+ *       like isk_run, while the forward runs); losses[k] = sum of the reduced batch losses of
  *       epoch k (divide by the global N for train_batch!'s return value, src/iso.jl:193).
  * Without isk_dp_comm_init (or with world == 1) isk_dp_run runs the same code without collectives. */
 int  isk_dp_comm_id(uint8_t id[128]);

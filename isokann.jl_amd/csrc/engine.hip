@@ -104,6 +104,7 @@ struct isk_engine {
     // side stream: the (weight-independent) ys featurization of the NEXT iteration runs here,
     // concurrently with the latency-bound training kernels of the current one
     hipStream_t side = nullptr;
+    hipStream_t copy = nullptr;       // small H2D staging (the epoch's shuffle order): never queued behind the side-stream featurizer
     hipEvent_t ev_fwd_done = nullptr, ev_ys_ready = nullptr;
     long long side_after_forward = 0;   // isk_run / isk_dp_run: launch the side-stream ys featurization right behind the forward
                                         // kernel (value = optimizer steps of the coming training phase), not after the target kernels
@@ -408,6 +409,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     if (se != hipSuccess) { delete e; return fail(ISK_EHIP, hipGetErrorString(se)); }
     e->own_stream = true;
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->copy, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fwd_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_ys_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_perm, hipEventDisableTiming) != hipSuccess) {
@@ -468,6 +470,7 @@ extern "C" void isk_destroy(isk_engine* e) {
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->side) (void)hipStreamSynchronize(e->side);
+    if (e->copy) (void)hipStreamSynchronize(e->copy);
     free_data(e);
     free_dev(e->d_theta); free_dev(e->d_grad); free_dev(e->d_m); free_dev(e->d_v);
     free_dev(e->d_loss_acc); free_dev(e->d_status); free_dev(e->d_mm); free_dev(e->d_lossw);
@@ -486,6 +489,7 @@ extern "C" void isk_destroy(isk_engine* e) {
     if (e->ev_perm) (void)hipEventDestroy(e->ev_perm);
     if (e->h_res) (void)hipHostFree(e->h_res);
     if (e->side) (void)hipStreamDestroy(e->side);
+    if (e->copy) (void)hipStreamDestroy(e->copy);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1571,8 +1575,8 @@ static int stage_perm_ahead(isk_engine* e, const int32_t* perm) {
         shuffle_perm(e, p);
         std::memcpy(e->h_perm, p.data(), (size_t)N * sizeof(int));
     }
-    HIPCHK(hipMemcpyAsync(e->d_perm, e->h_perm, (size_t)N * sizeof(int), hipMemcpyHostToDevice, e->side));
-    HIPCHK(hipEventRecord(e->ev_perm, e->side));
+    HIPCHK(hipMemcpyAsync(e->d_perm, e->h_perm, (size_t)N * sizeof(int), hipMemcpyHostToDevice, e->copy));
+    HIPCHK(hipEventRecord(e->ev_perm, e->copy));
     return ISK_OK;
 }
 
@@ -1986,7 +1990,6 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
     if (n < 0 || epochs < 0) return fail(ISK_EINVAL, "negative iteration count");
     if (local_batch < 1 || nbatches < 1 || (long long)local_batch * nbatches > e->N || global_batch < local_batch)
         return fail(ISK_EINVAL, "bad batch decomposition");
-    if (!perms && epochs > 0 && n > 0) return fail(ISK_EINVAL, "the data-parallel run takes the shuffle orders from the host");
     const bool coll = dp_collectives(e);
     if (coll && e->dp_checked_N != e->N) {          // equal shards: the gathered ISA arrays and the step count assume it (checked once)
         long long* d_n = nullptr;
@@ -2009,17 +2012,21 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
     long long k = 0;
     for (int it = 0; it < n; ++it) {
         if (e->cfg.featurize_every_iteration) featurize_resident(e);      // first: see isk_run
-        if (epochs > 0) CHK(stage_perm_ahead(e, perms + k * e->N));
         e->side_after_forward = (long long)nbatches * epochs;
         const int tr = dp_target_native(e);
         e->side_after_forward = 0;
         CHK(tr);
+        // the shuffle order (drawn here from the engine's seeded generator when the host passes none: ~50 us of host
+        // work) is staged while the forward runs
+        if (epochs > 0) CHK(stage_perm_ahead(e, perms ? perms + k * e->N : nullptr));
         featurize_ys_beside_training(e, (long long)nbatches * epochs);
         for (int ep = 0; ep < epochs; ++ep) {
             if (ep == 0) {
                 HIPCHK(hipStreamWaitEvent(e->stream, e->ev_perm, 0));
             } else {
-                const int32_t* p = perms + k * e->N;
+                std::vector<int32_t> drawn;
+                const int32_t* p = perms ? perms + k * e->N : nullptr;
+                if (!p) { drawn.resize(e->N); shuffle_perm(e, drawn); p = drawn.data(); }
                 for (long long i = 0; i < e->N; ++i)
                     if (p[i] < 0 || p[i] >= e->N) return fail(ISK_EINVAL, "permutation entry out of range");
                 std::memcpy(e->h_perm, p, (size_t)e->N * sizeof(int));
