@@ -177,6 +177,20 @@ def main():
         def barrier():
             dist.barrier()
 
+    if use_dp and world > 1:
+        # safety valve for the first step on a real multi-GPU node: if the engine-driven RCCL run raises (on every rank alike:
+        # e.g. a communicator that cannot be used), agree on it and continue on the host-driven torch.distributed hooks
+        import torch
+        failed = 0
+        try:
+            step()
+        except Exception as ex:      # noqa: BLE001
+            failed = 1
+            print(f"[bench] rank {rank}: native data-parallel step failed ({ex}); falling back to host-driven collectives", file=sys.stderr)
+        f = torch.tensor([failed], dtype=torch.int32, device=torch.device("cuda", local_rank))
+        dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        if int(f.item()):
+            local._native_agreed = False
     for _ in range(args.warmup):
         step()
     sync(); barrier(); sync()
