@@ -341,37 +341,39 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldArgs a) {
         }
         return;
     }
-    // bias blocks: one wave per output row
-    const int lane = tid & 63;
-    const int o = ((int)blockIdx.x - nchunks) * 4 + (tid >> 6);
+    // bias blocks: one output row per block, its 4 waves split the feature axis (the column-major W1 makes this a gather
+    // of one element per 64-B segment: the loads are all issued at once, the chain is one memory round trip)
+    const int lane = tid & 63, wv4 = tid >> 6;
+    const int o = (int)blockIdx.x - nchunks;
     if (o >= Np) return;
-    float v = 0.f;
-    if (o < N) {
-        v = b[o];
-        if (ln) {
-            float sacc = 0.f;
-            for (int k0 = 0; k0 < K; k0 += 64 * 8) {
-                float wv[8], bv[8];
+    float sacc = 0.f;
+    if (o < N && ln) {
+        const int per = ((K + 3) / 4 + 63) / 64 * 64;            // features per wave, multiple of 64
+        const int kbeg = wv4 * per, kend = (kbeg + per < K) ? kbeg + per : K;
+        for (int k0 = kbeg; k0 < kend; k0 += 64 * 8) {
+            float wv[8], bv[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int k = k0 + u * 64 + lane;
-                    wv[u] = (k < K) ? W[o + (long long)k * N] : 0.f;
-                    bv[u] = (k < K) ? beta[k] : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) sacc += wv[u] * bv[u];
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * 64 + lane;
+                const int kc = (k < kend) ? k : (kend - 1);      // clamped (branch-free loads), masked below
+                wv[u] = W[o + (long long)kc * N];
+                bv[u] = (k < kend) ? beta[kc] : 0.f;
             }
-            v += wave_sum(sacc);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sacc += wv[u] * bv[u];
         }
+        sacc = wave_sum(sacc);
     }
-    if (lane == 0) a.bias[layer][o] = v;
+    if (lane == 0) tile[wv4] = sacc;
+    __syncthreads();
+    if (tid == 0) a.bias[layer][o] = (o < N) ? b[o] + ((tile[0] + tile[1]) + (tile[2] + tile[3])) : 0.f;
 }
 
 void isk_launch_fold(const FoldArgs& a, hipStream_t st) {
     int bx = 1, maxNp = 16;
     for (int l = 0; l < a.nlayers; ++l) {
         const int Kp = a.Kp[l], Np = isk_pad16(a.widths[l + 1]);
-        bx = bx > (Kp / 16 + Np / 4) ? bx : (Kp / 16 + Np / 4);
+        bx = bx > (Kp / 16 + Np) ? bx : (Kp / 16 + Np);
         maxNp = maxNp > Np ? maxNp : Np;
     }
     const size_t lds = (size_t)16 * (maxNp + 1) * sizeof(float);
