@@ -737,3 +737,26 @@ def test_bf16_forward_every_tile_count(gpu_pkg, mode, monkeypatch):
         kw = O.expectation(om, np.asarray(ys, np.float32).astype(np.float64))
         assert np.abs(pkg.koopman(iso) - kw).max() <= tol * max(1.0, np.abs(kw).max()), widths
         iso.close()
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nout", [1, 3])
+def test_dp_native_engine_drawn_shuffles_match_isk_run(gpu_pkg, nout):
+    """isk_dp_run with perms = NULL draws the shuffle orders from the engine's seeded generator, one per epoch, exactly
+    like isk_run does: with one rank and no communicator the two runs are the same computation"""
+    import importlib
+    pkg = gpu_pkg
+    dp = importlib.import_module("isokann_jl_amd.dp")
+    N, mb = 160, 32
+    data, odata, om = _coords_case(pkg, 16, 40, N, 3, nout, seed=70 + nout)
+    isos = [pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(1e-2, 1e-3), minibatch=mb) for _ in range(2)]
+    pkg.run(isos[0], 3, 2)                                   # engine-drawn shuffles
+    comm = dp.Comm(device=None)
+    assert not comm.on and comm.world == 1
+    local = dp.HipLocal(isos[1])
+    losses = dp.dp_run(local, comm, 3, 2, mb, None)          # rng None -> the engine draws
+    assert len(losses) == 6 and np.all(np.isfinite(losses))
+    np.testing.assert_allclose(losses, isos[0].losses, rtol=2e-5)
+    np.testing.assert_allclose(isos[1].model.get_params(), isos[0].model.get_params(), atol=2e-6, rtol=2e-4)
+    for b in isos:
+        b.close()
+
