@@ -68,6 +68,20 @@ def test_features_pairlist_and_atoms(gpu_pkg):
     iso.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("A,F,N,K", [(600, 1700, 3, 1), (683, 2048, 5, 2), (9, 33, 1030, 1)])
+def test_features_pairlist_edge_shapes(gpu_pkg, A, F, N, K):
+    """rows go through buffer instructions with a per-row descriptor: fewer samples than waves, a feature count that is /
+    is not a multiple of the 64-lane store width, the largest register-resident atom count, more rows than one trip"""
+    pkg = gpu_pkg
+    xs, ys = O.synthetic_coords(A, N, K, seed=A)
+    pairs = O.random_pairs(A, F, seed=5)
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), minibatch=0)
+    np.testing.assert_allclose(pkg.features(iso), O.pdists(np.asarray(xs, np.float64), pairs), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(pkg.propfeatures(iso), O.pdists(np.asarray(ys, np.float64), pairs), rtol=2e-6, atol=1e-7)
+    iso.close()
+
+
 # ------------------------------------------------------------------ forward -----------
 @pytest.mark.parametrize("widths,ln,act", [
     ([2, 2, 1, 1], True, "sigmoid"),            # C1 default net
