@@ -835,8 +835,11 @@ static int forward_layered(isk_engine* e, const float* X, long long S, float* ou
             isk_launch_fold_bf16(e->d_Wt[l], e->d_W16L[l], layer_kp(e, l), nt_total, planes, e->stream);
         // plain bf16 keeps 16 output tiles per workgroup (two launches for a 512-wide layer), the others 8
         const int tb = planes == 1 ? ISK_MAX_NT_BF16 : 8;
-        for (int t0 = 0; t0 < nt_total; t0 += tb) {
-            const int ntb = std::min(tb, nt_total - t0);
+        // equal column blocks of a bf16 layer go out as ONE grouped launch (the sample rows are then read from HBM once
+        // per layer instead of once per column block); ISK_DENSE_GROUPS=0 restores one launch per block
+        static const int grouped = [] { const char* v = getenv("ISK_DENSE_GROUPS"); return v ? atoi(v) : 1; }();
+        const int groups = (grouped && planes && nt_total > tb && nt_total % tb == 0 && nt_total / tb <= 8) ? nt_total / tb : 1;
+        auto launch_block = [&](int t0, int ntb, int ngroups) -> int {
             MlpFwdArgs a;
             std::memset(&a, 0, sizeof(a));
             a.X = in; a.S = S; a.Fp = in_ld; a.nchunks = in_ld / 16;
@@ -844,11 +847,20 @@ static int forward_layered(isk_engine* e, const float* X, long long S, float* ou
             a.act1 = act_of_layer(e, l); a.H1 = N; a.nt1 = ntb; a.ntail = 0;
             a.out = dst; a.nout = out_ld;
             a.dense_mode = 1; a.w_nt_total = nt_total; a.w_tile0 = t0; a.out_ld = out_ld; a.out_col0 = t0 * 16;
+            a.dense_groups = ngroups;
             a.stride_a = ntb * 16 + 4; a.stride_b = 4;
             isk_fwd_layout_biases(a);
             int r = ISK_EUNSUPPORTED;
             if (planes) r = isk_launch_mlp_fwd_bf16x3(a, e->d_W16L[l], planes, e->stream);
-            if (r != 0 && ntb <= ISK_MAX_NT) r = isk_launch_mlp_fwd(a, e->stream);
+            if (r != 0 && ngroups == 1 && ntb <= ISK_MAX_NT) r = isk_launch_mlp_fwd(a, e->stream);     // the f32 kernel: one block per launch
+            return r;
+        };
+        for (int t0 = 0; t0 < nt_total; t0 += tb * groups) {
+            const int ntb = std::min(tb, nt_total - t0);
+            int r = launch_block(t0, ntb, groups);
+            if (r != 0 && groups > 1)
+                for (int g = 0; g < groups; ++g)
+                    if ((r = launch_block(t0 + g * tb, tb, 1)) != 0) break;
             if (r != 0) return r;
         }
         in = dst;

@@ -267,7 +267,7 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
 }
 
 template <int NT, int U, int NWV, bool EARLY, int NPL, bool DENSE>
-__device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __restrict__ W16, float* smem, long long u0, int nact
+__device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __restrict__ W16, float* smem, long long u0, int nact, int col_shift
 #if ISK_STAMP
                                          , unsigned long long (&g_ph)[8], unsigned long long& g_t
 #endif
@@ -311,8 +311,8 @@ __device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __res
 #endif
     // spelled out: with the unit index a loop variable hipcc may decline to unroll the (large) epilogue and then
     // keeps the whole accumulator array in scratch memory
-    if (0 < nact) unit_tail<NT, DENSE>(a, acc[0], u0 * 16, scrA, scrB, smem, lane);
-    if (U > 1 && 1 < nact) unit_tail<NT, DENSE>(a, acc[U - 1], (u0 + 1) * 16, scrA, scrB, smem, lane);
+    if (0 < nact) unit_tail<NT, DENSE>(a, acc[0], u0 * 16, scrA, scrB, smem, lane, col_shift);
+    if (U > 1 && 1 < nact) unit_tail<NT, DENSE>(a, acc[U - 1], (u0 + 1) * 16, scrA, scrB, smem, lane, col_shift);
     static_assert(U <= 2, "two units per pass");
     STAMP(5);
 }
@@ -321,9 +321,21 @@ template <int NT, int NWV, int NPL, bool DENSE>
 __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3p_kernel(MlpFwdArgs a, const uint4* __restrict__ W16, long long units,
                                                                    long long units_per_wave) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    stage_tail_weights(a, smem);
+    long long vblock = blockIdx.x;
+    int col_shift = 0;                       // the argument block itself stays untouched (a modified copy would live in scratch)
+    if (DENSE && a.dense_groups > 1) {
+        // grouped column blocks: block id = xcd + 8 * (group + G * j)  ->  row share xcd + 8 j, column block `group`
+        const int G = a.dense_groups;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int grp = slot % G;
+        vblock = (long long)(slot / G) * 8 + xcd;
+        col_shift = grp * a.nt1 * 16;
+        W16 += (long long)grp * a.nt1 * 64;                          // = w_tile0 + grp * nt1 in the plane image
+        if (vblock * NWV * units_per_wave >= units) return;          // workgroup-uniform: a share without rows
+    }
+    stage_tail_weights(a, smem, col_shift);
     __syncthreads();
-    const long long gw = (long long)blockIdx.x * NWV + (threadIdx.x >> 6);
+    const long long gw = vblock * NWV + (threadIdx.x >> 6);
     const long long ustart = gw * units_per_wave;
     long long uend = ustart + units_per_wave;
     if (uend > units) uend = units;
@@ -338,9 +350,9 @@ __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3p_kernel(MlpFwdArgs a,
     for (long long p = 0; p < npass; ++p) {
         const long long u = ustart + 2 * p;
         if (u + 1 < uend) {
-            if (early) pipe_run<NT, 2, NWV, true, NPL, DENSE>(a, W16, smem, u, 2, g_ph, g_t);
-            else pipe_run<NT, 2, NWV, false, NPL, DENSE>(a, W16, smem, u, 2, g_ph, g_t);
-        } else pipe_run<NT, 1, NWV, false, NPL, DENSE>(a, W16, smem, u, u < uend ? 1 : 0, g_ph, g_t);
+            if (early) pipe_run<NT, 2, NWV, true, NPL, DENSE>(a, W16, smem, u, 2, col_shift, g_ph, g_t);
+            else pipe_run<NT, 2, NWV, false, NPL, DENSE>(a, W16, smem, u, 2, col_shift, g_ph, g_t);
+        } else pipe_run<NT, 1, NWV, false, NPL, DENSE>(a, W16, smem, u, u < uend ? 1 : 0, col_shift, g_ph, g_t);
     }
     if (a.dbg && (threadIdx.x & 63) == 0) {
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
@@ -352,9 +364,9 @@ __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3p_kernel(MlpFwdArgs a,
     for (long long p = 0; p < npass; ++p) {
         const long long u = ustart + 2 * p;
         if (u + 1 < uend) {                                                            // wave-uniform
-            if (early) pipe_run<NT, 2, NWV, true, NPL, DENSE>(a, W16, smem, u, 2);
-            else pipe_run<NT, 2, NWV, false, NPL, DENSE>(a, W16, smem, u, 2);
-        } else pipe_run<NT, 1, NWV, false, NPL, DENSE>(a, W16, smem, u, u < uend ? 1 : 0);
+            if (early) pipe_run<NT, 2, NWV, true, NPL, DENSE>(a, W16, smem, u, 2, col_shift);
+            else pipe_run<NT, 2, NWV, false, NPL, DENSE>(a, W16, smem, u, 2, col_shift);
+        } else pipe_run<NT, 1, NWV, false, NPL, DENSE>(a, W16, smem, u, u < uend ? 1 : 0, col_shift);
     }
 #endif
 }
@@ -370,11 +382,13 @@ static size_t pipe_lds_bytes(const MlpFwdArgs& a) {
 template <int NT, int NWV, int NPL, bool DENSE>
 static void launch_pipe_nw(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
     const long long units = (a.S + 15) / 16;
-    const long long waves_max = (long long)ISK_NUM_CU * NWV;
+    const int G = (DENSE && a.dense_groups > 1) ? a.dense_groups : 1;
+    const long long waves_max = (long long)(ISK_NUM_CU / G) * NWV;
     long long upw = (units + waves_max - 1) / waves_max;
     if (upw < 1) upw = 1;
     const long long nwaves = (units + upw - 1) / upw;
-    const long long blocks = (nwaves + NWV - 1) / NWV;
+    long long blocks = (nwaves + NWV - 1) / NWV;
+    if (G > 1) blocks = (blocks + 7) / 8 * 8 * G;               // whole XCD rounds of row shares, G column blocks each
     const size_t lds = pipe_lds_bytes<NT, NWV, NPL, DENSE>(a);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16x3p_kernel<NT, NWV, NPL, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -53,7 +53,7 @@ __device__ __forceinline__ float act_apply(int act, float z) {
 // code out of the dense ones) because the split-bf16 kernel sits at the 256-register limit and every extra path spills
 template <int NT, bool DENSE = false>
 __device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT], long long row_base, float* scrA,
-                                          float* scrB, const float* tailw, int lane) {
+                                          float* scrB, const float* tailw, int lane, int col_shift = 0) {
     const int li = lane & 15, lq = lane >> 4;
     int stride = a.stride_a;
     if (DENSE) {
@@ -64,11 +64,11 @@ __device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT],
         for (int t = 0; t < NT; ++t) {
             const int col = t * 16 + li;
             const float bcol = tailw[a.bias_lds0 + col];
-            const bool colok = a.out_col0 + col < a.out_ld;
+            const bool colok = a.out_col0 + col_shift + col < a.out_ld;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long long grow = row_base + lq * 4 + r;
-                if (colok && grow < a.S) a.out[grow * a.out_ld + a.out_col0 + col] = act_apply(a.act1, acc[t][r] + bcol);
+                if (colok && grow < a.S) a.out[grow * a.out_ld + a.out_col0 + col_shift + col] = act_apply(a.act1, acc[t][r] + bcol);
             }
         }
         return;
@@ -171,7 +171,7 @@ __device__ __forceinline__ void unit_tail(const MlpFwdArgs& a, f32x4 (&acc)[NT],
 
 
 // stage the (small) fragment-linear tail weights in LDS once per workgroup
-__device__ __forceinline__ void stage_tail_weights(const MlpFwdArgs& a, float* smem) {
+__device__ __forceinline__ void stage_tail_weights(const MlpFwdArgs& a, float* smem, int bias_shift = 0) {
     for (int l = 0; l < a.ntail; ++l) {
         const int n4 = a.tail[l].kchunks * a.tail[l].ntiles * 64;
         const f32x4* src = (const f32x4*)a.tail[l].Wt;
@@ -180,7 +180,7 @@ __device__ __forceinline__ void stage_tail_weights(const MlpFwdArgs& a, float* s
     }
     // bias block: [bias1][tail biases...]
     float* bl = smem + a.bias_lds0;
-    for (int i = threadIdx.x; i < a.nt1 * 16; i += blockDim.x) bl[i] = a.bias1[i];
+    for (int i = threadIdx.x; i < a.nt1 * 16; i += blockDim.x) bl[i] = a.bias1[bias_shift + i];
     int off = a.nt1 * 16;
     for (int l = 0; l < a.ntail; ++l) {
         const int n = a.tail[l].ntiles * 16;

@@ -56,6 +56,10 @@ struct MlpFwdArgs {
     // dense-block mode (layer-by-layer path for networks too wide for the fused kernel): ntail == 0 and the
     // kernel computes columns [16*w_tile0, 16*(w_tile0+nt1)) of ONE layer, writing act(z) for every padded column
     int dense_mode, w_nt_total, w_tile0, out_ld, out_col0;
+    // dense_groups = G > 1: ONE launch computes G adjacent column blocks of nt1 tiles each.  Workgroups b, b+8, .. b+8(G-1)
+    // (same XCD, started together) take the same rows and different column blocks, so the sample rows they stream in
+    // lockstep are fetched from HBM once and re-read from that XCD's L2 (bf16 kernels only)
+    int dense_groups;
     int tailw_floats;       // total floats staged in LDS per workgroup: tail weights, then the bias block
     int bias_lds0;          // float offset of the bias block: [bias1: nt1*16][tail 0 bias: ntiles*16]...
     int stride_a, stride_b; // floats per row of the two per-wave LDS ping-pong buffers (padded width + 4)
