@@ -106,6 +106,12 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeatArgs a) {
 #define FEAT_LD(p) (*(p))
 #define FEAT_ST(p, v) (*(p) = (v))
 #endif
+// 12-byte buffer load, declared the way composable_kernel does: this hipcc lowers the __builtin_amdgcn_raw_buffer_load_b64 /
+// _b96 / _b128 builtins to a single-dword load (checked in the ISA), the intrinsic itself is fine
+typedef int isk_i32x4 __attribute__((ext_vector_type(4)));
+typedef float isk_f32x3 __attribute__((ext_vector_type(3)));
+__device__ isk_f32x3 isk_raw_buffer_load_f32x3(isk_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v3f32");
+
 template <int NFL, int NDL, bool PDIST, int PF = 1>
 __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const unsigned* __restrict__ packed_pairs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -126,7 +132,11 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
     // software pipeline: the next PF samples' rows (NDL or NFL dwords per lane each) are in flight in registers while
     // the current one is featurized, so a wave keeps HBM busy on its own (needed when the kernel runs
     // throttled beside the training kernels)
-    constexpr int NIN = PDIST ? NDL : NFL;
+    // pairwise distances: a lane takes whole atoms (xyz = one 12-B load, one ds_write_b96 into its 16-B cell) -- a third
+    // of the load and LDS-write instructions of a dword-per-lane row
+    constexpr int NAL = (NDL * 64 / 3 + 63) / 64;                  // atoms per lane
+    constexpr int NIN = PDIST ? 3 * NAL : NFL;
+    typedef float f32x3 __attribute__((ext_vector_type(3)));
     float nxt[PF][NIN];
     // Rows are read and written through BUFFER instructions: a wave-uniform descriptor per row whose size is the
     // row length (0 for a row past the end), so lanes beyond the row read 0 and their stores are dropped by the
@@ -138,19 +148,32 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
     };
     auto fetch = [&](float (&buf)[NIN], long long srow) {
         const __amdgpu_buffer_rsrc_t r = row_rsrc(a.in, srow, a.D, a.D);
+        if (PDIST) {
+            const unsigned long long p = (unsigned long long)(a.in + srow * (long long)a.D);
+            isk_i32x4 rv;
+            rv[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+            rv[1] = __builtin_amdgcn_readfirstlane((int)((p >> 32) & 0xffffu));
+            rv[2] = __builtin_amdgcn_readfirstlane(srow < a.S ? a.D * 4 : 0);
+            rv[3] = 0x00020000;
 #pragma unroll
-        for (int u = 0; u < NIN; ++u) buf[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (64 * u + lane) * 4, 0, FEAT_AUX));
+            for (int u = 0; u < NAL; ++u) {
+                const isk_f32x3 v = isk_raw_buffer_load_f32x3(rv, (64 * u + lane) * 12, 0, FEAT_AUX);
+                buf[3 * u] = v[0];
+                buf[3 * u + 1] = v[1];
+                buf[3 * u + 2] = v[2];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NIN; ++u) buf[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (64 * u + lane) * 4, 0, FEAT_AUX));
+        }
     };
     auto one = [&](float (&buf)[NIN], long long srow) {
         float d[NFL];
         if (PDIST) {
 #pragma unroll
-            for (int u = 0; u < NDL; ++u) {
-                const int i = 64 * u + lane;
-                if (i < a.D) {
-                    const int at = i / 3;
-                    ((float*)cw)[4 * at + (i - 3 * at)] = buf[u];
-                }
+            for (int u = 0; u < NAL; ++u) {
+                const int at = 64 * u + lane;
+                if (at < natoms) ((f32x3*)cw)[at] = (f32x3){buf[3 * u], buf[3 * u + 1], buf[3 * u + 2]};
             }
         } else {
 #pragma unroll
@@ -163,7 +186,7 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
             // the gathers are kept GW pairs deep in flight (a rolling register window, order pinned): left to itself
             // the compiler waits out the full LDS latency of every pair, 28 times per sample
             constexpr int GW = NFL < 6 ? NFL : 6;
-            typedef float f32x3 __attribute__((ext_vector_type(3)));     // 16-byte cells, xyz read (ds_read_b96)
+            // 16-byte cells, xyz read (ds_read_b96)
             const f32x3* cw3 = (const f32x3*)cw;
             f32x3 qa[GW], qb[GW];
 #pragma unroll
