@@ -89,3 +89,20 @@ def test_c2_full_size_matches_oracle_end_to_end(gpu_pkg):
     np.testing.assert_allclose(iso.losses, oiso.losses, rtol=2e-4)
     np.testing.assert_allclose(pkg.chis(iso), O.chis(oiso), atol=2e-5)
     iso.close()
+
+
+def test_c3_runs_are_bit_reproducible(gpu_pkg):
+    """Two identically seeded engines at the full C3 size produce bit-identical losses and parameters over 60 iterations:
+    the iteration overlaps a throttled side-stream featurizer (into the other half of a double buffer), prioritised
+    latency-chain kernels and the main stream's training -- a race between them would show up as a difference."""
+    pkg = gpu_pkg
+    out = []
+    for _ in range(2):
+        iso, om, ofeat, xs, ys, c = _workload(pkg, "c3", minibatch=1000, featurize_every_iteration=True, seed=11)
+        for _ in range(60):
+            pkg.run(iso, 1, 1)
+        out.append((np.array(iso.losses), iso.model.get_params().copy()))
+        iso.close()
+    assert np.all(np.isfinite(out[0][0]))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
