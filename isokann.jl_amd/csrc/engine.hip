@@ -134,6 +134,14 @@ struct isk_engine {
     int2* d_pairs = nullptr;
     unsigned* d_packed = nullptr;
     double bt1 = 0.9, bt2 = 0.999;
+    // device copy of [bt1, bt2]: opt_step derives the Adam bias corrections from it and the fold that follows advances it,
+    // so a training step's launch arguments never change and an epoch can be replayed as ONE hipGraph (train_epoch_graph)
+    double* d_bt = nullptr;
+    bool bt_dev_valid = false;
+    hipGraphExec_t tg_exec = nullptr;    // the captured epoch: nb x (train_fwd1, train_tail, train_grad1, opt_step, fold)
+    long long tg_bs = 0, tg_nb = 0;
+    int tg_flags = -1;
+    bool tg_disabled = false;
     // data
     long long N = 0, K = 0, D = 0;
     float *d_in_xs = nullptr, *d_in_ys = nullptr;   // raw coords / raw features
@@ -183,6 +191,7 @@ static void free_dev(void* p) { if (p) (void)hipFree(p); }
 static void free_data(isk_engine* e) {
     if (e->side) (void)hipStreamSynchronize(e->side);
     e->ys_ahead = false;
+    if (e->tg_exec) { (void)hipGraphExecDestroy(e->tg_exec); e->tg_exec = nullptr; }
     free_dev(e->d_in_xs); free_dev(e->d_in_ys); free_dev(e->d_xhat); free_dev(e->d_xhat_alt); free_dev(e->d_out); free_dev(e->d_ks);
     free_dev(e->d_target); free_dev(e->d_kw); e->d_kw = nullptr; free_dev(e->d_z1); free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm); free_dev(e->d_isa_work);
     e->d_isa_work = nullptr;
@@ -304,9 +313,10 @@ static TrainBuffers train_buffers(const isk_engine* e) {
     return b;
 }
 
-static void launch_fold(isk_engine* e) {
+static void launch_fold(isk_engine* e, bool advance_dev_bt = false) {
     FoldArgs a;
     std::memset(&a, 0, sizeof(a));
+    if (advance_dev_bt) { a.bt = e->d_bt; a.beta1 = e->cfg.beta1; a.beta2 = e->cfg.beta2; }
     a.theta = e->d_theta; a.nlayers = e->L;
     for (int l = 0; l < e->L; ++l) a.Kp[l] = layer_kp(e, l);
     for (int i = 0; i <= e->L; ++i) a.widths[i] = e->cfg.widths[i];
@@ -420,6 +430,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     const size_t pb = (size_t)(e->nparams + 2) * sizeof(float);
     ALLOC(e->d_theta, pb); ALLOC(e->d_grad, pb * ISK_MAX_SLABS); ALLOC(e->d_m, pb); ALLOC(e->d_v, pb);
     ALLOC(e->d_loss_acc, 2 * sizeof(double)); ALLOC(e->d_status, sizeof(int)); ALLOC(e->d_mm, 2 * sizeof(float));
+    ALLOC(e->d_bt, 2 * sizeof(double));
     ALLOC(e->d_lossw, (size_t)nout * sizeof(float));
     ALLOC(e->d_At, (size_t)nout * nout * sizeof(float)); ALLOC(e->d_rowperm, (size_t)nout * sizeof(int));
     ALLOC(e->d_W16, (size_t)isk_bf16_chunks(e->Fp) * 32 * isk_pad16(cfg->widths[1]) * 3 * sizeof(uint16_t));
@@ -472,7 +483,7 @@ extern "C" void isk_destroy(isk_engine* e) {
     if (e->side) (void)hipStreamSynchronize(e->side);
     if (e->copy) (void)hipStreamSynchronize(e->copy);
     free_data(e);
-    free_dev(e->d_theta); free_dev(e->d_grad); free_dev(e->d_m); free_dev(e->d_v);
+    free_dev(e->d_theta); free_dev(e->d_grad); free_dev(e->d_m); free_dev(e->d_v); free_dev(e->d_bt);
     free_dev(e->d_loss_acc); free_dev(e->d_status); free_dev(e->d_mm); free_dev(e->d_lossw);
     free_dev(e->d_At); free_dev(e->d_rowperm); free_dev(e->d_pairs); free_dev(e->d_packed); free_dev(e->d_isa_work_dp);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_Wt[l]); free_dev(e->d_bias[l]); }
@@ -504,6 +515,7 @@ extern "C" int isk_set_stream(isk_engine* e, void* s) {
     if (!e) return fail(ISK_EINVAL, "null engine");
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->own_stream) { (void)hipStreamDestroy(e->stream); e->own_stream = false; }
+    if (e->tg_exec) { (void)hipGraphExecDestroy(e->tg_exec); e->tg_exec = nullptr; }
     e->stream = (hipStream_t)s;
     return ISK_OK;
 }
@@ -542,7 +554,7 @@ extern "C" int isk_set_opt_state(isk_engine* e, const float* m, const float* v, 
     HIPCHK(hipMemcpyAsync(e->d_m, m, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
     if (v) HIPCHK(hipMemcpyAsync(e->d_v, v, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (bt) { e->bt1 = bt[0]; e->bt2 = bt[1]; }
+    if (bt) { e->bt1 = bt[0]; e->bt2 = bt[1]; e->bt_dev_valid = false; }
     return ISK_OK;
 }
 
@@ -560,7 +572,7 @@ extern "C" int isk_reset_opt_state(isk_engine* e) {
     if (!e) return fail(ISK_EINVAL, "null engine");
     HIPCHK(hipMemsetAsync(e->d_m, 0, (size_t)e->nparams * sizeof(float), e->stream));
     HIPCHK(hipMemsetAsync(e->d_v, 0, (size_t)e->nparams * sizeof(float), e->stream));
-    e->bt1 = e->cfg.beta1; e->bt2 = e->cfg.beta2;
+    e->bt1 = e->cfg.beta1; e->bt2 = e->cfg.beta2; e->bt_dev_valid = false;
     return ISK_OK;
 }
 
@@ -1549,18 +1561,33 @@ static void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, 
 // fold: refresh the weight images the forward / training kernels read.  The rocBLAS variant of the layered training
 // path reads theta itself (only layer 0's folded bias comes from an image, and only with LayerNorm), so inside an
 // epoch it skips the refresh and folds once at the end.
-static void launch_opt(isk_engine* e, float gscale, bool fold = true) {
+// bring the device copy of [beta1^t, beta2^t] up to date (after create / set_opt_state / reset, or steps taken in host mode);
+// synchronous and rare.  Never called while the stream is being captured.
+static bool prepare_dev_bt(isk_engine* e) {
+    if (e->bt_dev_valid) return true;
+    const double h[2] = {e->bt1, e->bt2};
+    if (hipMemcpyAsync(e->d_bt, h, sizeof(h), hipMemcpyHostToDevice, e->stream) != hipSuccess) return false;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
+    e->bt_dev_valid = true;
+    return true;
+}
+
+static void launch_opt(isk_engine* e, float gscale, bool fold = true, bool capturing = false) {
     OptArgs a;
     a.theta = e->d_theta; a.grad = e->d_grad; a.m = e->d_m; a.v = e->d_v; a.n = e->nparams;
     a.kind = e->cfg.opt_kind; a.lr = e->cfg.lr; a.reg = e->cfg.reg; a.beta1 = e->cfg.beta1; a.beta2 = e->cfg.beta2;
     a.eps = e->cfg.opt_eps; a.rho = e->cfg.rho;
     a.bc1 = (float)(1.0 - e->bt1); a.bc2 = (float)(1.0 - e->bt2);
+    // fused path with a fold behind every step: the bias corrections come from the device copy, which that fold advances
+    const bool dev = fold && !e->layered && (capturing ? e->bt_dev_valid : prepare_dev_bt(e));
+    a.bt = dev ? e->d_bt : nullptr;
     a.gscale = gscale; a.loss_acc = e->d_loss_acc;
     a.nslab = e->last_nslab;
     a.slab_prefix = (e->cfg.layernorm ? 2LL * e->F : 0LL) + (long long)e->F * e->cfg.widths[1] + e->cfg.widths[1];
     isk_launch_opt_step(a, e->stream);
     e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2;
-    if (fold) launch_fold(e);
+    if (!dev) e->bt_dev_valid = false;           // this step advanced only the host copy
+    if (fold) launch_fold(e, dev);
 }
 
 static int upload_target(isk_engine* e, const float* target) {
@@ -1592,6 +1619,59 @@ static int stage_perm_ahead(isk_engine* e, const int32_t* perm) {
     return ISK_OK;
 }
 
+// The epoch's nb x 5 dependent launches as ONE hipGraph launch.  A dependent kernel launched from the host costs ~3.0 us
+// on this stack, the same chain replayed from a graph ~1.9 us (measured with a 50-kernel chain of empty kernels); the
+// training chain is nothing but such launches (50 per iteration at C3, 500 at the reference's default minibatch of 100).
+// Every launch argument is constant from one epoch to the next: the batch slices are fixed offsets into d_perm (its
+// CONTENT is what the shuffle changes), and the Adam bias corrections are read from d_bt on the device.  The graph is
+// captured from the ordinary launch functions the first time and re-captured when the batch plan, the train_grad1
+// variant or the buffers change.  ISK_TRAIN_GRAPH=0 (or any capture error) keeps the per-kernel launches.
+static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
+    static const int on = [] { const char* v = getenv("ISK_TRAIN_GRAPH"); return v ? atoi(v) : 1; }();
+    if (!on || e->tg_disabled || e->layered || nb < 2) return false;
+    const int nslab = pick_slabs((int)bs);
+    const int flags = nslab | (e->ys_ahead ? 0x100 : 0);
+    if (!prepare_dev_bt(e)) return false;
+    if (!e->tg_exec || e->tg_bs != bs || e->tg_nb != nb || e->tg_flags != flags) {
+        if (e->tg_exec) { (void)hipGraphExecDestroy(e->tg_exec); e->tg_exec = nullptr; }
+        const double s1 = e->bt1, s2 = e->bt2;
+        if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            e->tg_disabled = true;
+            return false;
+        }
+        for (long long b = 0; b < nb; ++b) {
+            launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, nslab);
+            launch_opt(e, 1.0f, true, true);
+        }
+        hipGraph_t g = nullptr;
+        hipError_t r = hipStreamEndCapture(e->stream, &g);
+        if (r == hipSuccess) r = hipGraphInstantiate(&e->tg_exec, g, nullptr, nullptr, 0);
+        if (g) (void)hipGraphDestroy(g);
+        if (r != hipSuccess || !e->bt_dev_valid) {       // nothing has run: undo the host-side step bookkeeping
+            (void)hipGetLastError();
+            if (e->tg_exec) { (void)hipGraphExecDestroy(e->tg_exec); e->tg_exec = nullptr; }
+            e->bt1 = s1; e->bt2 = s2; e->bt_dev_valid = false;
+            e->tg_disabled = true;
+            return false;
+        }
+        e->tg_bs = bs; e->tg_nb = nb; e->tg_flags = flags;
+    } else {
+        // what the launch functions keep track of on the host
+        for (long long b = 0; b < nb; ++b) { e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2; }
+        e->last_nslab = nslab;
+        e->w16_dirty = true;
+    }
+    if (hipGraphLaunch(e->tg_exec, e->stream) != hipSuccess) {
+        // cannot happen after a successful instantiate; if it does the epoch has not run and the state says so
+        (void)hipGetLastError();
+        e->tg_disabled = true;
+        fail(ISK_EHIP, "hipGraphLaunch failed");
+        return true;
+    }
+    return true;
+}
+
 static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, double* loss, int* status_word = nullptr,
                        bool perm_staged = false) {
     const long long N = e->N;
@@ -1617,9 +1697,11 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
     {
         ScopedTimer t(e, ISK_T_TRAIN);
         const bool lazy_fold = e->layered && !e->cfg.layernorm && blas_ready(e);
-        for (long long b = 0; b < nb; ++b) {
-            launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, pick_slabs((int)bs));
-            launch_opt(e, 1.0f, !lazy_fold || b == nb - 1);
+        if (!train_epoch_graph(e, bs, nb)) {
+            for (long long b = 0; b < nb; ++b) {
+                launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, pick_slabs((int)bs));
+                launch_opt(e, 1.0f, !lazy_fold || b == nb - 1);
+            }
         }
     }
     // one round trip per epoch: loss, collapse flag and (for isk_run) the target's status word, into pinned memory

@@ -116,6 +116,7 @@ struct FoldArgs {
     long long off_W[ISK_MAX_LAYERS], off_b[ISK_MAX_LAYERS];
     float* Wt[ISK_MAX_LAYERS];            // fragment-linear per layer
     float* bias[ISK_MAX_LAYERS];          // padded per layer (layer 0: folded)
+    double* bt; double beta1, beta2;      // optional: advance the device copy of [beta1^t, beta2^t] (one thread; see OptArgs)
 };
 void isk_launch_fold(const FoldArgs& a, hipStream_t st);
 
@@ -190,6 +191,8 @@ struct OptArgs {
     long long n;
     int kind; float lr, reg, beta1, beta2, eps, rho;
     float bc1, bc2;         // 1 - beta1^t, 1 - beta2^t for this step
+    const double* bt;       // optional: device copy of [beta1^t, beta2^t] (then bc1/bc2 are derived from it, so the launch
+                            // arguments do not change from step to step and the epoch can be replayed as a hipGraph)
     int nslab; long long slab_prefix;   // gradient slabs to sum for parameter indices < slab_prefix
     float gscale;           // gradient multiplier (1, or 1/global_batch in data-parallel mode)
     const double* loss_acc; // collapsed flag at [1]: skip the update when set (src/iso.jl:186-189 throws before update!)

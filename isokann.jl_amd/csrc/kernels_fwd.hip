@@ -325,6 +325,10 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tile[];     // [16][Np + 1]
     const int layer = blockIdx.y;
     if (layer >= a.nlayers) return;
+    if (a.bt && blockIdx.x == 0 && layer == 0 && threadIdx.x == 0) {      // the optimizer step before this fold is done
+        a.bt[0] *= a.beta1;
+        a.bt[1] *= a.beta2;
+    }
     const int K = a.widths[layer], N = a.widths[layer + 1];
     const int Kp = a.Kp[layer], Np = (N + 15) & ~15;
     const int nt = Np / 16, nchunks = Kp / 16;

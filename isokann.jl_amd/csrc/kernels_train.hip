@@ -518,6 +518,7 @@ void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const in
 // update, as the reference throws before update! (src/iso.jl:186-189).
 __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a, double* loss_acc) {
     ISK_LATENCY_CHAIN_PRIO();
+    const float bc1 = a.bt ? (float)(1.0 - a.bt[0]) : a.bc1, bc2 = a.bt ? (float)(1.0 - a.bt[1]) : a.bc2;
     const float lstep = a.grad[a.n];
     const bool bad = (loss_acc[1] != 0.0) || !isfinite(lstep);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a, double* loss_a
             const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
             a.m[i] = m;
             a.v[i] = v;
-            d = m / a.bc1 / (sqrtf(v / a.bc2) + a.eps) * a.lr;
+            d = m / bc1 / (sqrtf(v / bc2) + a.eps) * a.lr;
         } else {
             const float vel = a.m[i];
             d = -a.rho * a.rho * vel + (1.f + a.rho) * a.lr * g;
