@@ -264,6 +264,31 @@ def test_train_batch_epoch(gpu_pkg, opt, minibatch):
     iso.close()
 
 
+@pytest.mark.gpu
+def test_train_batch_changing_batch_plan_and_restored_optimizer_state(gpu_pkg):
+    """the training epoch is replayed as a captured graph: a different batch plan re-captures it, and an optimizer state
+    written back from the host (Adam step products included) must reach the device copy the graph reads"""
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 20, 60, 130, 3, 1, seed=13)
+    rule = O.OptRule("adam", 1e-2, 1e-3)
+    iso = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.OptSpec("adam", 1e-2, 1e-3), minibatch=32)
+    rng = np.random.default_rng(1)
+    st = O.setup(rule, om)
+    for k, mb in enumerate([32, 32, 50, 32, 0, 50, 50]):
+        tgt = np.asarray(rng.uniform(size=(1, 130)), np.float32)
+        perm = rng.permutation(130)
+        l = pkg.train_batch(iso, tgt, minibatch=mb, perm=perm)
+        lo = O.train_batch(om, odata.features[0], tgt.astype(np.float64), st, mb, perm=perm)
+        assert abs(l - lo) <= 1e-4 * abs(lo), (k, mb)
+        if k == 3:                                  # round trip of the optimizer state through the host
+            m, v, bt = iso.get_opt_state()
+            iso.set_opt_state(m, v, bt)
+    np.testing.assert_allclose(iso.model.get_params(), om.get_flat(), atol=3e-5, rtol=3e-4)
+    _, _, bt = iso.get_opt_state()
+    assert bt[0] == pytest.approx(st.bt1) and bt[1] == pytest.approx(st.bt2)
+    iso.close()
+
+
 def test_nonfinite_loss_raises_and_keeps_weights(gpu_pkg):
     pkg = gpu_pkg
     data, odata, om = _coords_case(pkg, 10, 20, 40, 2, 1, seed=3)
