@@ -576,6 +576,23 @@ __global__ __launch_bounds__(256) void kmean_kernel(KmeanArgs a) {
         for (int i = lane; i < tot; i += WAVE) s += w ? base[i] * w[i / a.nout] : base[i];
         for (int o = 32; o >= a.nout; o >>= 1) s += __shfl_xor(s, o, WAVE);
         if (lane < a.nout) a.ks[n * a.nout + lane] = s / (float)a.K;
+    } else if (a.nout < 64) {
+        // nout does not divide 64 (C3: nout = 3): the first W = 64 - 64 % nout lanes walk the K x nout block with stride W,
+        // so a lane keeps one output index; the W / nout partial sums per output are combined through LDS
+        __shared__ float part[4][64];
+        const int wv = threadIdx.x >> 6;
+        const int W = WAVE - WAVE % a.nout;
+        float s = 0.f;
+        if (lane < W)
+            for (int i = lane; i < tot; i += W) s += w ? base[i] * w[i / a.nout] : base[i];
+        part[wv][lane] = s;
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the wave's own LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        if (lane < a.nout) {
+            float t = 0.f;
+            for (int j = lane; j < W; j += a.nout) t += part[wv][j];
+            a.ks[n * a.nout + lane] = t / (float)a.K;
+        }
     } else {
         for (int o = lane; o < a.nout; o += WAVE) {
             float s = 0.f;
