@@ -309,6 +309,7 @@ __global__ __launch_bounds__(ISA_T) void isa_target_kernel(IsaArgs a, const doub
     __shared__ long long shi[ISA_T / 64];
     __shared__ double vrow[D];
     __shared__ double Am[D * D];
+    __shared__ double Msh[D * 2 * D];
     __shared__ int bad;
     const long long N = a.N;
     double* T = a.work + N * D;
@@ -316,12 +317,25 @@ __global__ __launch_bounds__(ISA_T) void isa_target_kernel(IsaArgs a, const doub
     if (threadIdx.x == 0) {
         bad = 0;
         int idx[D];
+#pragma unroll
         for (int i = 0; i < D - 1; ++i) idx[i] = ind[i];
         idx[D - 1] = (int)shi[0];
         if (blockIdx.x == 0) ind[D - 1] = idx[D - 1];
-        double M[D * 2 * D];
+        // the d x d rows in ONE memory round trip (registers first): filled element by element, the pivoting matrix lives
+        // in scratch memory and every load waited for the one before it -- d*d dependent round trips on one thread
+        float kvs[D * D];
+#pragma unroll
         for (int i = 0; i < D; ++i)
-            for (int j = 0; j < D; ++j) { M[i * 2 * D + j] = (double)a.ks[(long long)idx[i] * D + j]; M[i * 2 * D + D + j] = (i == j) ? 1.0 : 0.0; }
+#pragma unroll
+            for (int j = 0; j < D; ++j) kvs[i * D + j] = a.ks[(long long)idx[i] * D + j];
+        __builtin_amdgcn_sched_barrier(0);
+        // the pivoting matrix is indexed at run time: in LDS (one thread uses it), not in a private array -- that one
+        // lives in scratch memory and every access of the elimination is a dependent memory round trip
+        double* M = Msh;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) { M[i * 2 * D + j] = (double)kvs[i * D + j]; M[i * 2 * D + D + j] = (i == j) ? 1.0 : 0.0; }
         // elimination with the multiplier taken against the UNSCALED pivot row (as LU does), so exactly
         // dependent rows cancel to exact zeros and are reported singular like Julia's inv()
         for (int c = 0; c < D && !bad; ++c) {
@@ -406,6 +420,7 @@ __global__ __launch_bounds__(ISA_T) void isa_perm_kernel(IsaArgs a, const double
     __shared__ double shd[ISA_MAXD * ISA_MAXD * (ISA_T / 64)];
     __shared__ double Cst[D * D];
     __shared__ int rperm[D];
+    __shared__ int psh[2 * D];
     const long long N = a.N;
     const double* T = a.work + N * D;
     if (threadIdx.x < D) rperm[threadIdx.x] = threadIdx.x;
@@ -417,7 +432,8 @@ __global__ __launch_bounds__(ISA_T) void isa_perm_kernel(IsaArgs a, const double
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            int p[D], best[D];
+            int* p = psh;                           // run-time indexed: LDS, not scratch (see isa_target_kernel)
+            int* best = psh + D;
             for (int i = 0; i < D; ++i) p[i] = i;
             double bc = 0;
             bool first = true;
