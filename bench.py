@@ -112,8 +112,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1000)
     ap.add_argument("--profile-steps", type=int, default=5)
-    ap.add_argument("--forward-mode", type=int, default=1, choices=[0, 1, 2],
-                    help="0 = f32 MFMA forward, 1 = split-bf16 (bf16x3, f32-equivalent) forward, 2 = plain bf16 operands (reduced precision)")
+    ap.add_argument("--forward-mode", type=int, default=3, choices=[0, 1, 2, 3],
+                    help="0 = f32 MFMA forward, 1 = split-bf16 (bf16x3, f32-equivalent), 2 = plain bf16 operands (reduced precision), "
+                         "3 = split-f16 (f16x2, f32-equivalent; planes written by the featurizer)")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel driver even with one rank (rehearsal)")
     args = ap.parse_args()
 
@@ -231,16 +232,32 @@ def main():
         ms, cnt = tm["fwd_ys"]
         traffic = None
         try:        # HBM bytes per launch of this kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
             if args.workload == "c3" and not args.cached_features:
-                traffic = pm["mlp_fwd_traffic_bytes_per_launch"]
+                traffic = pm["mlp_fwd_traffic_bytes_per_launch"][{0: "f32", 1: "bf16x3", 2: "bf16", 3: "f16x2"}[args.forward_mode]]
         except Exception:
             traffic = None
         if cnt:
             avg = ms / cnt
             alg_tf = fwd_flops / (avg * 1e-3) / 1e12
             nt1 = (widths[1] + 15) // 16
-            if args.forward_mode in (1, 2):
+            rows = N * K + (N if widths[-1] > 1 else 0)
+            fp = (widths[0] + 31) // 32 * 32
+            if args.forward_mode == 3:
+                # split-f16 forward: three f16 MFMAs per product block, operands pre-split -- the kernel streams 4*Fp bytes per
+                # row (f16 hi | lo planes) and is bound by that HBM stream; the executed matrix work is reported beside it
+                abytes = rows * (fp * 4 + 4 + widths[-1] * 4)            # plane row + row scale read, nout floats written
+                l1 = 2 * fp * (nt1 * 16)
+                exec_flops = rows * (3 * l1 + (ffwd - 2 * widths[0] * widths[1]))
+                ach = abytes / (avg * 1e-3) / 1e9
+                roof = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
+                        "kernel": f"mlp_fwd_bf16x3p_kernel<{nt1},8,2,false,true>",
+                        "dtype": "f16x2 split (2 scaled f16 planes per f32 operand, 3 MFMAs per block, f32 accumulate)",
+                        "algorithmic_bytes_per_launch": abytes,
+                        "mfma": {"executed_flops_per_launch": exec_flops, "tflops": exec_flops / (avg * 1e-3) / 1e12,
+                                 "frac_of_2500_f16_peak": exec_flops / (avg * 1e-3) / 1e12 / 2500.0},
+                        "algorithmic": {"flops_per_launch": fwd_flops, "tflops": alg_tf, "vs_f32_mfma_peak_157.3": alg_tf / 157.3}}
+            elif args.forward_mode in (1, 2):
                 # split-bf16 forward: six bf16 MFMAs per product block are EXECUTED for every algorithmic f32 one;
                 # the bound is the bf16 matrix pipe, so the roofline is priced in executed bf16 flops
                 l1 = 2 * ((widths[0] + 31) // 32 * 32) * (nt1 * 16)
@@ -270,8 +287,8 @@ def main():
                                 "runs at 5.4 TB/s (DESIGN.md section 3)"}
             except Exception:
                 pass
+            roof.setdefault("algorithmic_bytes_per_launch", rows * fp * 4)
             roof.update({"avg_ms": avg, "launches": cnt,
-                         "algorithmic_bytes_per_launch": (N * K + (N if widths[-1] > 1 else 0)) * ((widths[0] + 31) // 32 * 32) * 4,
                          "phases_ms": {k: (v[0] / v[1] if v[1] else None) for k, v in tm.items()}})
     if use_dp:
         dist.barrier()
@@ -285,13 +302,14 @@ def main():
             "metric": "ISOKANN train-step Koopman-samples (N*K)/sec", "value": value, "unit": "Koopman-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {0: "f32", 1: "f32 (Koopman forward GEMM as split-bf16 x3 MFMA, f32 accumulate; training f32)",
+            "dtype": {0: "f32", 3: "f32 (Koopman forward GEMM as split-f16 x2 MFMA, f32 accumulate, f32-equivalent; training f32)",
+                      1: "f32 (Koopman forward GEMM as split-bf16 x3 MFMA, f32 accumulate; training f32)",
                       2: "bf16 (Koopman forward GEMM with bf16 operands, f32 accumulate: REDUCED precision, not the headline; training f32)"}[args.forward_mode],
             "data": "synthetic", "dp_replicas_consistent": dp_consistent,
             "config": {"workload": c["label"], "N_per_gpu": N, "K": K, "features": widths[0], "widths": widths,
                        "minibatch_per_gpu": args.minibatch, "optimizer": args.opt + "+weightdecay",
                        "featurize": "cached" if args.cached_features else "every-iteration (fused pdist+LayerNorm kernel)",
-                       "forward_mode": {0: "f32", 1: "bf16x3", 2: "bf16"}[args.forward_mode],
+                       "forward_mode": {0: "f32", 1: "bf16x3", 2: "bf16", 3: "f16x2"}[args.forward_mode],
                        "parallelism": f"dp{world} over N" if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu,
             "final_loss": iso.losses[-1],

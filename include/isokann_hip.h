@@ -100,7 +100,12 @@ typedef struct isk_config {
                                             product block, f32 accumulate (f32-equivalent accuracy at 2.7x the
                                             f32 MFMA rate),
                                             2 = plain bf16 operands (leading plane only), f32 accumulate: the C5
-                                            configuration of the baseline; outputs agree with f32 to ~1e-2 relative.
+                                            configuration of the baseline; outputs agree with f32 to ~1e-2 relative,
+                                            3 = split-f16: two scaled f16 planes per operand (22 mantissa bits; the
+                                            samples are written pre-split by the featurizer, the weights at the fold),
+                                            three f16 MFMAs per product block, f32 accumulate: f32-equivalent accuracy,
+                                            half the matrix work of mode 1 and no conversion in the GEMM loop.  Shapes
+                                            it does not cover (layered path, > 2048 features, > 682 atoms) run mode 1.
                                             Training kernels are f32 in every mode. */
 } isk_config;
 

@@ -113,8 +113,15 @@ struct isk_engine {
     float *d_theta = nullptr, *d_grad = nullptr, *d_m = nullptr, *d_v = nullptr;
     float* d_Wt[ISK_MAX_LAYERS] = {nullptr};
     float* d_bias[ISK_MAX_LAYERS] = {nullptr};
-    void* d_W16 = nullptr;           // split-bf16 planes of the folded layer-1 weights (forward_mode 1)
+    void* d_W16 = nullptr;           // split-bf16 / split-f16 planes of the folded layer-1 weights (forward_mode 1, 2, 3)
     bool w16_dirty = true;
+    // forward_mode 3 (split-f16 x2): the featurizer writes pre-split f16 planes + inverse row scales, the xs rows also in f32
+    bool planes = false;             // effective: mode 3 requested AND the register featurizer / fused kernels cover the shape
+    unsigned* d_wmax = nullptr;      // scratch word for the weight-tensor maximum
+    float* d_wscale = nullptr;       // [1] inverse scale of the weight planes
+    float* d_xscale = nullptr;       // [(N*K + N)] inverse row scales of d_xhat
+    float* d_xscale_alt = nullptr;   //             ... of d_xhat_alt
+    float* d_xs32 = nullptr;         // [N][Fp] f32 standardised xs rows (training kernels)
     // layered path (networks too wide for the fused kernels): per-layer images and HBM activations
     bool layered = false;
     void* d_W16L[ISK_MAX_LAYERS] = {nullptr};     // bf16 planes per layer (forward_mode 1)
@@ -141,6 +148,7 @@ struct isk_engine {
     hipGraphExec_t tg_exec = nullptr;    // the captured epoch: nb x (train_fwd1, train_tail, train_grad1, opt_step, fold)
     long long tg_bs = 0, tg_nb = 0;
     int tg_flags = -1;
+    const float* tg_xs = nullptr;        // the xs feature rows the captured launches read (the per-iteration buffer pair swaps)
     bool tg_disabled = false;
     // data
     long long N = 0, K = 0, D = 0;
@@ -193,6 +201,8 @@ static void free_data(isk_engine* e) {
     e->ys_ahead = false;
     if (e->tg_exec) { (void)hipGraphExecDestroy(e->tg_exec); e->tg_exec = nullptr; }
     free_dev(e->d_in_xs); free_dev(e->d_in_ys); free_dev(e->d_xhat); free_dev(e->d_xhat_alt); free_dev(e->d_out); free_dev(e->d_ks);
+    free_dev(e->d_xscale); free_dev(e->d_xscale_alt); free_dev(e->d_xs32);
+    e->d_xscale = e->d_xscale_alt = e->d_xs32 = nullptr;
     free_dev(e->d_target); free_dev(e->d_kw); e->d_kw = nullptr; free_dev(e->d_z1); free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm); free_dev(e->d_isa_work);
     e->d_isa_work = nullptr;
     free_dev(e->d_actA); free_dev(e->d_actB); e->d_actA = e->d_actB = nullptr;
@@ -283,6 +293,7 @@ static MlpFwdArgs fwd_args(const isk_engine* e, const float* X, long long S, flo
     }
     a.stride_a = std::max(sa, 4); a.stride_b = std::max(sb, 4);
     a.out = out; a.nout = e->nout;
+    a.wscale = e->d_wscale;          // a.xscale is set by the caller that owns the plane rows (forward_mode 3)
     isk_fwd_layout_biases(a);
     static const int skew = [] { const char* v = getenv("ISK_BF16_SKEW"); return v ? atoi(v) : 1; }();
     a.sched_skew = skew;
@@ -305,7 +316,7 @@ static TrainShape train_shape(const isk_engine* e) {
 static TrainBuffers train_buffers(const isk_engine* e) {
     TrainBuffers b;
     std::memset(&b, 0, sizeof(b));
-    b.xhat_xs = e->d_xhat + (long long)e->N * e->K * e->Fp;
+    b.xhat_xs = e->d_xs32;      // a buffer of its own: d_xhat / d_xhat_alt swap every iteration (and hold f16 planes in forward_mode 3)
     b.target = e->d_target; b.lossw = e->d_lossw; b.theta = e->d_theta;
     b.W1t = e->d_Wt[0]; b.bias1 = e->d_bias[0];
     b.a1 = e->d_z1; b.delta1 = e->d_delta1; b.part = e->d_part; b.grad = e->d_grad;
@@ -382,7 +393,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     e->cfg.pairs = nullptr;
     e->L = cfg->n_layers; e->F = F; e->Fp = isk_pad32(F); e->Din = Din; e->nout = nout;
     if (const char* fm = getenv("ISK_FWD_MODE")) e->cfg.forward_mode = atoi(fm);
-    if (e->cfg.forward_mode < 0 || e->cfg.forward_mode > 2) { delete e; return fail(ISK_EINVAL, "unknown forward_mode"); }
+    if (e->cfg.forward_mode < 0 || e->cfg.forward_mode > 3) { delete e; return fail(ISK_EINVAL, "unknown forward_mode"); }
     {
         bool fits = isk_pad16(cfg->widths[1]) / 16 <= ISK_MAX_NT;
         size_t tailw = 0, tail_train = 0;
@@ -431,6 +442,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     ALLOC(e->d_theta, pb); ALLOC(e->d_grad, pb * ISK_MAX_SLABS); ALLOC(e->d_m, pb); ALLOC(e->d_v, pb);
     ALLOC(e->d_loss_acc, 2 * sizeof(double)); ALLOC(e->d_status, sizeof(int)); ALLOC(e->d_mm, 2 * sizeof(float));
     ALLOC(e->d_bt, 2 * sizeof(double));
+    ALLOC(e->d_wmax, sizeof(unsigned)); ALLOC(e->d_wscale, sizeof(float));
     ALLOC(e->d_lossw, (size_t)nout * sizeof(float));
     ALLOC(e->d_At, (size_t)nout * nout * sizeof(float)); ALLOC(e->d_rowperm, (size_t)nout * sizeof(int));
     ALLOC(e->d_W16, (size_t)isk_bf16_chunks(e->Fp) * 32 * isk_pad16(cfg->widths[1]) * 3 * sizeof(uint16_t));
@@ -462,6 +474,16 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
         (void)hipMemset(e->d_zero, 0, (size_t)4096 * sizeof(float));
     }
 #undef ALLOC
+    if (e->cfg.forward_mode == 3) {
+        // split-f16 needs the register featurizer (it writes the planes) and the fused forward kernel; anything else
+        // (wide networks on the layered path, > 2048 features, > 682 atoms) runs the split-bf16 forward instead
+        FeatArgs fa = {};
+        fa.pairs = e->d_pairs; fa.packed_pairs = e->d_packed; fa.D = e->Din; fa.F = e->F; fa.Fp = e->Fp;
+        MlpFwdArgs f = fwd_args(e, nullptr, 0, nullptr);
+        f.xscale = e->d_wscale;      // any non-null pointer: only the shape is inspected
+        e->planes = !e->layered && isk_featurize_reg_ok(fa) && isk_mlp_fwd_f16x2_fits(f);
+        if (!e->planes) e->cfg.forward_mode = 1;
+    }
     (void)hipMemset(e->d_theta, 0, pb); (void)hipMemset(e->d_grad, 0, pb * ISK_MAX_SLABS);
     (void)hipMemset(e->d_m, 0, pb); (void)hipMemset(e->d_v, 0, pb);
     (void)hipMemset(e->d_loss_acc, 0, 2 * sizeof(double)); (void)hipMemset(e->d_status, 0, sizeof(int));
@@ -487,7 +509,7 @@ extern "C" void isk_destroy(isk_engine* e) {
     free_dev(e->d_loss_acc); free_dev(e->d_status); free_dev(e->d_mm); free_dev(e->d_lossw);
     free_dev(e->d_At); free_dev(e->d_rowperm); free_dev(e->d_pairs); free_dev(e->d_packed); free_dev(e->d_isa_work_dp);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_Wt[l]); free_dev(e->d_bias[l]); }
-    free_dev(e->d_W16);
+    free_dev(e->d_W16); free_dev(e->d_wmax); free_dev(e->d_wscale);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_W16L[l]); free_dev(e->d_WtT[l]); }
     free_dev(e->d_G0); free_dev(e->d_D0); free_dev(e->d_zero); free_dev(e->d_W0g);
     blas_release(e);
@@ -579,13 +601,17 @@ extern "C" int isk_reset_opt_state(isk_engine* e) {
 // ---------------------------------------------------------------------------------------
 // data
 // ---------------------------------------------------------------------------------------
-static void featurize_rows(isk_engine* e, const float* in, long long S, float* xhat, hipStream_t st = nullptr) {
+// xscale != nullptr: split-f16 planes (forward_mode 3) with the inverse row scales there; xs32: the same rows in f32 as well
+static void featurize_rows(isk_engine* e, const float* in, long long S, float* xhat, hipStream_t st = nullptr, float* xscale = nullptr,
+                           float* xs32 = nullptr) {
     FeatArgs a = {};
     a.in = in; a.pairs = e->d_pairs; a.packed_pairs = e->d_packed; a.xhat = xhat; a.S = S; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
     a.background = (st != nullptr);
+    a.planes = xscale != nullptr; a.xscale = xscale; a.xhat32 = xs32;
     isk_launch_featurize(a, st ? st : e->stream);
 }
+static float* xs_scale_of(const isk_engine* e, float* xscale) { return xscale ? xscale + e->N * e->K : nullptr; }
 
 // per-iteration featurization.  ys (the 95 % share) may already have been produced on the side
 // stream, into the other buffer of the pair, while the previous iteration's MFMA-bound forward was
@@ -596,20 +622,21 @@ static void featurize_resident(isk_engine* e) {
         // the xs rows of the other buffer do not depend on the side stream: featurize them BEFORE waiting for it, so
         // the (un-throttled) xs launch runs under the tail of the throttled ys featurization instead of after it
         std::swap(e->d_xhat, e->d_xhat_alt);
+        std::swap(e->d_xscale, e->d_xscale_alt);
         e->ys_ahead = false;
         {
             ScopedTimer t(e, ISK_T_FEATURIZE);
-            featurize_rows(e, e->d_in_xs, e->N, e->d_xhat + (long long)e->N * e->K * e->Fp);
+            featurize_rows(e, e->d_in_xs, e->N, e->d_xhat + (long long)e->N * e->K * e->Fp, nullptr, xs_scale_of(e, e->d_xscale), e->d_xs32);
         }
         fold_ahead(e);                  // the weight planes of the coming forward: also ahead of the wait
         (void)hipStreamWaitEvent(e->stream, e->ev_ys_ready, 0);
         return;
     } else {
         ScopedTimer t(e, ISK_T_FEATURIZE);
-        featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat);
+        featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat, nullptr, e->d_xscale);
     }
     ScopedTimer t(e, ISK_T_FEATURIZE);
-    featurize_rows(e, e->d_in_xs, e->N, e->d_xhat + (long long)e->N * e->K * e->Fp);
+    featurize_rows(e, e->d_in_xs, e->N, e->d_xhat + (long long)e->N * e->K * e->Fp, nullptr, xs_scale_of(e, e->d_xscale), e->d_xs32);
 }
 
 // Where the next iteration's ys featurization runs (ISK_OVERLAP_FEATURIZE):
@@ -636,7 +663,7 @@ static void featurize_ys_ahead(isk_engine* e) {
     (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
     {
         ScopedTimer t(e, ISK_T_FEATURIZE, e->side);
-        featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat_alt, e->side);
+        featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat_alt, e->side, e->d_xscale_alt);
     }
     (void)hipEventRecord(e->ev_ys_ready, e->side);
     e->ys_ahead = true;
@@ -653,7 +680,7 @@ static void featurize_ys_beside_training(isk_engine* e, long long train_launch_s
     (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
     {
         ScopedTimer t(e, ISK_T_FEATURIZE, e->side);
-        featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat_alt, e->side);
+        featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat_alt, e->side, e->d_xscale_alt);
     }
     (void)hipEventRecord(e->ev_ys_ready, e->side);
     e->ys_ahead = true;
@@ -684,6 +711,11 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
     HIPCHK(hipMalloc((void**)&e->d_in_ys, (size_t)N * K * D * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_xhat, (size_t)S * e->Fp * sizeof(float)));
     if (e->cfg.featurize_every_iteration) HIPCHK(hipMalloc((void**)&e->d_xhat_alt, (size_t)S * e->Fp * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&e->d_xs32, (size_t)N * e->Fp * sizeof(float)));
+    if (e->planes) {
+        HIPCHK(hipMalloc((void**)&e->d_xscale, (size_t)S * sizeof(float)));
+        if (e->cfg.featurize_every_iteration) HIPCHK(hipMalloc((void**)&e->d_xscale_alt, (size_t)S * sizeof(float)));
+    }
     HIPCHK(hipMalloc((void**)&e->d_out, (size_t)S * e->nout * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_ks, (size_t)N * e->nout * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_target, (size_t)N * e->nout * sizeof(float)));
@@ -780,10 +812,11 @@ extern "C" int isk_features(isk_engine* e, const float* coords, int64_t D, int64
 
 // x rows already on the device as raw features [ncols][F] or coords [ncols][Din]
 static int forward_cols(isk_engine* e, const float* host_in, int64_t rowlen, int64_t ncols, bool is_coords, float* out) {
-    TmpBuf in, xh, o;
+    TmpBuf in, xh, o, xsc;
     HIPCHK(hipMalloc(&in.p, (size_t)ncols * rowlen * sizeof(float)));
     HIPCHK(hipMalloc(&xh.p, (size_t)ncols * e->Fp * sizeof(float)));
     HIPCHK(hipMalloc(&o.p, (size_t)ncols * e->nout * sizeof(float)));
+    if (e->planes) HIPCHK(hipMalloc(&xsc.p, (size_t)ncols * sizeof(float)));
     HIPCHK(hipMemcpyAsync(in.p, host_in, (size_t)ncols * rowlen * sizeof(float), hipMemcpyHostToDevice, e->stream));
     FeatArgs a = {};
     a.in = (const float*)in.p; a.pairs = is_coords ? e->d_pairs : nullptr; a.packed_pairs = is_coords ? e->d_packed : nullptr;
@@ -791,8 +824,10 @@ static int forward_cols(isk_engine* e, const float* host_in, int64_t rowlen, int
     a.D = (int)rowlen; a.F = e->F; a.Fp = e->Fp;
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
     a.background = 0;
+    a.planes = e->planes; a.xscale = (float*)xsc.p;
     isk_launch_featurize(a, e->stream);
     MlpFwdArgs f = fwd_args(e, (const float*)xh.p, ncols, (float*)o.p);
+    f.xscale = (const float*)xsc.p;
     if (launch_forward(e, f) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
     HIPCHK(hipMemcpyAsync(out, o.p, (size_t)ncols * e->nout * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -826,8 +861,9 @@ static int bf16_planes(const isk_engine* e) { return e->cfg.forward_mode == 1 ? 
 // stream is about to wait for)
 static void fold_ahead(isk_engine* e) {
     const int planes = bf16_planes(e);
-    if (e->layered || !planes || !e->w16_dirty) return;
-    isk_launch_fold_bf16(e->d_Wt[0], e->d_W16, e->Fp, isk_pad16(e->cfg.widths[1]) / 16, planes, e->stream);
+    if (e->layered || !(planes || e->planes) || !e->w16_dirty) return;
+    if (e->planes) isk_launch_fold_f16(e->d_Wt[0], e->d_W16, e->Fp, isk_pad16(e->cfg.widths[1]) / 16, e->d_wmax, e->d_wscale, e->stream);
+    else isk_launch_fold_bf16(e->d_Wt[0], e->d_W16, e->Fp, isk_pad16(e->cfg.widths[1]) / 16, planes, e->stream);
     e->w16_dirty = false;
 }
 
@@ -903,6 +939,12 @@ static int launch_forward(isk_engine* e, const MlpFwdArgs& f) {
         }
         return forward_layered(e, f.X, f.S, f.out, a, b);
     }
+    if (e->planes) {
+        // the rows are f16 planes: no other kernel can read them
+        if (!f.xscale) return ISK_EUNSUPPORTED;
+        fold_ahead(e);
+        return isk_launch_mlp_fwd_f16x2(f, e->d_W16, e->stream);
+    }
     if (const int planes = bf16_planes(e)) {
         if (e->w16_dirty) {
             isk_launch_fold_bf16(e->d_Wt[0], e->d_W16, e->Fp, f.nt1, planes, e->stream);
@@ -934,6 +976,7 @@ static int forward_resident(isk_engine* e, int which, bool ahead = false) {
     {
         ScopedTimer t(e, tid);
         MlpFwdArgs f = fwd_args(e, X, S, out);
+        if (e->planes) f.xscale = e->d_xscale + (which == 2 ? nys : 0);
         // diagnostic only (ISK_DEBUG_STAMPS=1 with a -DISK_STAMP build of the bf16x3 kernel): phase cycle sums
         static const bool stamps = getenv("ISK_DEBUG_STAMPS") != nullptr;
         static unsigned long long* dbg_st = nullptr;
@@ -1244,9 +1287,10 @@ static int compute_target(isk_engine* e, bool check, bool ahead = false) {
 static int koopman_cols(isk_engine* e, const float* ys, int64_t D, int64_t K, int64_t ncols, float* out_host) {
     const bool is_coords = e->cfg.featurizer != ISK_FEAT_IDENTITY;
     const long long S = K * ncols;
-    TmpBuf in, xh, o, ks;
+    TmpBuf in, xh, o, ks, xsc;
     HIPCHK(hipMalloc(&in.p, (size_t)S * D * sizeof(float)));
     HIPCHK(hipMalloc(&xh.p, (size_t)S * e->Fp * sizeof(float)));
+    if (e->planes) HIPCHK(hipMalloc(&xsc.p, (size_t)S * sizeof(float)));
     HIPCHK(hipMalloc(&o.p, (size_t)S * e->nout * sizeof(float)));
     HIPCHK(hipMalloc(&ks.p, (size_t)ncols * e->nout * sizeof(float)));
     HIPCHK(hipMemcpyAsync(in.p, ys, (size_t)S * D * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -1254,8 +1298,10 @@ static int koopman_cols(isk_engine* e, const float* ys, int64_t D, int64_t K, in
     a.in = (const float*)in.p; a.pairs = is_coords ? e->d_pairs : nullptr; a.packed_pairs = is_coords ? e->d_packed : nullptr;
     a.xhat = (float*)xh.p; a.S = S; a.D = (int)D; a.F = e->F; a.Fp = e->Fp;
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps; a.background = 0;
+    a.planes = e->planes; a.xscale = (float*)xsc.p;
     isk_launch_featurize(a, e->stream);
     MlpFwdArgs f = fwd_args(e, (const float*)xh.p, S, (float*)o.p);
+    f.xscale = (const float*)xsc.p;
     if (launch_forward(e, f) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
     KmeanArgs k;
     k.out_ys = (const float*)o.p; k.ks = (float*)ks.p; k.w = nullptr; k.N = ncols; k.K = (int)K; k.nout = e->nout;
@@ -1464,7 +1510,7 @@ static bool launch_grads_layered_blas(isk_engine* e, const int* d_idx, int B, fl
     if (!blas_ready(e)) return false;
     const int L = e->L;
     const long long Bpad = ((B + 15) / 16) * 16;
-    const float* xs = e->d_xhat + (long long)e->N * e->K * e->Fp;
+    const float* xs = e->d_xs32;
     hipStream_t st = e->stream;
     const float one = 1.f, zero = 0.f;
     const float* X0 = xs;
@@ -1517,7 +1563,7 @@ static void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float i
     if (launch_grads_layered_blas(e, d_idx, B, inv_div)) return;
     const int L = e->L;
     const long long Bpad = ((B + 15) / 16) * 16;
-    const float* xs = e->d_xhat + (long long)e->N * e->K * e->Fp;
+    const float* xs = e->d_xs32;
     hipStream_t st = e->stream;
     for (int l = 0; l < L; ++l) {
         const int N = e->cfg.widths[l + 1], Np = isk_pad16(N);
@@ -1632,7 +1678,8 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
     const int nslab = pick_slabs((int)bs);
     const int flags = nslab | (e->ys_ahead ? 0x100 : 0);
     if (!prepare_dev_bt(e)) return false;
-    if (!e->tg_exec || e->tg_bs != bs || e->tg_nb != nb || e->tg_flags != flags) {
+    const float* xs_rows = e->d_xs32;                    // part of the key: set_data re-allocates it
+    if (!e->tg_exec || e->tg_bs != bs || e->tg_nb != nb || e->tg_flags != flags || e->tg_xs != xs_rows) {
         if (e->tg_exec) { (void)hipGraphExecDestroy(e->tg_exec); e->tg_exec = nullptr; }
         const double s1 = e->bt1, s2 = e->bt2;
         if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
@@ -1655,7 +1702,7 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
             e->tg_disabled = true;
             return false;
         }
-        e->tg_bs = bs; e->tg_nb = nb; e->tg_flags = flags;
+        e->tg_bs = bs; e->tg_nb = nb; e->tg_flags = flags; e->tg_xs = xs_rows;
     } else {
         // what the launch functions keep track of on the host
         for (long long b = 0; b < nb; ++b) { e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2; }

@@ -13,6 +13,14 @@
 // rows stay private to a wave: f32 global -> VGPR in fragment shape, split into planes in registers.  Tail layers,
 // bias and activation are the f32 code shared with the f32 kernel (fwd_common.hpp).  The main loop is scheduled by
 // hand -- see the comment above PipeGeom for what the first version of this kernel lost and why.
+//
+// PRE = true ("split-f16 x2", forward_mode 3): the same pipeline with BOTH operands pre-split into two scaled f16 planes
+//      a * 2^s = hi + lo,  hi = f16(a 2^s), lo = f16(a 2^s - hi)                              (22 mantissa bits)
+// -- the samples by the featurizer (FeatArgs.planes: per-row scale, 128 B per 32-feature chunk = [hi | lo], the same
+// bytes as the f32 row), the weights by fold_f16_kernel (per-tensor scale) -- and a.b accumulated from THREE
+// v_mfma_f32_16x16x32_f16 (lo.hi + hi.lo + hi.hi; dropped lo.lo <= 2^-24 relative), rescaled once in the epilogue.
+// Half the matrix work of the bf16 split and no conversion VALU in the loop: the kernel becomes HBM-bound on the
+// sample stream (4*Fp bytes per row).
 #pragma once
 #include <cstdlib>
 #include <utility>
@@ -20,6 +28,7 @@
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct Planes {
     bf16x8 p0, p1, p2;
@@ -130,7 +139,7 @@ __device__ __forceinline__ void static_for_tiles(std::integer_sequence<int, Ts..
 #else
 #define X_LD(p) (*(p))
 #endif
-template <int NT, int U, int NTHR, bool EARLY, int NPL>
+template <int NT, int U, int NTHR, bool EARLY, int NPL, bool PRE>
 __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __restrict__ W16, u32x4* wbuf, const float* const (&xp)[U],
                                           int nch, int lane, f32x4 (&acc)[U][NT]
 #if ISK_STAMP
@@ -141,6 +150,8 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
     constexpr int STAGE16 = G::STAGE16, PER_T = G::PER_T, NX = G::NX, SLOTS = G::SLOTS;
     constexpr int TBAR = G::tile_dw(PER_T - 1);          // the stage's barrier follows the tile with the last LDS write
     constexpr bool XPF = TBAR < NT - 1;                  // next stage's first fragments can be fetched before this stage ends
+    constexpr int PXH = PRE ? 16 : PX_H;                 // float offset of a lane's second 16-byte load: the lo plane / the second half
+    static_assert(!PRE || NPL == 2, "pre-split samples come as two f16 planes");
     const int tid = threadIdx.x;
     const int last = nch - 1;
     const int nchp = (nch + 1) & ~1;
@@ -166,8 +177,8 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            xr[0][u][h] = *(const f32x4v*)(xp[u] + PX_H * h);
-            xr[1][u][h] = *(const f32x4v*)(xp[u] + (last > 0 ? PX_CH : 0) + PX_H * h);
+            xr[0][u][h] = *(const f32x4v*)(xp[u] + PXH * h);
+            xr[1][u][h] = *(const f32x4v*)(xp[u] + (last > 0 ? PX_CH : 0) + PXH * h);
         }
     __syncthreads();                                     // the previous pass's epilogue scratch aliases the buffers
 #pragma unroll
@@ -176,8 +187,13 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
     Planes cur[U], nxt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        split_half<0, NPL>(cur[u], xr[0][u][0]);
-        split_half<1, NPL>(cur[u], xr[0][u][1]);
+        if (PRE) {                                       // the loaded bytes ARE the operands
+            cur[u].p0 = __builtin_bit_cast(bf16x8, xr[0][u][0]);
+            cur[u].p1 = __builtin_bit_cast(bf16x8, xr[0][u][1]);
+        } else {
+            split_half<0, NPL>(cur[u], xr[0][u][0]);
+            split_half<1, NPL>(cur[u], xr[0][u][1]);
+        }
         nxt[u] = cur[u];
     }
     // consume every prologue load here, so the loop is entered with a clean vmcnt state and the waits inside
@@ -222,7 +238,12 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl) wf[fb ^ 1][pl] = wln[(pl * NT) * 64 + lane];
                 }
-                if (NPL == 1) {
+                if (PRE) {
+                    const f16x8 wh = __builtin_bit_cast(f16x8, wf[fb][0]), wl = __builtin_bit_cast(f16x8, wf[fb][NPL > 1 ? 1 : 0]);
+#define F_(P_, W_) _Pragma("unroll") for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, cur[u].P_), W_, acc[u][t], 0, 0, 0);
+                    F_(p1, wh) F_(p0, wl) F_(p0, wh)
+#undef F_
+                } else if (NPL == 1) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u].p0, wf[fb][0], acc[u][t], 0, 0, 0);
                 } else {
@@ -235,7 +256,7 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
                 // ---- this tile's share of the stage's side work
 #pragma unroll
                 for (int i = 0; i < NX; ++i)
-                    if (G::tile_x(i) == t && ISK_ABLATE != 12) xr[s][i >> 1][i & 1] = X_LD((const f32x4v*)(xp[i >> 1] + cx * PX_CH + PX_H * (i & 1)));
+                    if (G::tile_x(i) == t && ISK_ABLATE != 12) xr[s][i >> 1][i & 1] = X_LD((const f32x4v*)(xp[i >> 1] + cx * PX_CH + PXH * (i & 1)));
 #pragma unroll
                 for (int i = 0; i < PER_T; ++i)
                     if (G::tile_dw(i) == t && ISK_ABLATE != 14) wr[i * NTHR + tid] = wreg[i];
@@ -244,7 +265,7 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
                     if (G::tile_wl(i) == t && ISK_ABLATE != 14) wreg[i] = wc[goff[i]];
 #pragma unroll
                 for (int i = 0; i < NX; ++i)
-                    if (G::tile_sp(i) == t && ISK_ABLATE != 13) {
+                    if (!PRE && G::tile_sp(i) == t && ISK_ABLATE != 13) {
                         if (i & 1) split_half<1, NPL>(nxt[i >> 1], xr[s ^ 1][i >> 1][1]);
                         else split_half<0, NPL>(nxt[i >> 1], xr[s ^ 1][i >> 1][0]);
                     }
@@ -257,7 +278,12 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
                 }
             });
 #pragma unroll
-            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+            for (int u = 0; u < U; ++u) {
+                if (PRE) {                                   // chunk c + 1 landed in the other ring slot during stage c - 1
+                    cur[u].p0 = __builtin_bit_cast(bf16x8, xr[s ^ 1][u][0]);
+                    cur[u].p1 = __builtin_bit_cast(bf16x8, xr[s ^ 1][u][1]);
+                } else cur[u] = nxt[u];
+            }
             rdi = wri;
         }
     }
@@ -266,7 +292,7 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
     STAMP(4);
 }
 
-template <int NT, int U, int NWV, bool EARLY, int NPL, bool DENSE>
+template <int NT, int U, int NWV, bool EARLY, int NPL, bool DENSE, bool PRE>
 __device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __restrict__ W16, float* smem, long long u0, int nact, int col_shift
 #if ISK_STAMP
                                          , unsigned long long (&g_ph)[8], unsigned long long& g_t
@@ -295,8 +321,24 @@ __device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __res
             xp[u] = a.X + ub * 16 * (long long)a.Fp + lane * 4;
         }
 #else
-        xp[u] = a.X + r * (long long)a.Fp + lq * 8;
+        xp[u] = a.X + r * (long long)a.Fp + lq * (PRE ? 4 : 8);
 #endif
+    }
+    // pre-split operands: the inverse scales of this lane's four accumulator rows (row = 4 lq + r), fetched before the
+    // pass so the epilogue does not wait on them
+    float rsc[U][4];
+    if (PRE) {
+        const float wsc = a.wscale[0];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                long long r = (u0 + u) * 16 + lq * 4 + r4;
+                if (r > a.S - 1) r = a.S - 1;
+                if (r < 0) r = 0;
+                if (a.rows) r = a.rows[r];
+                rsc[u][r4] = a.xscale[r] * wsc;
+            }
     }
     f32x4 acc[U][NT];
 #pragma unroll
@@ -305,10 +347,18 @@ __device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __res
         for (int t = 0; t < NT; ++t) acc[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // a wave without a unit in this pass computes on clamped rows and discards the result
 #if ISK_STAMP
-    pipe_pass<NT, U, NWV * 64, EARLY, NPL>(a, (const u32x4*)W16, wbuf, xp, a.Fp / 32, lane, acc, g_ph, g_t);
+    pipe_pass<NT, U, NWV * 64, EARLY, NPL, PRE>(a, (const u32x4*)W16, wbuf, xp, a.Fp / 32, lane, acc, g_ph, g_t);
 #else
-    pipe_pass<NT, U, NWV * 64, EARLY, NPL>(a, (const u32x4*)W16, wbuf, xp, a.Fp / 32, lane, acc);
+    pipe_pass<NT, U, NWV * 64, EARLY, NPL, PRE>(a, (const u32x4*)W16, wbuf, xp, a.Fp / 32, lane, acc);
 #endif
+    if (PRE) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) acc[u][t][r4] *= rsc[u][r4];
+    }
     // spelled out: with the unit index a loop variable hipcc may decline to unroll the (large) epilogue and then
     // keeps the whole accumulator array in scratch memory
     if (0 < nact) unit_tail<NT, DENSE>(a, acc[0], u0 * 16, scrA, scrB, smem, lane, col_shift);
@@ -317,7 +367,7 @@ __device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __res
     STAMP(5);
 }
 
-template <int NT, int NWV, int NPL, bool DENSE>
+template <int NT, int NWV, int NPL, bool DENSE, bool PRE = false>
 __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3p_kernel(MlpFwdArgs a, const uint4* __restrict__ W16, long long units,
                                                                    long long units_per_wave) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -342,7 +392,7 @@ __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3p_kernel(MlpFwdArgs a,
     const long long npass = (units_per_wave + 1) / 2;              // identical for every wave: barriers inside
     // a workgroup's waves go to the SIMDs cyclically, so waves w and w + 4 share one: give them different schedules
     static_assert(NWV == 4 || NWV == 8, "wave count");
-    const bool early = NWV == 8 && (threadIdx.x >> 8) != 0 && a.sched_skew;
+    const bool early = !PRE && NWV == 8 && (threadIdx.x >> 8) != 0 && a.sched_skew;    // PRE: no conversion work to skew
 #if ISK_STAMP
     unsigned long long g_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long g_t0 = __builtin_amdgcn_s_memtime(), g_rt0 = __builtin_amdgcn_s_memrealtime();
@@ -350,9 +400,9 @@ __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3p_kernel(MlpFwdArgs a,
     for (long long p = 0; p < npass; ++p) {
         const long long u = ustart + 2 * p;
         if (u + 1 < uend) {
-            if (early) pipe_run<NT, 2, NWV, true, NPL, DENSE>(a, W16, smem, u, 2, col_shift, g_ph, g_t);
-            else pipe_run<NT, 2, NWV, false, NPL, DENSE>(a, W16, smem, u, 2, col_shift, g_ph, g_t);
-        } else pipe_run<NT, 1, NWV, false, NPL, DENSE>(a, W16, smem, u, u < uend ? 1 : 0, col_shift, g_ph, g_t);
+            if (early) pipe_run<NT, 2, NWV, true, NPL, DENSE, PRE>(a, W16, smem, u, 2, col_shift, g_ph, g_t);
+            else pipe_run<NT, 2, NWV, false, NPL, DENSE, PRE>(a, W16, smem, u, 2, col_shift, g_ph, g_t);
+        } else pipe_run<NT, 1, NWV, false, NPL, DENSE, PRE>(a, W16, smem, u, u < uend ? 1 : 0, col_shift, g_ph, g_t);
     }
     if (a.dbg && (threadIdx.x & 63) == 0) {
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
@@ -364,9 +414,9 @@ __global__ __launch_bounds__(NWV * 64) void mlp_fwd_bf16x3p_kernel(MlpFwdArgs a,
     for (long long p = 0; p < npass; ++p) {
         const long long u = ustart + 2 * p;
         if (u + 1 < uend) {                                                            // wave-uniform
-            if (early) pipe_run<NT, 2, NWV, true, NPL, DENSE>(a, W16, smem, u, 2, col_shift);
-            else pipe_run<NT, 2, NWV, false, NPL, DENSE>(a, W16, smem, u, 2, col_shift);
-        } else pipe_run<NT, 1, NWV, false, NPL, DENSE>(a, W16, smem, u, u < uend ? 1 : 0, col_shift);
+            if (early) pipe_run<NT, 2, NWV, true, NPL, DENSE, PRE>(a, W16, smem, u, 2, col_shift);
+            else pipe_run<NT, 2, NWV, false, NPL, DENSE, PRE>(a, W16, smem, u, 2, col_shift);
+        } else pipe_run<NT, 1, NWV, false, NPL, DENSE, PRE>(a, W16, smem, u, u < uend ? 1 : 0, col_shift);
     }
 #endif
 }
@@ -379,7 +429,7 @@ static size_t pipe_lds_bytes(const MlpFwdArgs& a) {
     return ((size_t)a.tailw_floats + (wb > scr ? wb : scr)) * sizeof(float);
 }
 
-template <int NT, int NWV, int NPL, bool DENSE>
+template <int NT, int NWV, int NPL, bool DENSE, bool PRE = false>
 static void launch_pipe_nw(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
     const long long units = (a.S + 15) / 16;
     const int G = (DENSE && a.dense_groups > 1) ? a.dense_groups : 1;
@@ -391,8 +441,8 @@ static void launch_pipe_nw(const MlpFwdArgs& a, const void* W16, hipStream_t st)
     if (G > 1) blocks = (blocks + 7) / 8 * 8 * G;               // whole XCD rounds of row shares, G column blocks each
     const size_t lds = pipe_lds_bytes<NT, NWV, NPL, DENSE>(a);
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16x3p_kernel<NT, NWV, NPL, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((mlp_fwd_bf16x3p_kernel<NT, NWV, NPL, DENSE>), dim3((unsigned)blocks), dim3(NWV * 64), lds, st, a, (const uint4*)W16, units, upw);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_bf16x3p_kernel<NT, NWV, NPL, DENSE, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mlp_fwd_bf16x3p_kernel<NT, NWV, NPL, DENSE, PRE>), dim3((unsigned)blocks), dim3(NWV * 64), lds, st, a, (const uint4*)W16, units, upw);
 }
 
 template <int NT, int NPL, bool DENSE>
@@ -402,5 +452,14 @@ static int launch_pipe_nt(const MlpFwdArgs& a, const void* W16, hipStream_t st) 
     if (NPL == 3 && !DENSE) {     // the fused split kernel's per-wave epilogue scratch can outgrow the ring with 8 waves
         if (pipe_lds_bytes<NT, 4, 3, false>(a) <= cap) { launch_pipe_nw<NT, 4, 3, false>(a, W16, st); return 0; }
     }
+    return ISK_EUNSUPPORTED;
+}
+
+// split-f16 x2 (pre-split samples): fused networks only
+template <int NT>
+static int launch_pipe_f16(const MlpFwdArgs& a, const void* W16, hipStream_t st, bool dry = false) {
+    const size_t cap = 158 * 1024;
+    if (pipe_lds_bytes<NT, 8, 2, false>(a) <= cap) { if (!dry) launch_pipe_nw<NT, 8, 2, false, true>(a, W16, st); return 0; }
+    if (pipe_lds_bytes<NT, 4, 2, false>(a) <= cap) { if (!dry) launch_pipe_nw<NT, 4, 2, false, true>(a, W16, st); return 0; }
     return ISK_EUNSUPPORTED;
 }

@@ -28,6 +28,20 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// power-of-two scale that brings a row (or tensor) maximum m into [2^14, 2^15): the largest f16 exponent range that cannot
+// overflow.  sc = 2^(141 - ex), inv = 2^(ex - 141) with ex the biased exponent of m; zero / tiny / non-finite maxima keep 1.
+__host__ __device__ __forceinline__ void isk_f16_scale(float m, float& sc, float& inv) {
+    unsigned ub;
+    __builtin_memcpy(&ub, &m, 4);
+    const int ex = (int)((ub >> 23) & 0xffu);
+    sc = 1.f; inv = 1.f;
+    if (ex >= 15 && ex != 255) {
+        const unsigned sb = (unsigned)(268 - ex) << 23, ib = (unsigned)(ex - 14) << 23;
+        __builtin_memcpy(&sc, &sb, 4);
+        __builtin_memcpy(&inv, &ib, 4);
+    }
+}
+
 __device__ __forceinline__ float act_apply(int act, float z) {
     switch (act) {
         case ISK_ACT_SIGMOID: {

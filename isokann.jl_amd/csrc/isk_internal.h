@@ -27,8 +27,14 @@ struct FeatArgs {
     int background;         // launched on the side stream next to other kernels: may be throttled
     float* raw;             // optional [S][Fp]: un-normalised features (needed by the coordinate pullback)
     float* stats;           // optional [S][2]: mean, 1/denominator of the LayerNorm standardisation
+    // split-f16 output (forward_mode 3; register featurizer only, see isk_featurize_reg_ok): xhat rows are written as
+    // [Fp/32 chunks][32 x f16 hi | 32 x f16 lo] of xhat * 2^s (same 4*Fp bytes per row), 2^-s goes to xscale[row]
+    int planes;
+    float* xscale;          // [S] inverse row scales (planes only)
+    float* xhat32;          // optional [S][Fp]: a second copy of the rows, always f32 (the xs rows the training kernels read)
 };
 void isk_launch_featurize(const FeatArgs& a, hipStream_t st);
+bool isk_featurize_reg_ok(const FeatArgs& a);
 
 // ---------------------------------------------------------------- forward ---------
 // Weight layout "fragment-linear": for layer with Kp inputs (multiple of 16) and Np outputs
@@ -64,6 +70,10 @@ struct MlpFwdArgs {
     int bias_lds0;          // float offset of the bias block: [bias1: nt1*16][tail 0 bias: ntiles*16]...
     int stride_a, stride_b; // floats per row of the two per-wave LDS ping-pong buffers (padded width + 4)
     int sched_skew;            // bf16x3 pipelined kernel: second wave of each SIMD converts early (0 = same schedule)
+    // split-f16 forward (forward_mode 3): X holds pre-split f16 planes (FeatArgs.planes), xscale the inverse row scales,
+    // wscale[0] the inverse scale of the weight planes (isk_launch_fold_f16); z = acc * xscale[row] * wscale[0]
+    const float* xscale;
+    const float* wscale;
     unsigned long long* dbg;   // diagnostic builds only (-DISK_STAMP): per-wave phase cycle sums, else nullptr
 };
 // append the bias block to the LDS image (call once nt1 / ntail / tail[] / tailw_floats are final)
@@ -78,6 +88,11 @@ int  isk_launch_mlp_fwd(const MlpFwdArgs& a, hipStream_t st);   // returns 0 or 
 // planes: 3 = split-bf16 (f32-equivalent), 1 = plain bf16 operands (forward_mode 2); the image from isk_launch_fold_bf16 must match
 int  isk_launch_mlp_fwd_bf16x3(const MlpFwdArgs& a, const void* W16, int planes, hipStream_t st);
 void isk_launch_fold_bf16(const float* Wt, void* out, int Kp, int nt, int planes, hipStream_t st);
+// split-f16 variant (forward_mode 3): W16 = two scaled f16 planes from isk_launch_fold_f16, samples pre-split by the featurizer
+int  isk_launch_mlp_fwd_f16x2(const MlpFwdArgs& a, const void* W16, hipStream_t st);
+int  isk_mlp_fwd_f16x2_fits(const MlpFwdArgs& a);   // 1 when the shape's LDS footprint fits the split-f16 kernel (a.xscale / a.wscale set)
+// wmax: one zero-initialised word (scratch for the tensor maximum), wscale_inv[0] <- inverse scale of the planes
+void isk_launch_fold_f16(const float* Wt, void* out, int Kp, int nt, unsigned* wmax, float* wscale_inv, hipStream_t st);
 #define ISK_MAX_NT_BF16 16   // output tiles per workgroup of the plain-bf16 forward
 int  isk_bf16_chunks(int Kp);     // 32-feature chunks in the plane image (padded to the kernel's ring size)
 

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeatArgs a) {
                     for (int j = 0; j < 4; ++j) v[j] = (c + j < a.F) ? (v[j] - mu) * rstd : 0.f;
                 }
                 *(f32x4*)(orow + c) = v;
+                if (a.xhat32) *(f32x4*)(a.xhat32 + s * (long long)a.Fp + c) = v;
             }
         }
         __syncthreads();
@@ -112,8 +113,37 @@ typedef int isk_i32x4 __attribute__((ext_vector_type(4)));
 typedef float isk_f32x3 __attribute__((ext_vector_type(3)));
 __device__ isk_f32x3 isk_raw_buffer_load_f32x3(isk_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v3f32");
 
-template <int NFL, int NDL, bool PDIST, int PF = 1>
+typedef float isk_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 isk_f16x2 __attribute__((ext_vector_type(2)));
+__device__ void isk_raw_buffer_store_f32x2(isk_f32x2 v, isk_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
+__device__ void isk_raw_buffer_store_u32(unsigned v, isk_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i32");
+
+// max over the 64 lanes of NON-NEGATIVE values (0 is the identity the DPP fill relies on), same DPP ladder as wave_sum_dpp
+__device__ __forceinline__ float wave_max_dpp(float v) {
+#define ISK_DPP_MAX(ctrl, rmask)                                                                                   \
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false)))
+    ISK_DPP_MAX(0x111, 0xf);
+    ISK_DPP_MAX(0x112, 0xf);
+    ISK_DPP_MAX(0x114, 0xf);
+    ISK_DPP_MAX(0x118, 0xf);
+    ISK_DPP_MAX(0x142, 0xa);
+    ISK_DPP_MAX(0x143, 0xc);
+#undef ISK_DPP_MAX
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// Feature <-> register mapping: lane l keeps the ADJACENT features f = 128*(i/2) + 2*l + (i%2), i < NFL, so a row goes
+// out as 8-byte stores (512 contiguous bytes per wave instruction) and, in PLANES mode, an f16 pair is one dword.
+//
+// PLANES (forward_mode 3): the standardised row is written pre-split for the split-f16 forward GEMM
+// (fwd_f16 path in fwd_bf16_kernel.hpp): per 32-feature chunk 128 bytes = [32 x f16 hi | 32 x f16 lo] with
+//     xs = xhat * 2^s (row scale, maximum in [2^14, 2^15)),  hi = f16(xs),  lo = f16(xs - hi)      (22 mantissa bits)
+// and 2^-s goes to xscale[row].  Same bytes per row as the f32 image (4*Fp); the forward kernel then loads MFMA A
+// operands straight from HBM with no conversion work.
+template <int NFL, int NDL, bool PDIST, int PF = 1, bool PLANES = false>
 __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const unsigned* __restrict__ packed_pairs) {
+    static_assert(NFL % 2 == 0, "a lane holds adjacent feature pairs");
+    constexpr int NPB = NFL / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int natoms = a.D / 3;
@@ -122,7 +152,7 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
     if (PDIST) {
 #pragma unroll
         for (int i = 0; i < NFL; ++i) {
-            const int f = lane + 64 * i;
+            const int f = 128 * (i >> 1) + 2 * lane + (i & 1);
             pr[i] = (f < a.F) ? packed_pairs[f] : 0u;
         }
     }
@@ -143,18 +173,18 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
     // hardware.  That keeps the loop free of branches around memory instructions -- with them hipcc's wait-count
     // pass can only emit vmcnt(0), which made every wave sit out a full load + store round trip per sample (the
     // "prefetched" row included).
-    auto row_rsrc = [&](const float* base, long long srow, long long ld, int len) {
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + srow * ld), 0, srow < a.S ? len * 4 : 0, 0x00020000);
+    auto row_rv = [&](const float* base, long long srow, long long ld, int len) {
+        const unsigned long long p = (unsigned long long)(base + srow * ld);
+        isk_i32x4 rv;
+        rv[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+        rv[1] = __builtin_amdgcn_readfirstlane((int)((p >> 32) & 0xffffu));
+        rv[2] = __builtin_amdgcn_readfirstlane(srow < a.S ? len * 4 : 0);
+        rv[3] = 0x00020000;
+        return rv;
     };
     auto fetch = [&](float (&buf)[NIN], long long srow) {
-        const __amdgpu_buffer_rsrc_t r = row_rsrc(a.in, srow, a.D, a.D);
         if (PDIST) {
-            const unsigned long long p = (unsigned long long)(a.in + srow * (long long)a.D);
-            isk_i32x4 rv;
-            rv[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
-            rv[1] = __builtin_amdgcn_readfirstlane((int)((p >> 32) & 0xffffu));
-            rv[2] = __builtin_amdgcn_readfirstlane(srow < a.S ? a.D * 4 : 0);
-            rv[3] = 0x00020000;
+            const isk_i32x4 rv = row_rv(a.in, srow, a.D, a.D);
 #pragma unroll
             for (int u = 0; u < NAL; ++u) {
                 const isk_f32x3 v = isk_raw_buffer_load_f32x3(rv, (64 * u + lane) * 12, 0, FEAT_AUX);
@@ -163,8 +193,12 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
                 buf[3 * u + 2] = v[2];
             }
         } else {
+            // dword loads (a row of odd length would make the last 8-byte access straddle the descriptor's end)
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + srow * (long long)a.D), 0,
+                                                                               srow < a.S ? a.D * 4 : 0, 0x00020000);
 #pragma unroll
-            for (int u = 0; u < NIN; ++u) buf[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (64 * u + lane) * 4, 0, FEAT_AUX));
+            for (int u = 0; u < NIN; ++u)
+                buf[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (128 * (u >> 1) + 2 * lane + (u & 1)) * 4, 0, FEAT_AUX));
         }
     };
     auto one = [&](float (&buf)[NIN], long long srow) {
@@ -206,31 +240,57 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
         if (a.normalize) {
             float sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < NFL; ++i) sum += (lane + 64 * i < a.F) ? d[i] : 0.f;
+            for (int i = 0; i < NFL; ++i) sum += (128 * (i >> 1) + 2 * lane + (i & 1) < a.F) ? d[i] : 0.f;
             mu = wave_sum_dpp(sum) * invF;
             float ss = 0.f;
 #pragma unroll
             for (int i = 0; i < NFL; ++i) {
                 const float t = d[i] - mu;
-                ss += (lane + 64 * i < a.F) ? t * t : 0.f;
+                ss += (128 * (i >> 1) + 2 * lane + (i & 1) < a.F) ? t * t : 0.f;
             }
             const float var = wave_sum_dpp(ss) * invF;
             if (a.ln_mode == ISK_LN_VAR_EPS2) rstd = 1.0f / sqrtf(var + a.eps * a.eps);
             else if (a.ln_mode == ISK_LN_STD_EPS) rstd = 1.0f / (sqrtf(var) + a.eps);
             else rstd = 1.0f / sqrtf(var + a.eps);
         }
-        const __amdgpu_buffer_rsrc_t ro = row_rsrc(a.xhat, srow, a.Fp, a.Fp);
+        float xh[NFL];
 #pragma unroll
-        for (int i = 0; i < NFL; ++i) {
-            const int f = lane + 64 * i;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (f < a.F) ? (d[i] - mu) * rstd : 0.f), ro, f * 4, 0, FEAT_AUX);
+        for (int i = 0; i < NFL; ++i) xh[i] = (128 * (i >> 1) + 2 * lane + (i & 1) < a.F) ? (d[i] - mu) * rstd : 0.f;
+        if (PLANES) {
+            float m = 0.f;
+#pragma unroll
+            for (int i = 0; i < NFL; ++i) m = fmaxf(m, fabsf(xh[i]));
+            float sc, inv;
+            isk_f16_scale(wave_max_dpp(m), sc, inv);
+            const isk_i32x4 ro = row_rv(a.xhat, srow, a.Fp, a.Fp);
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+                const isk_f32x2 sv = {xh[2 * pb] * sc, xh[2 * pb + 1] * sc};
+                const isk_f16x2 hi = __builtin_convertvector(sv, isk_f16x2);
+                const isk_f16x2 lo = __builtin_convertvector(sv - __builtin_convertvector(hi, isk_f32x2), isk_f16x2);
+                const int off = 512 * pb + (lane >> 4) * 128 + (lane & 15) * 4;   // chunk 4 pb + lane/16, pair lane%16
+                isk_raw_buffer_store_u32(__builtin_bit_cast(unsigned, hi), ro, off, 0, FEAT_AUX);
+                isk_raw_buffer_store_u32(__builtin_bit_cast(unsigned, lo), ro, off + 64, 0, FEAT_AUX);
+            }
+            if (lane == 0 && srow < a.S) a.xscale[srow] = inv;
+        } else {
+            const isk_i32x4 ro = row_rv(a.xhat, srow, a.Fp, a.Fp);
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb)
+                isk_raw_buffer_store_f32x2((isk_f32x2){xh[2 * pb], xh[2 * pb + 1]}, ro, (128 * pb + 2 * lane) * 4, 0, FEAT_AUX);
+        }
+        if (a.xhat32) {                                      // wave-uniform: a second, f32 copy (the xs rows the training kernels read)
+            const isk_i32x4 r32 = row_rv(a.xhat32, srow, a.Fp, a.Fp);
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb)
+                isk_raw_buffer_store_f32x2((isk_f32x2){xh[2 * pb], xh[2 * pb + 1]}, r32, (128 * pb + 2 * lane) * 4, 0, 0);
         }
         if (a.raw) {                                         // wave-uniform: kept for the coordinate pullback
-            const __amdgpu_buffer_rsrc_t rr = row_rsrc(a.raw, srow, a.Fp, a.Fp);
+            const isk_i32x4 rr = row_rv(a.raw, srow, a.Fp, a.Fp);
 #pragma unroll
-            for (int i = 0; i < NFL; ++i) {
-                const int f = lane + 64 * i;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (f < a.F) ? d[i] : 0.f), rr, f * 4, 0, 0);
+            for (int pb = 0; pb < NPB; ++pb) {
+                const int f = 128 * pb + 2 * lane;
+                isk_raw_buffer_store_f32x2((isk_f32x2){(f < a.F) ? d[2 * pb] : 0.f, (f + 1 < a.F) ? d[2 * pb + 1] : 0.f}, rr, f * 4, 0, 0);
             }
         }
         if (a.stats && lane == 0 && srow < a.S) { a.stats[2 * srow] = mu; a.stats[2 * srow + 1] = rstd; }
@@ -261,17 +321,19 @@ static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream
     static const int bg_total = [] { const char* v = getenv("ISK_FEAT_BG_WGS"); return v ? atoi(v) : 0; }();
     if (a.background && bg_total > 0) cap = bg_total;          // tuning knob: background workgroups in total
     if (blocks > cap) blocks = cap;
+    void* args[] = {(void*)&a, (void*)&packed};
     if (pd) {
         // background launches keep two samples in flight per wave (ISK_FEAT_PF=1: one).  Measured on C3, same box:
         // 1.554 -> 1.533 ms/step; three in flight: 1.558
         static const int pf = [] { const char* v = getenv("ISK_FEAT_PF"); return v ? atoi(v) : 1; }();
-        const void* fn = (const void*)featurize_reg_kernel<NFL, NDL, true, 1>;
-        if (a.background && pf == 2) fn = (const void*)featurize_reg_kernel<NFL, NDL, true, 2>;
+        const void* fn = a.planes ? (const void*)featurize_reg_kernel<NFL, NDL, true, 1, true> : (const void*)featurize_reg_kernel<NFL, NDL, true, 1, false>;
+        if (a.background && pf == 2)
+            fn = a.planes ? (const void*)featurize_reg_kernel<NFL, NDL, true, 2, true> : (const void*)featurize_reg_kernel<NFL, NDL, true, 2, false>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        void* args[] = {(void*)&a, (void*)&packed};
         (void)hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), args, lds, st);
     } else {
-        hipLaunchKernelGGL((featurize_reg_kernel<NFL, 1, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, packed);
+        const void* fn = a.planes ? (const void*)featurize_reg_kernel<NFL, 1, false, 1, true> : (const void*)featurize_reg_kernel<NFL, 1, false, 1, false>;
+        (void)hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), args, 0, st);
     }
 }
 
@@ -284,14 +346,20 @@ static void launch_feat_nd(const FeatArgs& a, const unsigned* packed, hipStream_
     else launch_feat_reg<NFL, 32>(a, packed, st);
 }
 
+// the register-resident featurizer covers rows of <= 2048 padded features and (pairwise distances) <= 682 atoms with
+// 16-bit atom indices; everything else takes the LDS-stash fallback, which has no split-f16 (PLANES) output
+bool isk_featurize_reg_ok(const FeatArgs& a) {
+    const bool pd = a.pairs != nullptr;
+    const int need = (a.Fp + 63) / 64;
+    return need <= 32 && (!pd || (a.packed_pairs != nullptr && a.D <= 2048 && (size_t)4 * (a.D / 3) * 16 <= 150 * 1024));
+}
+
 void isk_launch_featurize(const FeatArgs& a, hipStream_t st) {
     if (a.S <= 0) return;
     const bool pd = a.pairs != nullptr;
     const int need = (a.Fp + 63) / 64;
-    const bool reg_ok = need <= 32 && (!pd || (a.packed_pairs != nullptr && a.D <= 2048 && (size_t)4 * (a.D / 3) * 16 <= 150 * 1024));
-    if (reg_ok) {
-        if (need <= 1) launch_feat_nd<1>(a, a.packed_pairs, st);
-        else if (need <= 2) launch_feat_nd<2>(a, a.packed_pairs, st);
+    if (isk_featurize_reg_ok(a)) {
+        if (need <= 2) launch_feat_nd<2>(a, a.packed_pairs, st);
         else if (need <= 4) launch_feat_nd<4>(a, a.packed_pairs, st);
         else if (need <= 8) launch_feat_nd<8>(a, a.packed_pairs, st);
         else if (need <= 16) launch_feat_nd<16>(a, a.packed_pairs, st);

@@ -32,6 +32,67 @@ __global__ __launch_bounds__(256) void fold_bf16_kernel(const float* __restrict_
     }
 }
 
+// split-f16 x2 weight planes (forward_mode 3): fp32 fragment-linear [chunk16][nt][64][4] -> f16 [chunk32][2][nt][64][8],
+// every weight scaled by the power of two that brings the tensor maximum into [2^14, 2^15) (isk_f16_scale):
+//   hi = f16(w 2^s), lo = f16(w 2^s - hi);   wscale_inv[0] = 2^-s for the forward epilogue
+__global__ __launch_bounds__(1024) void wmax_kernel(const float* __restrict__ Wt, long long n4, unsigned* __restrict__ slot) {
+    // one atomic per workgroup: a thousand same-address atomics cost ~12 ns each, serialised (measured 13.7 us with one per wave)
+    __shared__ float red[16];
+    const f32x4* W4 = (const f32x4*)Wt;
+    float m = 0.f;
+    for (long long e = (long long)blockIdx.x * 1024 + threadIdx.x; e < n4; e += (long long)gridDim.x * 1024) {
+        const f32x4 v = W4[e];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+        atomicMax(slot, __builtin_bit_cast(unsigned, m));     // non-negative floats order like their bit patterns
+    }
+}
+
+__global__ __launch_bounds__(256) void fold_f16_kernel(const float* __restrict__ Wt, _Float16* __restrict__ out, int nchunk32, int nt,
+                                                       int nchunk16, unsigned* __restrict__ wmax, float* __restrict__ wscale_inv) {
+    float sc, inv;
+    isk_f16_scale(__builtin_bit_cast(float, wmax[0]), sc, inv);
+    if (blockIdx.x == 0 && threadIdx.x == 0) wscale_inv[0] = inv;
+    const long long total = (long long)nchunk32 * nt * 64 * 8;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int j = e & 7;
+        const int lane = (e >> 3) & 63;
+        const long long ct = e >> 9;
+        const int t = (int)(ct % nt);
+        const int c32 = (int)(ct / nt);
+        const int li = lane & 15, kq = lane >> 4;
+        const int c16 = 2 * c32 + (kq >> 1);
+        const int k16 = 8 * (kq & 1) + j;
+        float w = 0.f;
+        if (c16 < nchunk16) w = Wt[(((long long)c16 * nt + t) * 64 + (((k16 >> 2) << 4) | li)) * 4 + (k16 & 3)] * sc;
+        const _Float16 hi = (_Float16)w;
+        const _Float16 lo = (_Float16)(w - (float)hi);
+        const long long base = (long long)c32 * 2 * nt;
+        out[((base + t) * 64 + lane) * 8 + j] = hi;
+        out[((base + nt + t) * 64 + lane) * 8 + j] = lo;
+    }
+}
+
+void isk_launch_fold_f16(const float* Wt, void* out, int Kp, int nt, unsigned* wmax, float* wscale_inv, hipStream_t st) {
+    const int nchunk32 = isk_bf16_chunks(Kp), nchunk16 = Kp / 16;
+    const long long nw = (long long)nchunk16 * nt * 256;
+    (void)hipMemsetAsync(wmax, 0, sizeof(unsigned), st);
+    int mb = (int)((nw / 4 + 1023) / 1024);              // the image is a whole number of 1 KiB fragments
+    if (mb > 64) mb = 64;
+    hipLaunchKernelGGL(wmax_kernel, dim3(mb), dim3(1024), 0, st, Wt, nw / 4, wmax);
+    const long long total = (long long)nchunk32 * nt * 64 * 8;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fold_f16_kernel, dim3(blocks), dim3(256), 0, st, Wt, (_Float16*)out, nchunk32, nt, nchunk16, wmax, wscale_inv);
+}
+
 // chunks in the plane image: padded with zero planes (the pipelined kernel runs an even number of stages)
 int isk_bf16_chunks(int Kp) { return ((Kp + 31) / 32 + 5) / 6 * 6; }
 
@@ -51,6 +112,26 @@ int isk_launch_mlp_fwd_bf16_dense(const MlpFwdArgs& a, const void* W16, int plan
 #else
 #define NTCASE(N_, P_) case N_: return launch_pipe_nt<N_, P_, false>(a, W16, st);
 #endif
+
+// fits(): dry run of the dispatch (LDS footprint of the shape)
+static int f16x2_dispatch(const MlpFwdArgs& a, const void* W16, hipStream_t st, bool dry) {
+    if (a.Fp % 32 != 0 || a.dense_mode || !a.xscale || !a.wscale) return ISK_EUNSUPPORTED;
+#ifdef ISK_DEV_NT9
+#define F16CASE(N_) case N_: if (N_ == 9) return launch_pipe_f16<9>(a, W16, st, dry); return ISK_EUNSUPPORTED;
+#else
+#define F16CASE(N_) case N_: return launch_pipe_f16<N_>(a, W16, st, dry);
+#endif
+    switch (a.nt1) {
+        F16CASE(1) F16CASE(2) F16CASE(3) F16CASE(4) F16CASE(5) F16CASE(6) F16CASE(7) F16CASE(8) F16CASE(9) F16CASE(10)
+        default: return ISK_EUNSUPPORTED;
+    }
+#undef F16CASE
+}
+int isk_launch_mlp_fwd_f16x2(const MlpFwdArgs& a, const void* W16, hipStream_t st) {
+    if (a.S <= 0) return 0;
+    return f16x2_dispatch(a, W16, st, false);
+}
+int isk_mlp_fwd_f16x2_fits(const MlpFwdArgs& a) { return f16x2_dispatch(a, nullptr, nullptr, true) == 0; }
 
 int isk_launch_mlp_fwd_bf16x3(const MlpFwdArgs& a, const void* W16, int planes, hipStream_t st) {
     if (a.S <= 0) return 0;

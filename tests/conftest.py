@@ -15,6 +15,24 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "own_fwd_mode: the test selects the forward arithmetic itself (not run once per mode)")
+
+
+# forward arithmetic of the Koopman forward GEMM (isk_config.forward_mode): every GPU parity test runs in the f32-MFMA,
+# the split-bf16 and the split-f16 mode (the default of bench.py); plain bf16 (mode 2) is reduced precision and has
+# tests of its own.  ISK_TEST_FWD_MODES=3 (comma separated) restricts the sweep.
+FWD_MODES = {0: "f32", 1: "bf16x3", 3: "f16x2"}
+
+
+@pytest.fixture(params=[int(m) for m in os.environ.get("ISK_TEST_FWD_MODES", "0,1,3").split(",")], ids=lambda m: FWD_MODES.get(m, str(m)))
+def fwd_mode(request, monkeypatch):
+    if request.node.get_closest_marker("own_fwd_mode"):
+        if request.param != int(os.environ.get("ISK_TEST_FWD_MODES", "0").split(",")[0]):
+            pytest.skip("selects its own forward mode")
+        monkeypatch.delenv("ISK_FWD_MODE", raising=False)
+    else:
+        monkeypatch.setenv("ISK_FWD_MODE", str(request.param))
+    return request.param
 
 
 @pytest.fixture(scope="session")

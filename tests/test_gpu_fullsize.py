@@ -8,7 +8,7 @@ import pytest
 
 from oracle import isokann_oracle as O
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fwd_mode")]
 
 
 def _workload(pkg, name, **kw):

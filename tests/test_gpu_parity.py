@@ -15,7 +15,7 @@ import pytest
 
 from oracle import isokann_oracle as O
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fwd_mode")]
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -711,6 +711,7 @@ def test_pseudoinv_needs_multidimensional_chi(gpu_pkg):
 
 
 # --------------------------------------------------------------- plain bf16 forward (forward_mode 2, C5's arithmetic) ----
+@pytest.mark.own_fwd_mode
 @pytest.mark.parametrize("widths,ln", [([231, 38, 6, 1], True), ([100, 150, 20, 3], True), ([64, 96, 300, 300, 2], False),
                                        ([40, 512, 40, 1], False)])
 def test_forward_plain_bf16_within_1e2(gpu_pkg, widths, ln, monkeypatch):
@@ -737,6 +738,7 @@ def test_forward_plain_bf16_within_1e2(gpu_pkg, widths, ln, monkeypatch):
     assert np.abs(out[2][1] - out[0][1]).max() <= 1e-2 * scale
 
 
+@pytest.mark.own_fwd_mode
 def test_run_plain_bf16_forward_tracks_f32(gpu_pkg, monkeypatch):
     """three iterations with the plain-bf16 Koopman forward (training stays f32) stay close to the f32 run"""
     monkeypatch.delenv("ISK_FWD_MODE", raising=False)
@@ -754,17 +756,19 @@ def test_run_plain_bf16_forward_tracks_f32(gpu_pkg, monkeypatch):
 
 
 # --------------------------------------------------------------- every template instantiation of the bf16 forward ----
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.own_fwd_mode
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_bf16_forward_every_tile_count(gpu_pkg, mode, monkeypatch):
-    """first hidden widths 5, 21, ..., 149 (1..10 output tiles: every instantiation of the fused split-bf16 / plain-bf16
-    kernel) and wide layers whose dense blocks hit every tile count of the layered path (1..8 split, 1..16 plain)"""
+    """first hidden widths 5, 21, ..., 149 (1..10 output tiles: every instantiation of the fused split-bf16 / plain-bf16 /
+    split-f16 kernel) and wide layers whose dense blocks hit every tile count of the layered path (1..8 split, 1..16
+    plain; split-f16 requests run the split-bf16 kernels there)"""
     monkeypatch.delenv("ISK_FWD_MODE", raising=False)
     pkg = gpu_pkg
     rng = np.random.default_rng(12)
     F, N, K = 70, 40, 2
     xs = rng.normal(size=(F, N)) + 1
     ys = rng.normal(size=(F, K, N)) + 1
-    tol = 2e-5 if mode == 1 else 1e-2
+    tol = 1e-2 if mode == 2 else 2e-5
     fused = [[F, 16 * k + 5, 7, 1] for k in range(10)]
     dense = [[F, 160 + 16 * k + 3, 9, 1] for k in range(1, 17)]         # 171..419 wide: blocks of (8|16) tiles + remainder
     for widths in fused + dense:
