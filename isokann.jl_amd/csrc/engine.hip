@@ -165,7 +165,7 @@ struct isk_engine {
     hipEvent_t ev_perm = nullptr;   // the shuffle order of the coming epoch was uploaded on the side stream (isk_run)
     double* h_res = nullptr;     // pinned: [loss sum, collapsed flag] + status word read back once per epoch
     int* h_perm = nullptr;       // pinned staging for the shuffle order: an async copy from pageable memory waits for the stream
-    float* d_At = nullptr;
+    double* d_At = nullptr;      // host-driven data-parallel ISA: the Float64 simplex inverse (applied in Float64, as on the device path)
     int* d_rowperm = nullptr;
     double* d_isa_work = nullptr;
     // native data-parallel run (isk_dp_run): RCCL communicator + gathered ks / chi
@@ -444,7 +444,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     ALLOC(e->d_bt, 2 * sizeof(double));
     ALLOC(e->d_wmax, sizeof(unsigned)); ALLOC(e->d_wscale, sizeof(float));
     ALLOC(e->d_lossw, (size_t)nout * sizeof(float));
-    ALLOC(e->d_At, (size_t)nout * nout * sizeof(float)); ALLOC(e->d_rowperm, (size_t)nout * sizeof(int));
+    ALLOC(e->d_At, (size_t)nout * nout * sizeof(double)); ALLOC(e->d_rowperm, (size_t)nout * sizeof(int));
     ALLOC(e->d_W16, (size_t)isk_bf16_chunks(e->Fp) * 32 * isk_pad16(cfg->widths[1]) * 3 * sizeof(uint16_t));
     for (int l = 0; l < e->L; ++l) {
         ALLOC(e->d_Wt[l], (size_t)layer_kp(e, l) * isk_pad16(cfg->widths[l + 1]) * sizeof(float));
@@ -1333,10 +1333,12 @@ extern "C" int isk_validationloss(isk_engine* e, const float* vxs, const float* 
     launch_kmean(e);
     HIPCHK(hipMemcpyAsync(k2.data(), e->d_ks, (size_t)e->N * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    // Julia's extrema propagates NaN (then max > min is false and shiftscale throws): std::fmin / fmax would drop it
     float lo = INFINITY, hi = -INFINITY;
-    for (float v : k1) { lo = std::fmin(lo, v); hi = std::fmax(hi, v); }
-    for (float v : k2) { lo = std::fmin(lo, v); hi = std::fmax(hi, v); }
-    if (!(hi > lo)) return fail(ISK_ECONSTANT_CHI, isk_status_string(ISK_ECONSTANT_CHI));
+    bool nan = false;
+    for (float v : k1) { nan |= std::isnan(v); lo = std::fmin(lo, v); hi = std::fmax(hi, v); }
+    for (float v : k2) { nan |= std::isnan(v); lo = std::fmin(lo, v); hi = std::fmax(hi, v); }
+    if (nan || !(hi > lo)) return fail(ISK_ECONSTANT_CHI, isk_status_string(ISK_ECONSTANT_CHI));
     double acc = 0;
     for (int64_t i = 0; i < Nv; ++i) {
         const float sk = (k1[i] - lo) / (hi - lo);
@@ -1877,9 +1879,7 @@ extern "C" int isk_dp_isa_apply(isk_engine* e, const double* At, const int32_t* 
     CHK(need_data(e));
     if (!e->have_ks || !At || !rowperm) return fail(ISK_ESTATE, "call isk_dp_koopman_local first / null argument");
     const int d = e->nout;
-    std::vector<float> Af(d * d);
-    for (int i = 0; i < d * d; ++i) Af[i] = (float)At[i];
-    HIPCHK(hipMemcpyAsync(e->d_At, Af.data(), Af.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_At, At, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_rowperm, rowperm, d * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     isk_launch_isa_apply(e->d_ks, e->d_At, e->d_rowperm, e->d_target, e->N, d, e->stream);
@@ -2131,6 +2131,13 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
     if (n < 0 || epochs < 0) return fail(ISK_EINVAL, "negative iteration count");
     if (local_batch < 1 || nbatches < 1 || (long long)local_batch * nbatches > e->N || global_batch < local_batch)
         return fail(ISK_EINVAL, "bad batch decomposition");
+    // every argument check comes BEFORE the first collective: a rank that returned early from inside the loop would
+    // leave the others blocked in an all-reduce
+    if (perms)
+        for (long long i = 0; i < (long long)n * epochs * e->N; ++i)
+            if (perms[i] < 0 || perms[i] >= e->N) return fail(ISK_EINVAL, "permutation entry out of range");
+    if (e->cfg.target_kind != ISK_TARGET_SHIFTSCALE && e->cfg.target_kind != ISK_TARGET_ISA)
+        return fail(ISK_EINVAL, "host-side target transform: no native data-parallel run");
     const bool coll = dp_collectives(e);
     if (coll && e->dp_checked_N != e->N) {          // equal shards: the gathered ISA arrays and the step count assume it (checked once)
         long long* d_n = nullptr;
@@ -2168,9 +2175,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
                 std::vector<int32_t> drawn;
                 const int32_t* p = perms ? perms + k * e->N : nullptr;
                 if (!p) { drawn.resize(e->N); shuffle_perm(e, drawn); p = drawn.data(); }
-                for (long long i = 0; i < e->N; ++i)
-                    if (p[i] < 0 || p[i] >= e->N) return fail(ISK_EINVAL, "permutation entry out of range");
-                std::memcpy(e->h_perm, p, (size_t)e->N * sizeof(int));
+                std::memcpy(e->h_perm, p, (size_t)e->N * sizeof(int));     // validated before the first collective
                 HIPCHK(hipMemcpyAsync(e->d_perm, e->h_perm, (size_t)e->N * sizeof(int), hipMemcpyHostToDevice, e->stream));
             }
             HIPCHK(hipMemsetAsync(e->d_loss_acc, 0, 2 * sizeof(double), e->stream));

@@ -147,7 +147,7 @@ void isk_launch_minmax(const float* v, long long n, float* mm /*[2] device*/, hi
 // target = (ks - min)/(max - min); status[0] |= 1 if !(max > min)
 void isk_launch_shiftscale(const float* ks, const float* mm, float* target, long long n, int* status, hipStream_t st);
 // target[n][a] = sum_b At[a][b]*ks[n][b] rows permuted: target[n][i] = (At ks)[rowperm[i]]
-void isk_launch_isa_apply(const float* ks, const float* At /*[d*d] device, row-major At[a][b]*/, const int* rowperm,
+void isk_launch_isa_apply(const float* ks, const double* At /*[d*d] device, row-major At[a][b], Float64*/, const int* rowperm,
                           float* target, long long N, int d, hipStream_t st);
 
 // device-side Float64 inner simplex algorithm + fixperm + loss weights (single workgroup)

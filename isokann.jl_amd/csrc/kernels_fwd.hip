@@ -729,7 +729,8 @@ void isk_launch_shiftscale(const float* ks, const float* mm, float* target, long
     hipLaunchKernelGGL(shiftscale_kernel, dim3((unsigned)b), dim3(256), 0, st, ks, mm, target, n, status);
 }
 
-__global__ __launch_bounds__(256) void isa_apply_kernel(const float* ks, const float* At, const int* rowperm, float* target,
+// target = A' ks in Float64, rounded once to Float32 (src/isotarget.jl:104-106), like isa_target_kernel on the device path
+__global__ __launch_bounds__(256) void isa_apply_kernel(const float* ks, const double* At, const int* rowperm, float* target,
                                                         long long N, int d) {
     ISK_LATENCY_CHAIN_PRIO();
     const long long tot = N * d;
@@ -737,13 +738,13 @@ __global__ __launch_bounds__(256) void isa_apply_kernel(const float* ks, const f
         const long long n = e / d;
         const int i = (int)(e % d);
         const int a = rowperm[i];
-        float s = 0.f;
-        for (int b = 0; b < d; ++b) s += At[a * d + b] * ks[n * d + b];
-        target[e] = s;
+        double s = 0.0;
+        for (int b = 0; b < d; ++b) s += At[a * d + b] * (double)ks[n * d + b];
+        target[e] = (float)s;
     }
 }
 
-void isk_launch_isa_apply(const float* ks, const float* At, const int* rowperm, float* target, long long N, int d,
+void isk_launch_isa_apply(const float* ks, const double* At, const int* rowperm, float* target, long long N, int d,
                           hipStream_t st) {
     long long b = (N * d + 255) / 256;
     if (b > 1024) b = 1024;

@@ -65,21 +65,35 @@ __device__ __forceinline__ void block_argmax(double bv, long long bi, double* sh
 
 // finalize the G partial argmax records of the previous kernel: every workgroup does this redundantly.
 // On return shd[0] = max norm, shi[0] = row index, vrow_sh[k] = that row of X (old values).
+// When NO row is a candidate (every norm is NaN: the model has diverged) the records carry index -1: the selection
+// then falls back to row 0 with a zero row, the status word gets bit 2 (the reference throws DomainError at
+// src/isotarget.jl:94-97) and every index the later kernels derive from shi[0] stays inside the arrays.
 template <int D>
 __device__ __forceinline__ void finalize_argmax(const double* __restrict__ P, int G, double* shd, long long* shi,
-                                                double* vrow_sh) {
+                                                double* vrow_sh, int* __restrict__ status, long long N) {
     constexpr int PREC = IsaLayout<D>::PREC;
     double bv = -1.0;
     long long bi = 0x7fffffffffffffffLL;
     for (int g = threadIdx.x; g < G; g += ISA_T) {
         const double v = P[(long long)g * PREC];
         const long long i = (long long)P[(long long)g * PREC + 1];
-        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        if (i >= 0 && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
     }
     block_argmax(bv, bi, shd, shi);
     const long long sel = shi[0];
-    const int g = (int)(sel / ISA_ROWS);                       // the workgroup that owned that row
-    if (threadIdx.x < D) vrow_sh[threadIdx.x] = P[(long long)g * PREC + 2 + threadIdx.x];
+    const bool none = !(sel >= 0 && sel < N);                  // workgroup-uniform
+    __syncthreads();                                            // everyone has read the winner before it is replaced
+    if (none) {
+        if (threadIdx.x == 0) {
+            shi[0] = 0;
+            shd[0] = 0.0;
+            if (blockIdx.x == 0) atomicOr(status, 2);
+        }
+        if (threadIdx.x < D) vrow_sh[threadIdx.x] = 0.0;
+    } else {
+        const int g = (int)(sel / ISA_ROWS);                   // the workgroup that owned that row
+        if (threadIdx.x < D) vrow_sh[threadIdx.x] = P[(long long)g * PREC + 2 + threadIdx.x];
+    }
     __syncthreads();
 }
 
@@ -90,13 +104,14 @@ __device__ __forceinline__ void write_partial_argmax(double bv, long long bi, co
     constexpr int PREC = IsaLayout<D>::PREC;
     block_argmax(bv, bi, shd, shi);
     const long long sel = shi[0];
+    const bool any = sel != 0x7fffffffffffffffLL;              // false: no row of this slab was a candidate (all NaN, or an empty slab)
     if (threadIdx.x == 0) {
         P[(long long)blockIdx.x * PREC] = shd[0];
-        P[(long long)blockIdx.x * PREC + 1] = (double)sel;
+        P[(long long)blockIdx.x * PREC + 1] = any ? (double)sel : -1.0;
     }
     // the winning row belongs to this workgroup's slab and was written by this kernel: re-read after a barrier
     __syncthreads();
-    if (threadIdx.x < D) P[(long long)blockIdx.x * PREC + 2 + threadIdx.x] = (sel < 0x7fffffffffffffffLL) ? X[sel * D + threadIdx.x] : 0.0;
+    if (threadIdx.x < D) P[(long long)blockIdx.x * PREC + 2 + threadIdx.x] = any ? X[sel * D + threadIdx.x] : 0.0;
 }
 
 // ---- k0: X = Float64(ks'), finiteness; norms -> partial argmax, or whitening moments -------------------
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(ISA_T) void isa_step_kernel(IsaArgs a, int j, const
     __shared__ double vrow[D];
     const long long N = a.N;
     double* X = a.work;
-    finalize_argmax<D>(Pin, G, shd, shi, vrow);
+    finalize_argmax<D>(Pin, G, shd, shi, vrow, a.status, N);
     const double rn = shd[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) ind[j] = (int)shi[0];
     const double inv = (j == 0) ? 1.0 : 1.0 / rn;
@@ -313,13 +328,16 @@ __global__ __launch_bounds__(ISA_T) void isa_target_kernel(IsaArgs a, const doub
     __shared__ int bad;
     const long long N = a.N;
     double* T = a.work + N * D;
-    finalize_argmax<D>(Pin, G, shd, shi, vrow);
+    finalize_argmax<D>(Pin, G, shd, shi, vrow, a.status, N);
     if (threadIdx.x == 0) {
         bad = 0;
         int idx[D];
 #pragma unroll
         for (int i = 0; i < D - 1; ++i) idx[i] = ind[i];
         idx[D - 1] = (int)shi[0];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+            if (idx[i] < 0 || idx[i] >= N) { idx[i] = 0; bad = 1; }      // belt and braces: finalize_argmax keeps them in range
         if (blockIdx.x == 0) ind[D - 1] = idx[D - 1];
         // the d x d rows in ONE memory round trip (registers first): filled element by element, the pivoting matrix lives
         // in scratch memory and every load waited for the one before it -- d*d dependent round trips on one thread

@@ -206,6 +206,27 @@ def test_singular_isa_raises_domain_error(gpu_pkg):
     iso.close()
 
 
+@pytest.mark.parametrize("nout,N", [(2, 20), (3, 2500), (4, 1025)])
+def test_nan_model_isa_raises_domain_error(gpu_pkg, nout, N):
+    """a diverged model (NaN parameter: every Koopman value NaN) must come back as the reference's DomainError
+    (src/isotarget.jl:94-97), not as an out-of-bounds access: no row is an argmax candidate in any of the d rounds,
+    with one and with several row slabs; run() reports it too, and the weights stay as they were"""
+    pkg = gpu_pkg
+    om = _rand_model([6, 5, nout], seed=nout)
+    om.b[0][1] = np.nan
+    rng = np.random.default_rng(0)
+    xs, ys = rng.normal(size=(6, N)), rng.normal(size=(6, 2, N))
+    iso = pkg.Iso(pkg.SimulationData(xs, ys), model=_mk_model(pkg, om), minibatch=0)
+    with pytest.raises(pkg.DomainError) as ei:
+        pkg.isotarget(iso)
+    assert ei.value.status == pkg.capi.ESINGULAR
+    before = iso.model.get_params()
+    with pytest.raises(pkg.DomainError):
+        pkg.run(iso, 1, 1)
+    np.testing.assert_array_equal(np.isnan(iso.model.get_params()), np.isnan(before))
+    iso.close()
+
+
 # ------------------------------------------------------------------ gradients ---------
 @pytest.mark.parametrize("widths,ln,act,B", [
     ([50, 14, 5, 3], True, "sigmoid", 40),
