@@ -97,8 +97,16 @@ struct EventPair { hipEvent_t a, b; int id; };
 struct isk_engine {
     isk_config cfg;
     int L = 0, F = 0, Fp = 0, Din = 0, nout = 0;
+    // ENGINE layout of the flat parameter / gradient / optimizer-state vectors (what the kernels see).  Fused path
+    // (`native`): LayerNorm scale and bias padded to Fp, layer-1 weights fragment-linear [Fp/16][nt][64][4] (zero padded),
+    // everything else in Flux order; layered path: the Flux order itself.  See kernels_train.hip.
     long long nparams = 0, off_lns = -1, off_lnb = -1;
     long long off_W[ISK_MAX_LAYERS], off_b[ISK_MAX_LAYERS];
+    bool native = false;
+    // API layout (Flux trainables order, W column-major (out, in)): isk_get/set_params, optimizer state, isk_batch_grads
+    long long napi = 0, aoff_lns = -1, aoff_lnb = -1;
+    long long aoff_W[ISK_MAX_LAYERS], aoff_b[ISK_MAX_LAYERS];
+    bool wt_dirty = true;            // fused path: theta changed since the forward weight images (d_Wt, d_bias) were built
     hipStream_t stream = nullptr;
     bool own_stream = false;
     // side stream: the (weight-independent) ys featurization of the NEXT iteration runs here,
@@ -313,9 +321,11 @@ static TrainShape train_shape(const isk_engine* e) {
     return s;
 }
 
+static long long z1_rows(long long B) { return ((B + 31) / 32) * 32; }
 static TrainBuffers train_buffers(const isk_engine* e) {
     TrainBuffers b;
     std::memset(&b, 0, sizeof(b));
+    b.beta1 = e->cfg.beta1; b.beta2 = e->cfg.beta2;
     b.xhat_xs = e->d_xs32;      // a buffer of its own: d_xhat / d_xhat_alt swap every iteration (and hold f16 planes in forward_mode 3)
     b.target = e->d_target; b.lossw = e->d_lossw; b.theta = e->d_theta;
     b.W1t = e->d_Wt[0]; b.bias1 = e->d_bias[0];
@@ -324,10 +334,10 @@ static TrainBuffers train_buffers(const isk_engine* e) {
     return b;
 }
 
-static void launch_fold(isk_engine* e, bool advance_dev_bt = false) {
+static void launch_fold(isk_engine* e) {
     FoldArgs a;
     std::memset(&a, 0, sizeof(a));
-    if (advance_dev_bt) { a.bt = e->d_bt; a.beta1 = e->cfg.beta1; a.beta2 = e->cfg.beta2; }
+    a.native = e->native;
     a.theta = e->d_theta; a.nlayers = e->L;
     for (int l = 0; l < e->L; ++l) a.Kp[l] = layer_kp(e, l);
     for (int i = 0; i <= e->L; ++i) a.widths[i] = e->cfg.widths[i];
@@ -338,6 +348,40 @@ static void launch_fold(isk_engine* e, bool advance_dev_bt = false) {
         for (int l = 1; l < e->L; ++l)
             isk_launch_fold_T(e->d_theta, e->off_W[l], e->cfg.widths[l], e->cfg.widths[l + 1], e->d_WtT[l], e->stream);
     e->w16_dirty = true;
+    e->wt_dirty = false;
+}
+// fused path: the training steps read theta itself, the forward weight images are rebuilt when a forward needs them
+static void ensure_folded(isk_engine* e) {
+    if (e->wt_dirty) launch_fold(e);
+}
+
+// ---- API (Flux) order <-> engine order, on the host ------------------------------------
+static inline long long w1_native_index(const isk_engine* e, int o, int k) {
+    const int nt = isk_pad16(e->cfg.widths[1]) / 16;
+    return e->off_W[0] + (((long long)(k >> 4) * nt + (o >> 4)) * 64 + (((k & 15) >> 2) << 4 | (o & 15))) * 4 + (k & 3);
+}
+static void api_to_engine(const isk_engine* e, const float* a, std::vector<float>& out) {
+    out.assign((size_t)e->nparams, 0.f);
+    if (!e->native) { std::memcpy(out.data(), a, (size_t)e->napi * sizeof(float)); return; }
+    const int F = e->F, H1 = e->cfg.widths[1];
+    if (e->cfg.layernorm) {
+        std::memcpy(out.data() + e->off_lns, a + e->aoff_lns, (size_t)F * sizeof(float));
+        std::memcpy(out.data() + e->off_lnb, a + e->aoff_lnb, (size_t)F * sizeof(float));
+    }
+    for (int k = 0; k < F; ++k)
+        for (int o = 0; o < H1; ++o) out[w1_native_index(e, o, k)] = a[e->aoff_W[0] + o + (long long)k * H1];
+    std::memcpy(out.data() + e->off_b[0], a + e->aoff_b[0], (size_t)(e->napi - e->aoff_b[0]) * sizeof(float));   // b1 and every later block
+}
+static void engine_to_api(const isk_engine* e, const float* in, float* a) {
+    if (!e->native) { std::memcpy(a, in, (size_t)e->napi * sizeof(float)); return; }
+    const int F = e->F, H1 = e->cfg.widths[1];
+    if (e->cfg.layernorm) {
+        std::memcpy(a + e->aoff_lns, in + e->off_lns, (size_t)F * sizeof(float));
+        std::memcpy(a + e->aoff_lnb, in + e->off_lnb, (size_t)F * sizeof(float));
+    }
+    for (int k = 0; k < F; ++k)
+        for (int o = 0; o < H1; ++o) a[e->aoff_W[0] + o + (long long)k * H1] = in[w1_native_index(e, o, k)];
+    std::memcpy(a + e->aoff_b[0], in + e->off_b[0], (size_t)(e->napi - e->aoff_b[0]) * sizeof(float));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -411,9 +455,19 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
         e->layered = !fits;
     }
     long long off = 0;
-    if (cfg->layernorm) { e->off_lns = off; off += F; e->off_lnb = off; off += F; }
+    if (cfg->layernorm) { e->aoff_lns = off; off += F; e->aoff_lnb = off; off += F; }
     for (int l = 0; l < e->L; ++l) {
-        e->off_W[l] = off; off += (long long)cfg->widths[l] * cfg->widths[l + 1];
+        e->aoff_W[l] = off; off += (long long)cfg->widths[l] * cfg->widths[l + 1];
+        e->aoff_b[l] = off; off += cfg->widths[l + 1];
+    }
+    e->napi = off;
+    e->native = !e->layered;
+    off = 0;
+    const long long lnlen = e->native ? e->Fp : F;
+    if (cfg->layernorm) { e->off_lns = off; off += lnlen; e->off_lnb = off; off += lnlen; }
+    for (int l = 0; l < e->L; ++l) {
+        e->off_W[l] = off;
+        off += (l == 0 && e->native) ? (long long)e->Fp * isk_pad16(cfg->widths[1]) : (long long)cfg->widths[l] * cfg->widths[l + 1];
         e->off_b[l] = off; off += cfg->widths[l + 1];
     }
     e->nparams = off;
@@ -441,7 +495,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     const size_t pb = (size_t)(e->nparams + 2) * sizeof(float);
     ALLOC(e->d_theta, pb); ALLOC(e->d_grad, pb * ISK_MAX_SLABS); ALLOC(e->d_m, pb); ALLOC(e->d_v, pb);
     ALLOC(e->d_loss_acc, 2 * sizeof(double)); ALLOC(e->d_status, sizeof(int)); ALLOC(e->d_mm, 2 * sizeof(float));
-    ALLOC(e->d_bt, 2 * sizeof(double));
+    ALLOC(e->d_bt, 4 * sizeof(double));
     ALLOC(e->d_wmax, sizeof(unsigned)); ALLOC(e->d_wscale, sizeof(float));
     ALLOC(e->d_lossw, (size_t)nout * sizeof(float));
     ALLOC(e->d_At, (size_t)nout * nout * sizeof(double)); ALLOC(e->d_rowperm, (size_t)nout * sizeof(int));
@@ -547,15 +601,31 @@ extern "C" int isk_set_stream(isk_engine* e, void* s) {
 // ---------------------------------------------------------------------------------------
 extern "C" int isk_nparams(isk_engine* e, int64_t* n) {
     if (!e || !n) return fail(ISK_EINVAL, "null argument");
-    *n = e->nparams;
+    *n = e->napi;
+    return ISK_OK;
+}
+
+// flat vectors cross the ABI in Flux order; the engine order (fragment-linear layer-1 weights on the fused path) stays inside
+static int upload_flat(isk_engine* e, float* dst, const float* api) {
+    std::vector<float> v;
+    api_to_engine(e, api, v);
+    HIPCHK(hipMemcpyAsync(dst, v.data(), (size_t)e->nparams * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));          // `v` is pageable and dies here
+    return ISK_OK;
+}
+static int download_flat(isk_engine* e, const float* src, float* api) {
+    std::vector<float> v((size_t)e->nparams);
+    HIPCHK(hipMemcpyAsync(v.data(), src, (size_t)e->nparams * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    engine_to_api(e, v.data(), api);
     return ISK_OK;
 }
 
 extern "C" int isk_set_params(isk_engine* e, const float* flat, int64_t n) {
     if (!e || !flat) return fail(ISK_EINVAL, "null argument");
-    if (n != e->nparams) return fail(ISK_EINVAL, "parameter count mismatch");
+    if (n != e->napi) return fail(ISK_EINVAL, "parameter count mismatch");
     HIPCHK(hipSetDevice(e->cfg.device));
-    HIPCHK(hipMemcpyAsync(e->d_theta, flat, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    CHK(upload_flat(e, e->d_theta, flat));
     launch_fold(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     e->have_target = false; e->have_ks = false;
@@ -564,28 +634,24 @@ extern "C" int isk_set_params(isk_engine* e, const float* flat, int64_t n) {
 
 extern "C" int isk_get_params(isk_engine* e, float* flat, int64_t n) {
     if (!e || !flat) return fail(ISK_EINVAL, "null argument");
-    if (n != e->nparams) return fail(ISK_EINVAL, "parameter count mismatch");
-    HIPCHK(hipMemcpyAsync(flat, e->d_theta, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    return ISK_OK;
+    if (n != e->napi) return fail(ISK_EINVAL, "parameter count mismatch");
+    return download_flat(e, e->d_theta, flat);
 }
 
 extern "C" int isk_set_opt_state(isk_engine* e, const float* m, const float* v, int64_t n, const double bt[2]) {
     if (!e || !m) return fail(ISK_EINVAL, "null argument");
-    if (n != e->nparams) return fail(ISK_EINVAL, "parameter count mismatch");
-    HIPCHK(hipMemcpyAsync(e->d_m, m, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    if (v) HIPCHK(hipMemcpyAsync(e->d_v, v, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    if (n != e->napi) return fail(ISK_EINVAL, "parameter count mismatch");
+    CHK(upload_flat(e, e->d_m, m));
+    if (v) CHK(upload_flat(e, e->d_v, v));
     if (bt) { e->bt1 = bt[0]; e->bt2 = bt[1]; e->bt_dev_valid = false; }
     return ISK_OK;
 }
 
 extern "C" int isk_get_opt_state(isk_engine* e, float* m, float* v, int64_t n, double bt[2]) {
     if (!e) return fail(ISK_EINVAL, "null argument");
-    if (n != e->nparams) return fail(ISK_EINVAL, "parameter count mismatch");
-    if (m) HIPCHK(hipMemcpyAsync(m, e->d_m, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    if (v) HIPCHK(hipMemcpyAsync(v, e->d_v, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    if (n != e->napi) return fail(ISK_EINVAL, "parameter count mismatch");
+    if (m) CHK(download_flat(e, e->d_m, m));
+    if (v) CHK(download_flat(e, e->d_v, v));
     if (bt) { bt[0] = e->bt1; bt[1] = e->bt2; }
     return ISK_OK;
 }
@@ -719,7 +785,16 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
     HIPCHK(hipMalloc((void**)&e->d_out, (size_t)S * e->nout * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_ks, (size_t)N * e->nout * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_target, (size_t)N * e->nout * sizeof(float)));
-    HIPCHK(hipMalloc((void**)&e->d_z1, (size_t)Bpad * H1p * sizeof(float)));
+    {
+        // K-slice partials of train_fwd1n: KS(B) * pad32(B) rows for any batch size B <= N
+        long long zrows = z1_rows(N);
+        for (long long RB = 1; (RB - 1) * 32 < N; ++RB) {       // every row-block count a batch of <= N rows can have
+            int ks, cpb;
+            isk_fwd1n_plan((int)(RB * 32), e->Fp, H1p / 16, &ks, &cpb);
+            if (ks > 1) zrows = std::max(zrows, ks * RB * 32); else break;
+        }
+        HIPCHK(hipMalloc((void**)&e->d_z1, (size_t)zrows * H1p * sizeof(float)));
+    }
     HIPCHK(hipMalloc((void**)&e->d_delta1, (size_t)Bpad * H1p * sizeof(float)));
     const TrainShape ts = train_shape(e);
     HIPCHK(hipMalloc((void**)&e->d_part, (size_t)isk_train_part_floats(ts, (int)N) * sizeof(float)));
@@ -860,6 +935,7 @@ static int bf16_planes(const isk_engine* e) { return e->cfg.forward_mode == 1 ? 
 // fused networks: refresh the bf16 weight planes now (launch_forward would do it lazily, i.e. behind whatever the
 // stream is about to wait for)
 static void fold_ahead(isk_engine* e) {
+    ensure_folded(e);
     const int planes = bf16_planes(e);
     if (e->layered || !(planes || e->planes) || !e->w16_dirty) return;
     if (e->planes) isk_launch_fold_f16(e->d_Wt[0], e->d_W16, e->Fp, isk_pad16(e->cfg.widths[1]) / 16, e->d_wmax, e->d_wscale, e->stream);
@@ -920,6 +996,7 @@ static int forward_layered(isk_engine* e, const float* X, long long S, float* ou
 
 // the forward over feature rows: f32 MFMA or split-bf16 (cfg.forward_mode)
 static int launch_forward(isk_engine* e, const MlpFwdArgs& f) {
+    ensure_folded(e);
     if (e->layered) {
         float *a = e->d_actA, *b = e->d_actB;
         TmpBuf ta, tb;
@@ -1369,7 +1446,11 @@ extern "C" int isk_chicoords_pullback(isk_engine* e, const float* coords, int64_
         HIPCHK(hipMalloc(&xh.p, (size_t)n * e->Fp * sizeof(float)));
         HIPCHK(hipMalloc(&raw.p, (size_t)n * e->Fp * sizeof(float)));
         HIPCHK(hipMalloc(&st.p, (size_t)n * 2 * sizeof(float)));
-        HIPCHK(hipMalloc(&z1.p, (size_t)npad * H1p * sizeof(float)));
+        {
+            int ks = 1, cpb;
+            if (e->native) isk_fwd1n_plan((int)n, e->Fp, H1p / 16, &ks, &cpb);
+            HIPCHK(hipMalloc(&z1.p, (size_t)ks * z1_rows(n) * H1p * sizeof(float)));
+        }
         HIPCHK(hipMalloc(&d1.p, (size_t)npad * H1p * sizeof(float)));
         if (!e->layered) HIPCHK(hipMalloc(&part.p, (size_t)isk_train_part_floats(ts, (int)n) * sizeof(float)));
         HIPCHK(hipMalloc(&ct.p, (size_t)n * e->nout * sizeof(float)));
@@ -1414,7 +1495,10 @@ extern "C" int isk_chicoords_pullback(isk_engine* e, const float* coords, int64_
             TrainBuffers tb = train_buffers(e);
             tb.xhat_xs = (const float*)xh.p; tb.target = (const float*)ct.p; tb.a1 = (float*)z1.p; tb.delta1 = (float*)d1.p;
             tb.part = (float*)part.p; tb.cot_mode = 1;
-            isk_launch_train_fwd1(ts, tb, nullptr, (int)n, e->stream);
+            int cpb;
+            isk_fwd1n_plan((int)n, e->Fp, H1p / 16, &tb.KS, &cpb);
+            tb.zstride = z1_rows(n) * H1p;
+            isk_launch_train_fwd1n(ts, tb, nullptr, (int)n, e->stream);
             isk_launch_train_tail(ts, tb, nullptr, (int)n, 1.0f, e->stream);
         }
         VjpArgs v = {};
@@ -1423,6 +1507,7 @@ extern "C" int isk_chicoords_pullback(isk_engine* e, const float* coords, int64_
         v.off_W0 = e->off_W[0]; v.off_lns = e->cfg.layernorm ? e->off_lns : -1;
         v.grad = (float*)gr.p; v.S = n; v.D = (int)D; v.F = e->F; v.Fp = e->Fp; v.H1 = e->cfg.widths[1]; v.H1p = H1p;
         v.ln_mode = e->cfg.ln_mode;
+        v.native = e->native;
         isk_launch_vjp_back(v, e->stream);
         HIPCHK(hipMemcpyAsync(grad + c0 * D, gr.p, (size_t)n * D * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -1595,20 +1680,6 @@ static void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float i
     e->last_nslab = 1;
 }
 
-static void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nslab = 1) {
-    if (e->layered) { launch_grads_layered(e, d_idx, B, inv_div); return; }
-    const TrainShape s = train_shape(e);
-    const TrainBuffers b = train_buffers(e);
-    isk_launch_train_fwd1(s, b, d_idx, B, e->stream);
-    isk_launch_train_tail(s, b, d_idx, B, inv_div, e->stream);
-    // while the throttled featurizer shares the CUs, use the 8-wave variant (80 KB LDS instead of 158 KB) so both fit
-    isk_launch_train_grad1(s, b, d_idx, B, nslab | (e->ys_ahead ? 0x100 : 0), e->stream);
-    e->last_nslab = nslab;
-}
-
-// fold: refresh the weight images the forward / training kernels read.  The rocBLAS variant of the layered training
-// path reads theta itself (only layer 0's folded bias comes from an image, and only with LayerNorm), so inside an
-// epoch it skips the refresh and folds once at the end.
 // bring the device copy of [beta1^t, beta2^t] up to date (after create / set_opt_state / reset, or steps taken in host mode);
 // synchronous and rare.  Never called while the stream is being captured.
 static bool prepare_dev_bt(isk_engine* e) {
@@ -1620,22 +1691,44 @@ static bool prepare_dev_bt(isk_engine* e) {
     return true;
 }
 
+// one optimizer step's gradient into d_grad (slab 0 .. nslab-1).  step: an optimizer step follows (launch_opt), so
+// train_tail hands the Adam bias corrections of this step over on the device
+static void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nslab = 1, bool step = true, bool capturing = false) {
+    if (e->layered) { launch_grads_layered(e, d_idx, B, inv_div); return; }
+    const TrainShape s = train_shape(e);
+    TrainBuffers b = train_buffers(e);
+    int cpb;
+    isk_fwd1n_plan(B, e->Fp, isk_pad16(e->cfg.widths[1]) / 16, &b.KS, &cpb);
+    b.zstride = z1_rows(B) * isk_pad16(e->cfg.widths[1]);
+    if (step && (capturing ? e->bt_dev_valid : prepare_dev_bt(e))) b.bt = e->d_bt;
+    isk_launch_train_fwd1n(s, b, d_idx, B, e->stream);
+    isk_launch_train_tail(s, b, d_idx, B, inv_div, e->stream);
+    // while the throttled featurizer shares the CUs, use the 8-wave variant (80 KB LDS instead of 158 KB) so both fit
+    isk_launch_train_grad1n(s, b, d_idx, B, nslab | (e->ys_ahead ? 0x100 : 0), e->stream);
+    e->last_nslab = nslab;
+}
+
+// fold: refresh the weight images the forward / training kernels read.  The rocBLAS variant of the layered training
+// path reads theta itself (only layer 0's folded bias comes from an image, and only with LayerNorm), so inside an
+// epoch it skips the refresh and folds once at the end.
 static void launch_opt(isk_engine* e, float gscale, bool fold = true, bool capturing = false) {
     OptArgs a;
     a.theta = e->d_theta; a.grad = e->d_grad; a.m = e->d_m; a.v = e->d_v; a.n = e->nparams;
     a.kind = e->cfg.opt_kind; a.lr = e->cfg.lr; a.reg = e->cfg.reg; a.beta1 = e->cfg.beta1; a.beta2 = e->cfg.beta2;
     a.eps = e->cfg.opt_eps; a.rho = e->cfg.rho;
     a.bc1 = (float)(1.0 - e->bt1); a.bc2 = (float)(1.0 - e->bt2);
-    // fused path with a fold behind every step: the bias corrections come from the device copy, which that fold advances
-    const bool dev = fold && !e->layered && (capturing ? e->bt_dev_valid : prepare_dev_bt(e));
-    a.bt = dev ? e->d_bt : nullptr;
+    // fused path: the bias corrections of this step were handed over on the device by train_tail (launch_grads)
+    const bool dev = !e->layered && e->bt_dev_valid;
+    (void)capturing;
+    a.bt = dev ? e->d_bt + 2 : nullptr;
     a.gscale = gscale; a.loss_acc = e->d_loss_acc;
     a.nslab = e->last_nslab;
-    a.slab_prefix = (e->cfg.layernorm ? 2LL * e->F : 0LL) + (long long)e->F * e->cfg.widths[1] + e->cfg.widths[1];
+    a.slab_prefix = e->off_b[0] + e->cfg.widths[1];          // [LN | W1 | b1]: the blocks train_grad1n writes per row slab
     isk_launch_opt_step(a, e->stream);
     e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2;
     if (!dev) e->bt_dev_valid = false;           // this step advanced only the host copy
-    if (fold) launch_fold(e, dev);
+    if (e->native) { e->wt_dirty = true; e->w16_dirty = true; }      // the training steps read theta; forwards re-fold on demand
+    else if (fold) launch_fold(e);
 }
 
 static int upload_target(isk_engine* e, const float* target) {
@@ -1690,7 +1783,7 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
             return false;
         }
         for (long long b = 0; b < nb; ++b) {
-            launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, nslab);
+            launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, nslab, true, true);
             launch_opt(e, 1.0f, true, true);
         }
         hipGraph_t g = nullptr;
@@ -1710,6 +1803,7 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
         for (long long b = 0; b < nb; ++b) { e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2; }
         e->last_nslab = nslab;
         e->w16_dirty = true;
+        e->wt_dirty = true;
     }
     if (hipGraphLaunch(e->tg_exec, e->stream) != hipSuccess) {
         // cannot happen after a successful instantiate; if it does the epoch has not run and the state says so
@@ -1780,12 +1874,12 @@ extern "C" int isk_batch_grads(isk_engine* e, const float* target, const int32_t
     if (target) CHK(upload_target(e, target));
     if (!e->have_target) return fail(ISK_ESTATE, "no target: pass one or call isk_target first");
     HIPCHK(hipMemcpyAsync(e->d_perm, idx, (size_t)nidx * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    launch_grads(e, e->d_perm, nidx, 1.0f / (float)nidx);
+    launch_grads(e, e->d_perm, nidx, 1.0f / (float)nidx, 1, false);
     std::vector<float> g((size_t)e->nparams + 1);
     HIPCHK(hipMemcpyAsync(g.data(), e->d_grad, g.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipGetLastError());
-    std::memcpy(grads, g.data(), (size_t)e->nparams * sizeof(float));
+    engine_to_api(e, g.data(), grads);
     if (loss) *loss = (double)g[e->nparams];
     return ISK_OK;
 }

@@ -132,6 +132,7 @@ struct FoldArgs {
     float* Wt[ISK_MAX_LAYERS];            // fragment-linear per layer
     float* bias[ISK_MAX_LAYERS];          // padded per layer (layer 0: folded)
     double* bt; double beta1, beta2;      // optional: advance the device copy of [beta1^t, beta2^t] (one thread; see OptArgs)
+    int native;                           // 1: theta is in the fused path's engine layout (layer 0 fragment-linear, LayerNorm blocks padded)
 };
 void isk_launch_fold(const FoldArgs& a, hipStream_t st);
 
@@ -174,29 +175,50 @@ struct TrainShape {
     long long off_W[ISK_MAX_LAYERS], off_b[ISK_MAX_LAYERS];
     long long nparams;
 };
+// column of output o inside a delta1 row of H1p = 16 nt floats: the first 4*(nt/4) tiles are interleaved four at a time so
+// that lane c's dwordx4 at 64 q + 4 c yields column c of tiles 4q .. 4q+3; the remaining tiles keep their place
+__host__ __device__ static inline int isk_delta1_pos(int o, int H1p) {
+    const int nb4 = (H1p / 16) / 4;
+    if (o >= 64 * nb4) return o;
+    const int t = o >> 4, c = o & 15;
+    return 64 * (t >> 2) + 4 * c + (t & 3);
+}
+#define ISK_FWD1_MAXKS 8     // K slices of train_fwd1n (partials summed by train_tail)
 struct TrainBuffers {
     const float* xhat_xs;   // [N][Fp]
     const float* target;    // [N][nout]
     const float* lossw;     // [nout]
-    const float* theta;     // flat params
-    const float* W1t;       // folded layer-1 weights (fragment-linear)
-    const float* bias1;     // folded layer-1 bias
-    float* a1;              // [Bpad][H1p]     layer-1 activations of the batch
-    float* delta1;          // [Bpad][H1p]     dL/dz1
+    const float* theta;     // flat params, engine layout (fused path: layer-1 weights fragment-linear, see kernels_train.hip)
+    const float* W1t;       // folded layer-1 weights (fragment-linear)            -- layered path only
+    const float* bias1;     // folded layer-1 bias                                  -- layered path only
+    float* a1;              // [KS][Bpad32][H1p]  K-slice partials of the layer-1 pre-activations (train_fwd1n -> train_tail)
+    long long zstride;      // floats between two K-slice partials
+    int KS;                 // K slices the coming train_tail sums (isk_fwd1n_plan of the batch size)
+    double* bt;             // optional [4]: beta^t of the coming step [0..1]; train_tail hands them to opt_step in [2..3] and advances
+    double beta1, beta2;
+    float* delta1;          // [Bpad][H1p]     dL/dz1, columns in isk_delta1_pos order
     float* part;            // per-workgroup partial sums from the tail kernel
     float* grad;            // flat gradient [nparams] + [loss, nonfinite]
     double* loss_acc;       // [2]: epoch loss sum (double), collapsed flag (as double)
     int cot_mode;           // 1: `target` is a cotangent (coordinate pullback), see isk_launch_train_tail
     int Fp;
 };
-// batch rows are perm[first .. first+B)
-void isk_launch_train_fwd1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, hipStream_t st);
+struct Fwd1nArgs {
+    const float* X; int Fp, nch; const int* perm; int B;
+    const float* W1n; const float* g; const float* beta;      // g == nullptr: no LayerNorm
+    int KS, cpb;                                              // K slices, 16-feature chunks per slice
+    int nt, ntg;                                              // layer-1 output tiles, tile groups (<= 5 tiles per workgroup)
+    float* zp; long long zstride;
+};
+void isk_fwd1n_plan(int B, int Fp, int nt, int* KS, int* cpb);
+// batch rows are perm[first .. first+B); fused path: K-slice partials into b.a1
+void isk_launch_train_fwd1n(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, hipStream_t st);
 // out[n][.] (row stride 16*nt) = X[row(n)][0..ldx) * Wt + bias   (train_fwd1_kernel on any layer; ldx multiple of 16)
 void isk_launch_gemm_rows(const float* X, int ldx, const float* Wt, const float* bias, int nt, const int* perm, int B, float* out,
                           hipStream_t st);
 void isk_launch_train_tail(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div, hipStream_t st);
 // cotangent mode: b.target holds the cotangent [B][nout]; delta_L = cot .* act'(z_L), no loss, no weights
-void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st);
+void isk_launch_train_grad1n(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st);
 #define ISK_MAX_SLABS 8
 int  isk_train_tail_nblocks(int B);
 long long isk_train_part_floats(const TrainShape& s, int maxB);
@@ -206,7 +228,7 @@ struct OptArgs {
     long long n;
     int kind; float lr, reg, beta1, beta2, eps, rho;
     float bc1, bc2;         // 1 - beta1^t, 1 - beta2^t for this step
-    const double* bt;       // optional: device copy of [beta1^t, beta2^t] (then bc1/bc2 are derived from it, so the launch
+    const double* bt;       // optional: device [beta1^t, beta2^t] of THIS step (then bc1/bc2 are derived from it, so the launch
                             // arguments do not change from step to step and the epoch can be replayed as a hipGraph)
     int nslab; long long slab_prefix;   // gradient slabs to sum for parameter indices < slab_prefix
     float gscale;           // gradient multiplier (1, or 1/global_batch in data-parallel mode)
@@ -229,6 +251,7 @@ struct VjpArgs {
     float* grad;            // [S][D]
     long long S;
     int D, F, Fp, H1, H1p, ln_mode;
+    int native;             // 1: theta in the engine's fused-path layout (fragment-linear W1), delta1 columns in isk_delta1_pos order
 };
 void isk_launch_vjp_back(const VjpArgs& a, hipStream_t st);
 

@@ -393,11 +393,41 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tile[];     // [16][Np + 1]
     const int layer = blockIdx.y;
     if (layer >= a.nlayers) return;
-    if (a.bt && blockIdx.x == 0 && layer == 0 && threadIdx.x == 0) {      // the optimizer step before this fold is done
+    if (a.bt && blockIdx.x == 0 && layer == 0 && threadIdx.x == 0) {      // layered path: the optimizer step before this fold is done
         a.bt[0] *= a.beta1;
         a.bt[1] *= a.beta2;
     }
     const int K = a.widths[layer], N = a.widths[layer + 1];
+    if (a.native && layer == 0) {
+        // fused path: theta keeps W1 fragment-linear (zero padded) and the LayerNorm blocks padded to Kp, so the folded
+        // image is an elementwise product and the folded bias a strided dot product
+        const int Kp0 = a.Kp[0], Np0 = (N + 15) & ~15, nt0 = Np0 / 16, nch0 = Kp0 / 16;
+        const float* W = a.theta + a.off_W[0];
+        const bool ln0 = a.off_lns >= 0;
+        const int t0 = threadIdx.x;
+        if ((int)blockIdx.x < nch0) {
+            const int c = blockIdx.x;
+            for (int idx = t0; idx < nt0 * 256; idx += 256) {
+                const int j = idx & 3, ln_ = (idx >> 2) & 63;
+                const long long e = (long long)c * nt0 * 256 + idx;
+                a.Wt[0][e] = W[e] * (ln0 ? a.theta[a.off_lns + c * 16 + 4 * (ln_ >> 4) + j] : 1.f);
+            }
+            return;
+        }
+        const int o = (int)blockIdx.x - nch0;
+        if (o >= Np0) return;
+        float sacc = 0.f;
+        if (o < N && ln0) {
+            const float* Wo = W + ((long long)(o >> 4) * 64 + (o & 15)) * 4;          // + ((c*nt)*64 + 16 kq)*4 + j
+            for (int k = t0; k < K; k += 256)
+                sacc += Wo[((long long)(k >> 4) * nt0 * 64 + ((k & 15) >> 2) * 16) * 4 + (k & 3)] * a.theta[a.off_lnb + k];
+            sacc = wave_sum(sacc);
+        }
+        if ((t0 & 63) == 0) tile[t0 >> 6] = sacc;
+        __syncthreads();
+        if (t0 == 0) a.bias[0][o] = (o < N) ? a.theta[a.off_b[0] + o] + ((tile[0] + tile[1]) + (tile[2] + tile[3])) : 0.f;
+        return;
+    }
     const int Kp = a.Kp[layer], Np = (N + 15) & ~15;
     const int nt = Np / 16, nchunks = Kp / 16;
     const float* W = a.theta + a.off_W[layer];

@@ -1,15 +1,21 @@
 // Training-path kernels for gfx950 (MI355X): one optimizer step of train_batch!
 // (src/iso.jl:179-194 of the reference) is the chain
-//   train_fwd1  -> z1 = W1g * xhat[batch] + bias1                       (f32 MFMA, split-K over 4 waves)
-//   train_tail  -> tail layers fwd, weighted loss, backward to delta1,  (VALU, 16 samples / workgroup)
-//                  per-workgroup partial sums of the small gradients
-//   train_grad1 -> G = delta1' * xhat[batch]  (f32 MFMA), LayerNorm-affine unfold:
+//   train_fwd1n -> K-slice partials of z1 = W1 * (g .* xhat[batch] + beta)   (f32 MFMA; workgroup = 32 rows x one K slice)
+//   train_tail  -> z1 = sum of the partials + b1, tail layers fwd, weighted loss, backward to delta1
+//                  (VALU, 16 samples / workgroup), per-workgroup partial sums of the small gradients
+//   train_grad1n-> G = delta1' * xhat[batch]  (f32 MFMA), LayerNorm-affine unfold:
 //                  dW1 = g.*G + beta*D', dg = sum_o W1.*G, dbeta = W1'*D; reduces the partials
 //   opt_step    -> WeightDecay + Adam | Nesterov on the flat parameter buffer (Optimisers.jl rules)
-//   fold        -> refresh the fragment-linear weights (kernels_fwd.hip)
 // The LayerNorm standardisation has no trainable parameters, so it is hoisted out of the loop
-// (xhat is cached); its affine part (g, beta) is folded into layer 1 on the way in and unfolded
+// (xhat is cached); its affine part (g, beta) is applied to the sample operand as it is loaded and unfolded
 // on the way back, which removes the dL/d(a0) GEMM entirely: only G (one GEMM) is needed.
+//
+// "Native" parameter layout (fused path): inside the engine the layer-1 weights live in the FRAGMENT-LINEAR order the
+// MFMA B operand wants -- W1n[((c*nt + t)*64 + lane)*4 + j] = W1[o = 16t + lane%16][k = 16c + 4(lane/16) + j], zero padded to
+// [Fp/16][nt] whole fragments -- and so do their gradient and optimizer state (the optimizer is elementwise, any order
+// does).  The LayerNorm scale / bias blocks are padded to Fp.  Consequences: no per-step re-layout ("fold") kernel at all,
+// train_fwd1n's weight loads and train_grad1n's gradient stores are whole coalesced KiB straight from / to the
+// accumulator registers.  The Flux order exists only at the C ABI (isk_get/set_params convert on the host).
 #include <cstdlib>
 #include "isk_internal.h"
 
@@ -111,20 +117,161 @@ __global__ __launch_bounds__(FW1_WAVES * 64) void train_fwd1_kernel(const float*
     }
 }
 
-void isk_launch_train_fwd1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, hipStream_t st) {
-    const int units = (B + 15) / 16;
-    const int nt1 = isk_pad16(s.widths[1]) / 16;
-    const int upx = (units + 7) / 8;                      // units per XCD group
-    hipLaunchKernelGGL(train_fwd1_kernel, dim3(8 * upx * nt1), dim3(FW1_WAVES * 64), 0, st, b.xhat_xs, b.Fp, b.Fp / 16, b.W1t,
-                       b.bias1, nt1, perm, B, b.a1);
-}
-
 // generic row GEMM on the same kernel: out[n][16*t + j] = sum_k X[row(n)][k] * Wt(k, t) + bias, any layer
 void isk_launch_gemm_rows(const float* X, int ldx, const float* Wt, const float* bias, int nt, const int* perm, int B, float* out,
                           hipStream_t st) {
     const int units = (B + 15) / 16;
     const int upx = (units + 7) / 8;
     hipLaunchKernelGGL(train_fwd1_kernel, dim3(8 * upx * nt), dim3(FW1_WAVES * 64), 0, st, X, ldx, ldx / 16, Wt, bias, nt, perm, B, out);
+}
+
+
+// ------------------------------------------------------------------ train_fwd1n ------
+// grid (row blocks of 32 batch rows, tile groups x KS K-slices); workgroup = 8 waves that split the slice's 16-feature
+// chunks; every wave accumulates the group's NTB (<= 5) output tiles of both 16-row units, the eight partial tile sets
+// are combined through LDS and written as ONE K-slice partial zp[ks][row][H1p] (train_tail sums the KS partials as it
+// loads them).  Sized to run BESIDE the side-stream featurizer, whose waves hold ~248 of a SIMD's 512 registers for the
+// whole training phase: <= 128 registers per wave (two workgroups per CU fit next to it), at most two chunks per wave so
+// that all of a wave's loads are in flight before its first MFMA (one memory round trip per launch).  At C3 (B = 1000):
+// 32 row blocks x 2 tile groups x 8 slices = 512 workgroups of 100 KB input each = 51 MB through L2 per step, against
+// 125 MB for the 567 (unit, tile) workgroups of the first version.
+#define FW1N_WAVES 8
+#define FW1N_NTB 5
+template <int NTB, bool LN>
+__global__ __launch_bounds__(FW1N_WAVES * 64, 4) void train_fwd1n_kernel(Fwd1nArgs a) {
+    ISK_LATENCY_CHAIN_PRIO();
+    extern __shared__ __attribute__((aligned(16))) float red[];          // [4 wave pairs][2 units][NTB][256]: 40 KB at NTB = 5
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int rb = blockIdx.x;
+    const int tg = blockIdx.y % a.ntg, ks = blockIdx.y / a.ntg;
+    const int t0 = tg * NTB;                                              // first tile of this group
+    int r0 = rb * 32 + li, r1 = r0 + 16;
+    if (r0 > a.B - 1) r0 = a.B - 1;
+    if (r1 > a.B - 1) r1 = a.B - 1;
+    const long long x0r = a.perm ? a.perm[r0] : r0, x1r = a.perm ? a.perm[r1] : r1;
+    const float* x0 = a.X + x0r * (long long)a.Fp + lq * 4;
+    const float* x1 = a.X + x1r * (long long)a.Fp + lq * 4;
+    const f32x4* Wp = (const f32x4*)a.W1n + lane;
+    const int cbeg = ks * a.cpb;
+    int cend = cbeg + a.cpb;
+    if (cend > a.nch) cend = a.nch;
+    f32x4 acc0[NTB], acc1[NTB];
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) { acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    struct Frag { f32x4 xa, xb, g, b, w[NTB]; };
+    auto load = [&](Frag& f, int c) {
+        f.xa = *(const f32x4*)(x0 + c * 16);
+        f.xb = *(const f32x4*)(x1 + c * 16);
+        if (LN) { f.g = *(const f32x4*)(a.g + c * 16 + lq * 4); f.b = *(const f32x4*)(a.beta + c * 16 + lq * 4); }
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) {
+            const int tt = t0 + t < a.nt ? t0 + t : a.nt - 1;             // a short last group re-reads its last tile (discarded)
+            f.w[t] = Wp[(long long)(c * a.nt + tt) * 64];
+        }
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float pa = LN ? fmaf(f.xa[j], f.g[j], f.b[j]) : f.xa[j];       // LayerNorm affine on the operand
+            const float pb = LN ? fmaf(f.xb[j], f.g[j], f.b[j]) : f.xb[j];
+#pragma unroll
+            for (int t = 0; t < NTB; ++t) {
+                acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, f.w[t][j], acc0[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb, f.w[t][j], acc1[t], 0, 0, 0);
+            }
+        }
+    };
+    // two fragment sets in flight: the next chunk's loads are issued before this chunk's MFMAs (clamped, branch-free)
+    Frag fa, fb;
+    const int c0 = cbeg + wave;
+    const int clast = cend - 1;
+    load(fa, c0 < clast ? c0 : clast);
+    for (int c = c0; c < cend; c += 2 * FW1N_WAVES) {
+        load(fb, c + FW1N_WAVES < clast ? c + FW1N_WAVES : clast);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 * FW1N_WAVES < cend) load(fa, c + 2 * FW1N_WAVES);     // wave-uniform; rare (long slices only)
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + FW1N_WAVES < cend) mma(fb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // two stages keep the buffer at four tile sets (two workgroups per CU fit beside the featurizer's LDS image):
+    // waves 4..7 park their tiles, waves 0..3 add them to their own and park the sums
+    const int wp = wave & 3;
+    if (wave >= 4) {
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) {
+            *(f32x4*)(red + (((wp * 2 + 0) * NTB + t) * 64 + lane) * 4) = acc0[t];
+            *(f32x4*)(red + (((wp * 2 + 1) * NTB + t) * 64 + lane) * 4) = acc1[t];
+        }
+    }
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) {
+            f32x4* p0 = (f32x4*)(red + (((wp * 2 + 0) * NTB + t) * 64 + lane) * 4);
+            f32x4* p1 = (f32x4*)(red + (((wp * 2 + 1) * NTB + t) * 64 + lane) * 4);
+            *p0 += acc0[t];                                  // same lane reads and rewrites its own slot: no barrier in between
+            *p1 += acc1[t];
+        }
+    }
+    __syncthreads();
+    // 2*NTB*64 accumulator quads, summed over the four wave pairs and stored: quad q = (unit, tile, lane') -> rows 4 lq' .. + 3, column 16 t + li'
+    const int H1p = a.nt * 16;
+    float* zp = a.zp + (long long)ks * a.zstride;
+    for (int q = threadIdx.x; q < 2 * NTB * 64; q += FW1N_WAVES * 64) {
+        f32x4 v = *(const f32x4*)(red + q * 4);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *(const f32x4*)(red + (w * 2 * NTB * 64 + q) * 4);
+        const int u = q / (NTB * 64), rem = q - u * NTB * 64, t = rem >> 6, lp = rem & 63;
+        if (t0 + t >= a.nt) continue;
+        const long long row = (long long)(rb * 2 + u) * 16 + (lp >> 4) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zp[(row + r) * H1p + (t0 + t) * 16 + (lp & 15)] = v[r];
+    }
+}
+
+// K-slice plan of train_fwd1n for a batch of B rows and nt layer-1 output tiles: about two workgroups per CU, at least
+// one chunk per wave
+void isk_fwd1n_plan(int B, int Fp, int nt, int* KS, int* cpb) {
+    const int nch = Fp / 16, RB = (B + 31) / 32, ntg = (nt + FW1N_NTB - 1) / FW1N_NTB;
+    int ks = 512 / (RB * ntg);
+    if (ks > ISK_FWD1_MAXKS) ks = ISK_FWD1_MAXKS;
+    if (ks > nch / FW1N_WAVES) ks = nch / FW1N_WAVES;
+    if (ks < 1) ks = 1;
+    *cpb = (nch + ks - 1) / ks;
+    *KS = (nch + *cpb - 1) / *cpb;
+}
+
+void isk_launch_train_fwd1n(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, hipStream_t st) {
+    Fwd1nArgs a;
+    a.X = b.xhat_xs; a.Fp = b.Fp; a.nch = b.Fp / 16; a.perm = perm; a.B = B;
+    a.W1n = b.theta + s.off_W[0];
+    a.g = s.layernorm ? b.theta + s.off_lns : nullptr;
+    a.beta = s.layernorm ? b.theta + s.off_lnb : nullptr;
+    a.nt = isk_pad16(s.widths[1]) / 16;
+    a.ntg = (a.nt + FW1N_NTB - 1) / FW1N_NTB;
+    isk_fwd1n_plan(B, b.Fp, a.nt, &a.KS, &a.cpb);
+    a.zp = b.a1; a.zstride = b.zstride;
+    const int RB = (B + 31) / 32;
+    // tiles per group: the groups are as even as the tile count allows (9 tiles: 5 + 4)
+    const int ntb = (a.nt + a.ntg - 1) / a.ntg;
+    const dim3 grid(RB, a.ntg * a.KS), blk(FW1N_WAVES * 64);
+#define FCASE(N_)                                                                                                           \
+    case N_: {                                                                                                              \
+        const size_t lds = (size_t)4 * 2 * N_ * 256 * sizeof(float);                                                        \
+        if (a.g) {                                                                                                          \
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)train_fwd1n_kernel<N_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            hipLaunchKernelGGL((train_fwd1n_kernel<N_, true>), grid, blk, lds, st, a);                                      \
+        } else {                                                                                                            \
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)train_fwd1n_kernel<N_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((train_fwd1n_kernel<N_, false>), grid, blk, lds, st, a);                                     \
+        }                                                                                                                   \
+    } break;
+    switch (ntb) { FCASE(1) FCASE(2) FCASE(3) FCASE(4) default: FCASE(5) }
+#undef FCASE
 }
 
 // ------------------------------------------------------------------ train_tail -------
@@ -152,8 +299,12 @@ __host__ __device__ static inline int tail_off_w(const TrainShape& s, int l) {
     return o;
 }
 
-#define TAIL_THREADS 1024
-__global__ __launch_bounds__(TAIL_THREADS) void train_tail_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm,
+// 512 threads at <= 128 registers: two waves per SIMD, which is what fits beside a featurizer wave (~248 of the SIMD's 512
+// registers); the phases are latency chains, not throughput loops, so eight waves lose nothing against sixteen
+#define TAIL_THREADS 512
+#define TAIL_ZU (4096 / TAIL_THREADS)      /* z1 elements per thread in the prefetched first pass (16 x H1 <= 4096) */
+#define TAIL_WU (2048 / TAIL_THREADS)      /* tail weights per thread and layer in the prefetched first pass */
+__global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm,
                                                                   int B, float inv_div) {
     ISK_LATENCY_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -164,36 +315,86 @@ __global__ __launch_bounds__(TAIL_THREADS) void train_tail_kernel(TrainShape s, 
     const int unit = blockIdx.x;
     const int H1 = s.widths[1];
     const int H1p = (H1 + 15) & ~15;
-    // stage the tail weights (Flux layout W[o + k*N]) in LDS; 16 waves keep the loads in flight
-    for (int l = 1; l < L; ++l) {
-        float* Wl = sm + tail_off_w(s, l);
-        const float* Wg = b.theta + s.off_W[l];
-        const int n = s.widths[l + 1] * s.widths[l];
-        for (int e0 = 0; e0 < n; e0 += NTH * 2) {
-            float v[2];
+    // The kernel is a chain of short phases; its global loads are what it waits for.  Everything the first pass of every
+    // phase needs is requested HERE, before the first wait: the batch row of this thread's loss element (the target load
+    // depends on it and follows as soon as it lands), the K-slice partials of z1, the tail weights.
+    const int nout_ = s.widths[L];
+    const bool lp = tid < 16 * nout_;                    // this thread's element (sample tid / nout, output tid % nout) of the loss phase
+    long long lp_row = 0;
+    if (lp) {
+        const int row = unit * 16 + tid / nout_;
+        const int rowc = row < B ? row : B - 1;
+        lp_row = perm ? perm[rowc] : rowc;
+    }
+    float zv[TAIL_ZU];
+    {
+        const float* b1 = b.theta + s.off_b[0];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { const int e = e0 + u * NTH + tid; v[u] = (e < n) ? Wg[e] : 0.f; }
+        for (int u = 0; u < TAIL_ZU; ++u) {
+            const int e = u * NTH + tid;
+            const int sidx = e / H1, o = e - sidx * H1;
+            // z1 = b1 + the KS K-slice partials of train_fwd1n.  Branch-free and fully unrolled (clamped addresses, masked
+            // adds): as a run-time loop every partial was a load -> wait -> add round trip of its own
+            const int ec = e < 16 * H1 ? e : 0;
+            const int sc_ = ec / H1, oc = ec - sc_ * H1;
+            (void)sidx; (void)o;
+            const float* zp = b.a1 + (long long)(unit * 16 + sc_) * H1p + oc;
+            float pz[ISK_FWD1_MAXKS];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { const int e = e0 + u * NTH + tid; if (e < n) Wl[e] = v[u]; }
+            for (int ks = 0; ks < ISK_FWD1_MAXKS; ++ks) pz[ks] = zp[(long long)(ks < b.KS ? ks : 0) * b.zstride];
+            float z = b1[oc];
+#pragma unroll
+            for (int ks = 0; ks < ISK_FWD1_MAXKS; ++ks) z += ks < b.KS ? pz[ks] : 0.f;
+            zv[u] = z;
         }
+    }
+    float wv[ISK_MAX_LAYERS][TAIL_WU];
+#pragma unroll
+    for (int l = 1; l < ISK_MAX_LAYERS; ++l) {
+        if (l < L) {
+            const float* Wg = b.theta + s.off_W[l];
+            const int n = s.widths[l + 1] * s.widths[l];
+#pragma unroll
+            for (int u = 0; u < TAIL_WU; ++u) { const int e = u * NTH + tid; wv[l][u] = (e < n) ? Wg[e] : 0.f; }
+        }
+    }
+    const float lp_tgt = lp ? b.target[lp_row * nout_ + tid % nout_] : 0.f;
+    const float lp_w = (lp && !b.cot_mode) ? b.lossw[tid % nout_] : 0.f;
+    // stage the tail weights (Flux layout W[o + k*N]) in LDS
+#pragma unroll
+    for (int l = 1; l < ISK_MAX_LAYERS; ++l) {
+        if (l < L) {
+            float* Wl = sm + tail_off_w(s, l);
+            const float* Wg = b.theta + s.off_W[l];
+            const int n = s.widths[l + 1] * s.widths[l];
+#pragma unroll
+            for (int u = 0; u < TAIL_WU; ++u) { const int e = u * NTH + tid; if (e < n) Wl[e] = wv[l][u]; }
+            for (int e = TAIL_WU * NTH + tid; e < n; e += NTH) Wl[e] = Wg[e];    // tails beyond 2048 weights per layer
+        }
+    }
+    if (b.bt && unit == 0 && tid == 0) {
+        // Adam's bias corrections, kept on the device so that a step's launch arguments never change (hipGraph replay):
+        // bt[0..1] = beta^t of the coming optimizer step; hand them to opt_step in bt[2..3] and advance
+        b.bt[2] = b.bt[0]; b.bt[3] = b.bt[1];
+        b.bt[0] *= b.beta1; b.bt[1] *= b.beta2;
     }
     {
         float* A0 = sm;
         float* Z0 = sm + 16 * H1;
         const int act0 = (L == 1) ? s.lastact : s.act;
-        for (int e0 = 0; e0 < 16 * H1; e0 += NTH * 4) {
-            float v[4];
+        const float* b1 = b.theta + s.off_b[0];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * NTH + tid;
-                const int sidx = e / H1, o = e - sidx * H1;
-                v[u] = (e < 16 * H1) ? b.a1[(long long)(unit * 16 + sidx) * H1p + o] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * NTH + tid;
-                if (e < 16 * H1) { Z0[e] = v[u]; A0[e] = t_act(act0, v[u]); }
-            }
+        for (int u = 0; u < TAIL_ZU; ++u) {
+            const int e = u * NTH + tid;
+            if (e < 16 * H1) { Z0[e] = zv[u]; A0[e] = t_act(act0, zv[u]); }
+        }
+        for (int e = TAIL_ZU * NTH + tid; e < 16 * H1; e += NTH) {               // first hidden layers wider than 256
+            const int sidx = e / H1, o = e - sidx * H1;
+            const float* zp = b.a1 + (long long)(unit * 16 + sidx) * H1p + o;
+            float z = b1[o];
+            for (int ks = 0; ks < b.KS; ++ks) z += zp[(long long)ks * b.zstride];
+            Z0[e] = z;
+            A0[e] = t_act(act0, z);
         }
     }
     __syncthreads();
@@ -236,14 +437,16 @@ __global__ __launch_bounds__(TAIL_THREADS) void train_tail_kernel(TrainShape s, 
             const int row = unit * 16 + sidx;
             const bool valid = row < B;
             const int rowc = valid ? row : B - 1;
-            const long long prow = perm ? perm[rowc] : rowc;
+            const bool first = p < NTH;                    // == tid: prefetched in the prologue
+            const long long prow = first ? lp_row : (perm ? perm[rowc] : rowc);
+            const float tg = first ? lp_tgt : b.target[prow * nout + o];
             const float out = AL[p];
             float d = 0.f;
             if (b.cot_mode) {                              // pullback: delta_L = cotangent .* act'(z_L)
-                if (valid) d = b.target[prow * nout + o] * t_dact(s.lastact, ZL[p], out);
+                if (valid) d = tg * t_dact(s.lastact, ZL[p], out);
             } else {
-                const float w = b.lossw[o];
-                const float r = (out - b.target[prow * nout + o]) * w;
+                const float w = first ? lp_w : b.lossw[o];
+                const float r = (out - tg) * w;
                 if (valid) {
                     lsum += r * r;
                     d = 2.f * r * w * inv_div * t_dact(s.lastact, ZL[p], out);
@@ -298,12 +501,13 @@ __global__ __launch_bounds__(TAIL_THREADS) void train_tail_kernel(TrainShape s, 
         }
         __syncthreads();
     }
-    // delta1 -> global (zero padded)
+    // delta1 -> global (zero padded), columns in the order train_grad1n loads them: one dwordx4 per row covers FOUR
+    // output tiles (position 64 q + 4 c + u holds output 16 (4 q + u) + c), see isk_delta1_pos
     {
         const float* Z0 = sm + 16 * H1;
         for (int e = tid; e < 16 * H1p; e += NTH) {
             const int sidx = e / H1p, o = e - sidx * H1p;
-            b.delta1[(long long)(unit * 16 + sidx) * H1p + o] = (o < H1) ? Z0[sidx * H1 + o] : 0.f;
+            b.delta1[(long long)(unit * 16 + sidx) * H1p + isk_delta1_pos(o, H1p)] = (o < H1) ? Z0[sidx * H1 + o] : 0.f;
         }
     }
 }
@@ -319,13 +523,15 @@ void isk_launch_train_tail(const TrainShape& s, const TrainBuffers& b, const int
     hipLaunchKernelGGL(train_tail_kernel, dim3(units), dim3(TAIL_THREADS), lds, st, s, b, perm, B, inv_div);
 }
 
-// ------------------------------------------------------------------ train_grad1 ------
-// grid = Fp/16 feature tiles; workgroup = NW waves that SPLIT THE BATCH ROWS (the step is
-// latency-bound, so every SIMD gets 4 waves of independent gathers); each wave accumulates all
-// NT output tiles:  Gt[f][o] = sum_n xhat[n][f] * delta1[n][o]  (f32 MFMA), the NW partial tiles are
-// combined through LDS, then waves 0..NT-1 run the LayerNorm-affine unfold of their tile.
-// Output-column mapping: tiles are loaded four at a time with one dwordx4 per row, so tile t,
-// lane column li holds o = 64*(t/4) + 4*li + t%4 for the first 4*(NT/4) tiles, 16*t + li after.
+// ------------------------------------------------------------------ train_grad1n -----
+// grid = (Fp/16 feature tiles, row slabs); workgroup = NW waves that SPLIT THE BATCH ROWS (the step is
+// latency-bound, so every SIMD gets several waves of independent gathers); each wave accumulates all
+// NT output tiles:  Gt[f][o] = sum_n xhat[n][f] * delta1[n][o]  (f32 MFMA).  The NW partial tile sets are combined
+// through LDS by ALL threads, and because the engine keeps W1 (and its gradient) fragment-linear, accumulator
+// element (tile t, lane, r) IS gradient element ft*NT*256 + t*256 + 4*lane + r: the workgroup's share of dW1 is one
+// contiguous range, read (W1, for the LayerNorm unfold) and written as whole coalesced lines, no transposition.
+// delta1 rows are stored by train_tail in isk_delta1_pos order, so the dwordx4 a lane loads per row is column li of
+// four consecutive tiles.
 __device__ __forceinline__ long long part_to_grad(const TrainShape& s, long long e) {
     if (e == 0) return s.nparams;                       // loss slot
     e -= 1;
@@ -342,16 +548,19 @@ __device__ __forceinline__ long long part_to_grad(const TrainShape& s, long long
 }
 
 template <int NT, int NW>
-__global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm,
-                                                             int B, int nparts) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm,
+                                                              int B, int nparts) {
     ISK_LATENCY_CHAIN_PRIO();
     constexpr int NB4 = NT / 4, NR = NT % 4;
     constexpr int CB = 4;                          // chunks per batch: their row indices are fetched together
+    constexpr int NTH = NW * 64;
+    static_assert(NTH % 256 == 0, "a thread keeps one (lane, r) of the accumulator layout across tiles");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* red = sm;                               // [NW][NT][256]
     float* Dred = sm + NW * NT * 256;              // [NW][NT][16]
-    float* Dsh = Dred + NW * NT * 16;              // [NT*16] in tile order
-    const int H1 = s.widths[1], F = s.widths[0];
+    float* Dsh = Dred + NW * NT * 16;              // [NT*16]
+    float* psh = Dsh + NT * 16;                    // [NW][2][4]  per-wave (dg, dbeta) partials of 4 features
+    const int H1 = s.widths[1];
     const int H1p = NT * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -360,6 +569,10 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
     float* const gout = b.grad + (long long)slab * (s.nparams + 2);   // each writes its (linear) share to its own gradient slab
     const long long PS = part_size(s);
     const bool ln = s.layernorm != 0;
+    constexpr int NE = (NT * 256 + NTH - 1) / NTH;
+    const int rr_ = tid & 3, lanep = (tid >> 2) & 63, lqp = lanep >> 4, lip = lanep & 15;
+    const int k = ft * 16 + 4 * lqp + rr_;
+    const float* W1n = b.theta + s.off_W[0] + (long long)ft * NT * 256;
     // small-gradient partial vectors: one element per 16-lane group, lanes split the partials (slab 0 only)
     if (slab == 0) {
         const long long ngroups = (long long)gridDim.x * (NW * 4);
@@ -386,7 +599,7 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
     const int nchunks = (B + 15) / 16;
     const float* Xc = b.xhat_xs + ft * 16 + li;
     for (int c0 = wave + NW * slab; c0 < nchunks; c0 += NW * CB * nslab) {
-        long long rr[CB][4];
+        int rr[CB][4];                                                // row indices fit 32 bits (isk_set_data checks N)
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             const int chunk = c0 + cb * NW * nslab;
@@ -406,7 +619,7 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
                 float br[4][NR > 0 ? NR : 1];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    av[j] = Xc[rr[cb][j] * (long long)b.Fp];
+                    av[j] = Xc[(long long)rr[cb][j] * b.Fp];
                     const float* drow = b.delta1 + (long long)(r0 + j) * H1p;
 #pragma unroll
                     for (int q = 0; q < NB4; ++q) bq[j][q] = *(const f32x4*)(drow + 64 * q + 4 * li);
@@ -439,75 +652,79 @@ __global__ __launch_bounds__(NW * 64) void train_grad1_kernel(TrainShape s, Trai
         d += __shfl_xor(d, 32, WAVE);
         if (lq == 0) Dred[(wave * NT + t) * 16 + li] = d;
     }
+    // what the epilogue needs from memory is requested here (the accumulators are parked, registers are free) and arrives
+    // under the two barriers: this thread's share of W1 (fragment-linear: contiguous) and its feature's LayerNorm scale / bias
+    float w1v[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) w1v[i] = (ln && tid + NTH * i < NT * 256) ? W1n[tid + NTH * i] : 0.f;
+    const float gk = ln ? b.theta[s.off_lns + k] : 1.f, bk = ln ? b.theta[s.off_lnb + k] : 0.f;   // LayerNorm blocks are padded to Fp
     __syncthreads();
-    if (tid < NT * 16) {                                               // D in tile order: Dsh[t*16 + li]
+    if (tid < NT * 16) {                                               // D[o], o = 16 t + li = tid
         float d = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) d += Dred[w * NT * 16 + tid];
         Dsh[tid] = d;
-        const int t = tid >> 4, l2 = tid & 15;
-        const int o = (t < 4 * NB4) ? 64 * (t >> 2) + 4 * l2 + (t & 3) : 16 * t + l2;
-        if (ft == 0 && o < H1) gout[s.off_b[0] + o] = d;                // db1 == D (this slab's rows)
+        if (ft == 0 && tid < H1) gout[s.off_b[0] + tid] = d;            // db1 == D (this slab's rows)
     }
     __syncthreads();
-    // Epilogue, coalesced: wave w owns feature row f = 16*ft + w (NW >= 16 waves cover the tile; with
-    // NW == 8 each wave takes two rows) and its lanes walk the outputs o, so the W1 reads and the dW1
-    // writes are contiguous in Flux's (out, in) layout.  G[f][o] is re-assembled from the NW partial
-    // accumulator tiles in LDS: C layout row = 4*lq + r is the feature, col = li the output slot.
-    const float* W1 = b.theta + s.off_W[0];
-    const float* g = ln ? b.theta + s.off_lns : nullptr;
-    const float* beta = ln ? b.theta + s.off_lnb : nullptr;
-    float* gW1 = gout + s.off_W[0];
-    for (int fl = wave; fl < 16; fl += NW) {
-        const int f = ft * 16 + fl;
-        if (f >= F) continue;                                   // wave-uniform
-        const int flq = fl >> 2, fr = fl & 3;
-        const float gf = ln ? g[f] : 1.f, bf = ln ? beta[f] : 0.f;
-        float pg = 0.f, pb = 0.f;
-        for (int o = lane; o < H1; o += WAVE) {
-            int t, l2;
-            if (o < 64 * NB4) { t = 4 * (o >> 6) + (o & 3); l2 = (o & 63) >> 2; }
-            else { t = 4 * NB4 + ((o - 64 * NB4) >> 4); l2 = o & 15; }
-            const int slot = ((t * 64) + flq * 16 + l2) * 4 + fr;
+    // Epilogue.  Thread tid keeps accumulator slot (lane' = (tid/4) % 64, r = tid % 4) for the tiles t = tid/256 + (NTH/256) i:
+    // feature k = 16 ft + 4 (lane'/16) + r, output 16 t + lane'%16.  Element e = 256 t + 4 lane' + r of the workgroup's
+    // contiguous share of the (fragment-linear) layer-1 gradient.
+    float* gW1 = gout + s.off_W[0] + (long long)ft * NT * 256;
+    float pg = 0.f, pb = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + NTH * i;
+        if (e < NT * 256) {
             float G = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) G += red[w * NT * 256 + slot];
+            for (int w = 0; w < NW; ++w) G += red[w * NT * 256 + e];
             if (ln) {
-                const float w1 = W1[o + (long long)f * H1];
-                const float Do = Dsh[t * 16 + l2];
-                gW1[o + (long long)f * H1] = gf * G + bf * Do;
-                pg += w1 * G;
-                pb += w1 * Do;
+                const float Do = Dsh[(e >> 8) * 16 + lip];
+                gW1[e] = gk * G + bk * Do;
+                pg += w1v[i] * G;
+                pb += w1v[i] * Do;
             } else {
-                gW1[o + (long long)f * H1] = G;
+                gW1[e] = G;
             }
         }
-        if (ln) {
-            pg = wave_sum_t(pg);
-            pb = wave_sum_t(pb);
-            if (lane == 0) { gout[s.off_lns + f] = pg; gout[s.off_lnb + f] = pb; }
+    }
+    if (ln) {
+        // dg[k], dbeta[k]: sum over the 16 output columns (lane bits 2..5 of this wave) and over the tiles (the waves
+        // with the same wave % 4 hold the same features)
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) { pg += __shfl_xor(pg, o, WAVE); pb += __shfl_xor(pb, o, WAVE); }
+        if (lane < 4) { psh[(wave * 2 + 0) * 4 + lane] = pg; psh[(wave * 2 + 1) * 4 + lane] = pb; }
+        __syncthreads();
+        if (tid < 32) {
+            const int which = tid >> 4, kl = tid & 15, q = kl >> 2, r = kl & 3;     // feature 16 ft + kl: lq' = q, r
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                if ((w & 3) == q) v += psh[(w * 2 + which) * 4 + r];
+            gout[(which ? s.off_lnb : s.off_lns) + ft * 16 + kl] = v;
         }
     }
 }
 
 template <int NT, int NW>
-static void launch_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st) {
+static void launch_grad1n(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st) {
     const int nparts = (B + 15) / 16;
-    const size_t lds = (size_t)(NW * NT * 256 + NW * NT * 16 + NT * 16) * sizeof(float);
+    const size_t lds = (size_t)(NW * NT * 256 + NW * NT * 16 + NT * 16 + NW * 8) * sizeof(float);
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)train_grad1_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((train_grad1_kernel<NT, NW>), dim3(b.Fp / 16, nslab), dim3(NW * 64), lds, st, s, b, perm, B, nparts);
+        (void)hipFuncSetAttribute((const void*)train_grad1n_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((train_grad1n_kernel<NT, NW>), dim3(b.Fp / 16, nslab), dim3(NW * 64), lds, st, s, b, perm, B, nparts);
 }
 
-void isk_launch_train_grad1(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab_flags, hipStream_t st) {
+void isk_launch_train_grad1n(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab_flags, hipStream_t st) {
     const int nt1 = isk_pad16(s.widths[1]) / 16;
     const int nslab = nslab_flags & 0xff;
     static const int nw8_env = [] { const char* v = getenv("ISK_GRAD1_NW8"); return v ? atoi(v) : -1; }();
     const int nw8 = nw8_env >= 0 ? nw8_env : ((nslab_flags & 0x100) != 0);
-#define G1CASE(NT_) case NT_: if (nw8) launch_grad1<NT_, 8>(s, b, perm, B, nslab, st); else launch_grad1<NT_, 16>(s, b, perm, B, nslab, st); break;
+#define G1CASE(NT_) case NT_: if (nw8) launch_grad1n<NT_, 8>(s, b, perm, B, nslab, st); else launch_grad1n<NT_, 16>(s, b, perm, B, nslab, st); break;
     switch (nt1) {
         G1CASE(1) G1CASE(2) G1CASE(3) G1CASE(4) G1CASE(5) G1CASE(6) G1CASE(7) G1CASE(8) G1CASE(9)
-        default: launch_grad1<10, 8>(s, b, perm, B, nslab, st); break;
+        default: launch_grad1n<10, 8>(s, b, perm, B, nslab, st); break;
     }
 #undef G1CASE
 }
@@ -570,7 +787,7 @@ __global__ __launch_bounds__(256) void vjp_back_kernel(VjpArgs a) {
     const long long n = blockIdx.x;
     const int tid = threadIdx.x;
     const bool ln = a.off_lns >= 0;
-    for (int o = tid; o < a.H1p; o += 256) dl[o] = a.delta1[n * a.H1p + o];
+    for (int o = tid; o < a.H1p; o += 256) dl[o] = a.delta1[n * a.H1p + (a.native ? isk_delta1_pos(o, a.H1p) : o)];
     if (a.pairs)
         for (int i = tid; i < a.D; i += 256) gc[i] = 0.f;
     __syncthreads();
@@ -578,12 +795,21 @@ __global__ __launch_bounds__(256) void vjp_back_kernel(VjpArgs a) {
     const float* g = ln ? a.theta + a.off_lns : nullptr;
     const float* xh = a.xhat + n * a.Fp;
     float s1 = 0.f, s2 = 0.f;
+    const int nt = a.H1p / 16;
     for (int f = tid; f < a.F; f += 256) {
-        const float* w = W1 + (long long)f * a.H1;
+        // W1[o][f]: Flux layout (o fastest) on the layered path, fragment-linear on the fused path (a.native)
+        const float* w = a.native ? W1 + ((long long)(f >> 4) * nt * 64 + ((f & 15) >> 2) * 16) * 4 + (f & 3) : W1 + (long long)f * a.H1;
         float acc0 = 0.f, acc1 = 0.f;
-        int o = 0;
-        for (; o + 1 < a.H1; o += 2) { acc0 += dl[o] * w[o]; acc1 += dl[o + 1] * w[o + 1]; }
-        if (o < a.H1) acc0 += dl[o] * w[o];
+        if (a.native) {
+            for (int o = 0; o < a.H1; ++o) {
+                const float wv = w[(o >> 4) * 256 + (o & 15) * 4];
+                if (o & 1) acc1 += dl[o] * wv; else acc0 += dl[o] * wv;
+            }
+        } else {
+            int o = 0;
+            for (; o + 1 < a.H1; o += 2) { acc0 += dl[o] * w[o]; acc1 += dl[o + 1] * w[o + 1]; }
+            if (o < a.H1) acc0 += dl[o] * w[o];
+        }
         float v = acc0 + acc1;
         if (ln) v *= g[f];
         dx[f] = v;
