@@ -448,7 +448,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
             const int w = isk_pad16(cfg->widths[l + 1]) + 4;
             if (l + 1 < e->L) { if (l % 2 == 0) sa = std::max(sa, w); else sb = std::max(sb, w); }
         }
-        for (int l = 0; l < e->L; ++l) tail_train += (size_t)32 * cfg->widths[l + 1];
+        for (int l = 0; l < e->L; ++l) tail_train += (size_t)33 * cfg->widths[l + 1];   // 16 x (A, Z) per layer + the bias
         if ((tailw + (size_t)8 * 16 * (sa + sb)) * sizeof(float) > 150 * 1024) fits = false;   // fused forward LDS
         if (tail_train * sizeof(float) > 150 * 1024) fits = false;                              // train_tail LDS
         if (getenv("ISK_FORCE_LAYERED")) fits = false;

@@ -32,7 +32,10 @@ __device__ __forceinline__ float t_sigmoid(float z) {
     float r = 1.0f / (1.0f + e);
     return z >= 0.f ? r : e * r;
 }
-__device__ __forceinline__ float t_act(int act, float z) {
+// NOT inlined: train_tail calls these from a dozen places and each inlined copy carries every activation's code (tanhf
+// alone is ~100 instructions); the kernel is a chain of short phases that each START with instruction-cache misses, so
+// its size is its latency (8280 -> see DESIGN.md instructions)
+__device__ __attribute__((noinline)) float t_act(int act, float z) {
     switch (act) {
         case ISK_ACT_SIGMOID: return t_sigmoid(z);
         case ISK_ACT_TANH: return tanhf(z);
@@ -41,7 +44,7 @@ __device__ __forceinline__ float t_act(int act, float z) {
         default: return z;
     }
 }
-__device__ __forceinline__ float t_dact(int act, float z, float a) {
+__device__ __attribute__((noinline)) float t_dact(int act, float z, float a) {
     switch (act) {
         case ISK_ACT_SIGMOID: return a * (1.f - a);
         case ISK_ACT_TANH: return 1.f - a * a;
@@ -298,15 +301,49 @@ __host__ __device__ static inline int tail_off_w(const TrainShape& s, int l) {
     for (int i = 1; i < l; ++i) o += s.widths[i + 1] * s.widths[i];
     return o;
 }
+// ... | b_1 | b_2 | ... behind the weights: the tail biases (a global load in the middle of a phase is a full memory round trip)
+__host__ __device__ static inline int tail_off_b(const TrainShape& s, int l) {
+    int o = tail_off_w(s, s.nlayers);
+    for (int i = 1; i < l; ++i) o += s.widths[i + 1];
+    return o;
+}
 
 // 512 threads at <= 128 registers: two waves per SIMD, which is what fits beside a featurizer wave (~248 of the SIMD's 512
 // registers); the phases are latency chains, not throughput loops, so eight waves lose nothing against sixteen
+// one 16 x 16 tile  C[m][n] = sum_k A(m, k) * B(k, n)  on the f32 MFMA, operands fetched element-wise (LDS): fa(k) is
+// this lane's A(lane % 16, k), fb(k) its B(k, lane % 16); step s contracts k = 4 s + lane / 16.  Four independent
+// accumulation chains hide the MFMA latency; callers mask k >= K (and columns past the matrix) to 0 on BOTH operands.
+template <class FA, class FB>
+__device__ __forceinline__ f32x4 tail_tile_mma(int nsteps, int lq, FA fa, FB fb, int st0 = 0) {
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+    int st = st0;
+    for (; st + 3 < nsteps; st += 4) {
+        const int k0 = 4 * st + lq;
+        const float a0 = fa(k0), a1 = fa(k0 + 4), a2 = fa(k0 + 8), a3 = fa(k0 + 12);
+        const float b0 = fb(k0), b1 = fb(k0 + 4), b2 = fb(k0 + 8), b3 = fb(k0 + 12);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, c3, 0, 0, 0);
+    }
+    for (; st < nsteps; ++st) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa(4 * st + lq), fb(4 * st + lq), c0, 0, 0, 0);
+    return (c0 + c1) + (c2 + c3);
+}
+
+#ifdef ISK_TAIL_STAMP
+__device__ unsigned long long g_tail_stamps[32];
+extern "C" void isk_debug_tail_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_stamps), sizeof(unsigned long long) * 32); }
+#define TSTAMP(k) do { if (blockIdx.x == 7 && threadIdx.x == 0) { g_tail_stamps[k] = __builtin_amdgcn_s_memrealtime(); g_tail_stamps[16 + k] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
 #define TAIL_THREADS 512
 #define TAIL_ZU (4096 / TAIL_THREADS)      /* z1 elements per thread in the prefetched first pass (16 x H1 <= 4096) */
 #define TAIL_WU (2048 / TAIL_THREADS)      /* tail weights per thread and layer in the prefetched first pass */
 __global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm,
                                                                   int B, float inv_div) {
     ISK_LATENCY_CHAIN_PRIO();
+    TSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float lred[TAIL_THREADS / 64];
     constexpr int NTH = TAIL_THREADS;
@@ -315,6 +352,7 @@ __global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TrainShape 
     const int unit = blockIdx.x;
     const int H1 = s.widths[1];
     const int H1p = (H1 + 15) & ~15;
+    const int wv = tid >> 6, li = tid & 15, lq = (tid >> 4) & 3;
     // The kernel is a chain of short phases; its global loads are what it waits for.  Everything the first pass of every
     // phase needs is requested HERE, before the first wait: the batch row of this thread's loss element (the target load
     // depends on it and follows as soon as it lands), the K-slice partials of z1, the tail weights.
@@ -348,36 +386,52 @@ __global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TrainShape 
             zv[u] = z;
         }
     }
-    float wv[ISK_MAX_LAYERS][TAIL_WU];
+    // weights and biases of the first TAIL_PF tail layers (deeper tails stage the rest with plain loops below); clamped
+    // addresses instead of predicated loads: every branch around a load is code, and this kernel's size is latency
+    // (a chain of short phases, each starting on instruction-cache misses)
+    constexpr int TAIL_PF = 2;
+    float wpre[TAIL_PF][TAIL_WU], bpre[TAIL_PF];
 #pragma unroll
-    for (int l = 1; l < ISK_MAX_LAYERS; ++l) {
-        if (l < L) {
-            const float* Wg = b.theta + s.off_W[l];
-            const int n = s.widths[l + 1] * s.widths[l];
+    for (int i = 0; i < TAIL_PF; ++i) {
+        const int l = (1 + i < L) ? 1 + i : (L > 1 ? L - 1 : 0);       // a duplicate of the last layer when the tail is shorter
+        const float* Wg = b.theta + s.off_W[l];
+        const int n = s.widths[l + 1] * s.widths[l];
 #pragma unroll
-            for (int u = 0; u < TAIL_WU; ++u) { const int e = u * NTH + tid; wv[l][u] = (e < n) ? Wg[e] : 0.f; }
-        }
+        for (int u = 0; u < TAIL_WU; ++u) { const int e = u * NTH + tid; wpre[i][u] = Wg[e < n ? e : n - 1]; }
+        bpre[i] = b.theta[s.off_b[l] + (tid < s.widths[l + 1] ? tid : 0)];
     }
     const float lp_tgt = lp ? b.target[lp_row * nout_ + tid % nout_] : 0.f;
     const float lp_w = (lp && !b.cot_mode) ? b.lossw[tid % nout_] : 0.f;
     // stage the tail weights (Flux layout W[o + k*N]) in LDS
 #pragma unroll
-    for (int l = 1; l < ISK_MAX_LAYERS; ++l) {
+    for (int i = 0; i < TAIL_PF; ++i) {
+        const int l = 1 + i;
         if (l < L) {
             float* Wl = sm + tail_off_w(s, l);
             const float* Wg = b.theta + s.off_W[l];
             const int n = s.widths[l + 1] * s.widths[l];
 #pragma unroll
-            for (int u = 0; u < TAIL_WU; ++u) { const int e = u * NTH + tid; if (e < n) Wl[e] = wv[l][u]; }
+            for (int u = 0; u < TAIL_WU; ++u) { const int e = u * NTH + tid; if (e < n) Wl[e] = wpre[i][u]; }
             for (int e = TAIL_WU * NTH + tid; e < n; e += NTH) Wl[e] = Wg[e];    // tails beyond 2048 weights per layer
+            float* bl = sm + tail_off_b(s, l);
+            if (tid < s.widths[l + 1]) bl[tid] = bpre[i];
+            for (int e = NTH + tid; e < s.widths[l + 1]; e += NTH) bl[e] = b.theta[s.off_b[l] + e];
         }
     }
-    if (b.bt && unit == 0 && tid == 0) {
-        // Adam's bias corrections, kept on the device so that a step's launch arguments never change (hipGraph replay):
-        // bt[0..1] = beta^t of the coming optimizer step; hand them to opt_step in bt[2..3] and advance
-        b.bt[2] = b.bt[0]; b.bt[3] = b.bt[1];
-        b.bt[0] *= b.beta1; b.bt[1] *= b.beta2;
+    for (int l = 1 + TAIL_PF; l < L; ++l) {                                   // deeper tails: not prefetched
+        float* Wl = sm + tail_off_w(s, l);
+        const float* Wg = b.theta + s.off_W[l];
+        const int n = s.widths[l + 1] * s.widths[l];
+        for (int e = tid; e < n; e += NTH) Wl[e] = Wg[e];
+        float* bl = sm + tail_off_b(s, l);
+        for (int e = tid; e < s.widths[l + 1]; e += NTH) bl[e] = b.theta[s.off_b[l] + e];
     }
+    // Adam's bias corrections, kept on the device so that a step's launch arguments never change (hipGraph replay):
+    // bt[0..1] = beta^t of the coming optimizer step; handed to opt_step in bt[2..3] and advanced at the END of the kernel
+    // (stores only: loaded here with everything else, so no wave waits for them in the middle of a phase)
+    const bool bt_owner = b.bt && unit == 0 && tid == 0;
+    double bt0 = 0.0, bt1 = 0.0;
+    if (bt_owner) { bt0 = b.bt[0]; bt1 = b.bt[1]; }
     {
         float* A0 = sm;
         float* Z0 = sm + 16 * H1;
@@ -398,33 +452,68 @@ __global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TrainShape 
         }
     }
     __syncthreads();
+    TSTAMP(1);
     for (int l = 1; l < L; ++l) {
         const int K = s.widths[l], N = s.widths[l + 1];
         const float* Ap = sm + tail_off_act(s, l - 1);
         float* Al = sm + tail_off_act(s, l);
         float* Zl = Al + 16 * N;
         const float* Wl = sm + tail_off_w(s, l);
-        const float* bias = b.theta + s.off_b[l];
+        const float* bias = sm + tail_off_b(s, l);
         const int actl = (l == L - 1) ? s.lastact : s.act;
-        // each (sample, output) dot product is split over 4 adjacent lanes along k
-        for (int p4 = tid; p4 < 16 * N * 4; p4 += NTH) {
-            const int p = p4 >> 2, ks = p4 & 3;
-            const int sidx = p / N, o = p - sidx * N;
-            const float* arow = Ap + sidx * K;
-            float z0 = 0.f, z1 = 0.f;
-            int k = ks;
-            for (; k + 4 < K; k += 8) { z0 += Wl[o + k * N] * arow[k]; z1 += Wl[o + (k + 4) * N] * arow[k + 4]; }
-            if (k < K) z0 += Wl[o + k * N] * arow[k];
-            float z = z0 + z1;
-            z += __shfl_xor(z, 1, WAVE);
-            z += __shfl_xor(z, 2, WAVE);
-            if (ks == 0) {
-                z += bias[o];
-                Zl[p] = z;
-                Al[p] = t_act(actl, z);
+        // Z_l (16 x N) = A_{l-1} (16 x K) * W_l' on the f32 MFMA: a wave per 16-column tile (the VALU version of this
+        // phase -- 2 LDS reads per multiply-add -- took 4 us of the kernel's 16)
+        // narrow layers (fewer tiles than waves: the C3 tail is ONE tile deep 142) also split the contraction over the
+        // waves, partial tiles meet in LDS
+        const int nsteps = (K + 3) / 4;
+        constexpr int NWV = NTH / 64;
+        const int tiles = (N + 15) / 16;
+        const int ksplit = tiles < NWV ? NWV / tiles : 1;
+        const int spp = (nsteps + ksplit - 1) / ksplit;               // steps per part
+        float* pbuf = sm + tail_off_b(s, L);                          // [NWV][256] partial tiles
+        const float* arow = Ap + li * K;
+        if (l == 1) TSTAMP(6);
+        for (int j = wv; j < tiles * ksplit; j += NWV) {
+            const int t = j / ksplit, part = j - t * ksplit;
+            const int n = 16 * t + li;
+            const bool nok = n < N;
+            const float* wcol = Wl + (nok ? n : N - 1);
+            int s1 = (part + 1) * spp;
+            if (s1 > nsteps) s1 = nsteps;
+            const f32x4 acc = tail_tile_mma(s1, lq,
+                [&](int k) { const float v = arow[k < K ? k : K - 1]; return k < K ? v : 0.f; },
+                [&](int k) { const float v = wcol[(k < K ? k : K - 1) * N]; return (k < K && nok) ? v : 0.f; }, part * spp);
+            if (ksplit > 1) {
+                *(f32x4*)(pbuf + (wv * 64 + (tid & 63)) * 4) = acc;  // job j runs on wave j (tiles * ksplit <= NWV)
+            } else if (nok) {
+                const float bn = bias[n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                       // accumulator rows 4 lq + r = samples, column n
+                    const float z = acc[r] + bn;
+                    Zl[(4 * lq + r) * N + n] = z;
+                    Al[(4 * lq + r) * N + n] = t_act(actl, z);
+                }
             }
         }
+        if (l == 1) TSTAMP(7);
+        if (ksplit > 1) {
+            __syncthreads();
+            if (l == 1) TSTAMP(8);
+            for (int e = tid; e < tiles * 256; e += NTH) {            // element (tile, lane', r) of the accumulator layout
+                const int t = e >> 8, lp_ = (e >> 2) & 63, r = e & 3;
+                const int n = 16 * t + (lp_ & 15), row = 4 * (lp_ >> 4) + r;
+                if (n < N) {
+                    float z = bias[n];
+                    for (int pp = 0; pp < ksplit; ++pp) z += pbuf[(t * ksplit + pp) * 256 + (e & 255)];
+                    Zl[row * N + n] = z;
+                    Al[row * N + n] = t_act(actl, z);
+                }
+            }
+            if (l == 1) TSTAMP(9);
+        }
         __syncthreads();
+        if (l == 1) TSTAMP(10);
+        TSTAMP(2);
     }
     // loss + delta of the last layer (overwrites Z_{L-1})
     const int nout = s.widths[L];
@@ -459,6 +548,7 @@ __global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TrainShape 
     for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, WAVE);
     if ((tid & 63) == 0) lred[tid >> 6] = lsum;
     __syncthreads();
+    TSTAMP(3);
     float* part = b.part + (long long)unit * part_size(s);
     if (tid == 0) {
         float t = 0.f;
@@ -477,12 +567,43 @@ __global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TrainShape 
         for (int i = 1; i < l; ++i) poff += (long long)s.widths[i + 1] * s.widths[i] + s.widths[i + 1];
         float* pW = part + poff;
         float* pb = pW + (long long)N * K;
-        for (int e = tid; e < N * K; e += NTH) {
-            const int k = e / N, o = e - k * N;
-            float acc = 0.f;
+        // Both products of the layer as MFMA tile jobs dealt to the waves (they read A_{l-1}, delta_l, W_l and write the
+        // partial dW_l / Z_{l-1}: no barrier between them):
+        //   dW_l (N x K)       = delta_l' (N x 16) * A_{l-1} (16 x K)          jobs [0, tN*tK)
+        //   delta_{l-1} (16xK) = (delta_l (16 x N) * W_l (N x K)) .* act'      jobs [tN*tK, tN*tK + tK)
+        const int tN = (N + 15) / 16, tK = (K + 15) / 16;
+        for (int j = wv; j < tN * tK + tK; j += NTH / 64) {
+            if (j < tN * tK) {
+                const int to = j / tK, tk = j - to * tK;
+                const int o = 16 * to + li, kk = 16 * tk + li;           // A' row index (output), B' column index (input)
+                const bool ook = o < N, kok = kk < K;
+                const int oc = ook ? o : N - 1, kc = kok ? kk : K - 1;
+                const f32x4 acc = tail_tile_mma(4, lq,
+                    [&](int q) { const float v = Zl[q * N + oc]; return ook ? v : 0.f; },
+                    [&](int q) { const float v = Ap[q * K + kc]; return kok ? v : 0.f; });
+                if (kok) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc += Zl[q * N + o] * Ap[q * K + k];
-            pW[e] = acc;
+                    for (int r = 0; r < 4; ++r) {                    // accumulator rows = outputs 16 to + 4 lq + r, column = input kk
+                        const int oo = 16 * to + 4 * lq + r;
+                        if (oo < N) pW[oo + (long long)kk * N] = acc[r];
+                    }
+                }
+            } else {
+                const int tk = j - tN * tK;
+                const int kk = 16 * tk + li;
+                const bool kok = kk < K;
+                const int kc = kok ? kk : K - 1;
+                const f32x4 acc = tail_tile_mma((N + 3) / 4, lq,
+                    [&](int o) { const float v = Zl[li * N + (o < N ? o : N - 1)]; return o < N ? v : 0.f; },
+                    [&](int o) { const float v = Wl[(o < N ? o : N - 1) + kc * N]; return (o < N && kok) ? v : 0.f; });
+                if (kok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                    // rows = samples 4 lq + r, column = input kk; in place
+                        const int p = (4 * lq + r) * K + kk;
+                        Zp[p] = acc[r] * t_dact(s.act, Zp[p], Ap[p]);
+                    }
+                }
+            }
         }
         for (int o = tid; o < N; o += NTH) {
             float acc = 0.f;
@@ -490,16 +611,8 @@ __global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TrainShape 
             for (int q = 0; q < 16; ++q) acc += Zl[q * N + o];
             pb[o] = acc;
         }
-        for (int p = tid; p < 16 * K; p += NTH) {
-            const int sidx = p / K, k = p - sidx * K;
-            const float* drow = Zl + sidx * N;
-            float a0 = 0.f, a1 = 0.f;
-            int o = 0;
-            for (; o + 1 < N; o += 2) { a0 += Wl[o + k * N] * drow[o]; a1 += Wl[o + 1 + k * N] * drow[o + 1]; }
-            if (o < N) a0 += Wl[o + k * N] * drow[o];
-            Zp[p] = (a0 + a1) * t_dact(s.act, Zp[p], Ap[p]);      // read and written by this thread only
-        }
         __syncthreads();
+        TSTAMP(4);
     }
     // delta1 -> global (zero padded), columns in the order train_grad1n loads them: one dwordx4 per row covers FOUR
     // output tiles (position 64 q + 4 c + u holds output 16 (4 q + u) + c), see isk_delta1_pos
@@ -510,9 +623,14 @@ __global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TrainShape 
             b.delta1[(long long)(unit * 16 + sidx) * H1p + isk_delta1_pos(o, H1p)] = (o < H1) ? Z0[sidx * H1 + o] : 0.f;
         }
     }
+    if (bt_owner) {
+        b.bt[2] = bt0; b.bt[3] = bt1;
+        b.bt[0] = bt0 * b.beta1; b.bt[1] = bt1 * b.beta2;
+    }
+    TSTAMP(5);
 }
 
-static size_t tail_lds_bytes(const TrainShape& s) { return (size_t)tail_off_w(s, s.nlayers) * sizeof(float); }
+static size_t tail_lds_bytes(const TrainShape& s) { return ((size_t)tail_off_b(s, s.nlayers) + (TAIL_THREADS / 64) * 256) * sizeof(float); }
 
 void isk_launch_train_tail(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div,
                            hipStream_t st) {
