@@ -450,7 +450,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
         }
         for (int l = 0; l < e->L; ++l) tail_train += (size_t)33 * cfg->widths[l + 1];   // 16 x (A, Z) per layer + the bias
         if ((tailw + (size_t)8 * 16 * (sa + sb)) * sizeof(float) > 150 * 1024) fits = false;   // fused forward LDS
-        if (tail_train * sizeof(float) > 150 * 1024) fits = false;                              // train_tail LDS
+        if ((tail_train + 8 * 256) * sizeof(float) > 150 * 1024) fits = false;                  // train_tail LDS (+ its partial-tile buffer)
         if (getenv("ISK_FORCE_LAYERED")) fits = false;
         e->layered = !fits;
     }

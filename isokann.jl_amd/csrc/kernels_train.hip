@@ -308,13 +308,11 @@ __host__ __device__ static inline int tail_off_b(const TrainShape& s, int l) {
     return o;
 }
 
-// 512 threads at <= 128 registers: two waves per SIMD, which is what fits beside a featurizer wave (~248 of the SIMD's 512
-// registers); the phases are latency chains, not throughput loops, so eight waves lose nothing against sixteen
 // one 16 x 16 tile  C[m][n] = sum_k A(m, k) * B(k, n)  on the f32 MFMA, operands fetched element-wise (LDS): fa(k) is
 // this lane's A(lane % 16, k), fb(k) its B(k, lane % 16); step s contracts k = 4 s + lane / 16.  Four independent
 // accumulation chains hide the MFMA latency; callers mask k >= K (and columns past the matrix) to 0 on BOTH operands.
 template <class FA, class FB>
-__device__ __forceinline__ f32x4 tail_tile_mma(int nsteps, int lq, FA fa, FB fb, int st0 = 0) {
+__device__ __forceinline__ f32x4 tail_tile_mma(int st0, int nsteps, int lq, FA fa, FB fb) {
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
     int st = st0;
     for (; st + 3 < nsteps; st += 4) {
@@ -337,211 +335,213 @@ extern "C" void isk_debug_tail_stamps(unsigned long long* out) { (void)hipMemcpy
 #else
 #define TSTAMP(k) do { } while (0)
 #endif
+
+// The kernel is a chain of short dependent phases on 16 samples: what it costs is latency, and in its first versions most
+// of that was SCALAR: TrainShape arrived by value and every phase re-derived its LDS offsets, tile counts and loop bounds
+// from it with chains of dependent kernarg loads and integer divisions (in-kernel stamps: 1 us of "setup" in front of
+// each 0.9 us of arithmetic).  So: the host precomputes one descriptor per tail layer (TailLay, fetched as a block),
+// element loops are 2-D (row = tid / 32, column = tid % 32 + 32 i: no division), the products run as MFMA tiles.
+// 512 threads at <= 128 registers: two waves per SIMD, which is what fits beside a featurizer wave (~248 of the SIMD's
+// 512 registers).
 #define TAIL_THREADS 512
-#define TAIL_ZU (4096 / TAIL_THREADS)      /* z1 elements per thread in the prefetched first pass (16 x H1 <= 4096) */
+#define TAIL_ZI 5                          /* z1 columns per thread: H1 <= 160 on the fused path (ISK_MAX_NT tiles) */
 #define TAIL_WU (2048 / TAIL_THREADS)      /* tail weights per thread and layer in the prefetched first pass */
-__global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm,
+struct TailLay {
+    int K, N, act;              // inputs, outputs, activation of this layer
+    int tN, tK;                 // 16-wide tiles over N and over K
+    int nsteps, ksplit, spp;    // forward contraction: 4-deep steps, wave split, steps per part
+    int oAp, oZp;               // LDS float offsets: previous layer's activations / pre-activations (delta after the backward)
+    int oA, oZ, oW, oB;         //                    this layer's activations, pre-activations, weights (Flux), bias
+    int nW;                     // K * N
+    long long gW, gb;           // offsets in theta
+    long long pW, pb;           // offsets in the per-workgroup partial vector
+};
+struct TailDesc {
+    int L;                      // tail layers (model layers - 1)
+    int H1, H1p, nout, act0, lastact, hidden_act;
+    int oP;                     // LDS offset of the [8][256] partial-tile buffer
+    long long off_b0, PS;       // layer-1 bias in theta; partial-vector length
+    TailLay lay[ISK_MAX_LAYERS - 1];
+};
+
+__global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TailDesc d, TrainBuffers b, const int* __restrict__ perm,
                                                                   int B, float inv_div) {
     ISK_LATENCY_CHAIN_PRIO();
     TSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float lred[TAIL_THREADS / 64];
-    constexpr int NTH = TAIL_THREADS;
-    const int L = s.nlayers;
+    constexpr int NTH = TAIL_THREADS, NWV = NTH / 64;
+    const int L = d.L;
     const int tid = threadIdx.x;
     const int unit = blockIdx.x;
-    const int H1 = s.widths[1];
-    const int H1p = (H1 + 15) & ~15;
+    const int H1 = d.H1, H1p = d.H1p, nout = d.nout;
     const int wv = tid >> 6, li = tid & 15, lq = (tid >> 4) & 3;
-    // The kernel is a chain of short phases; its global loads are what it waits for.  Everything the first pass of every
-    // phase needs is requested HERE, before the first wait: the batch row of this thread's loss element (the target load
-    // depends on it and follows as soon as it lands), the K-slice partials of z1, the tail weights.
-    const int nout_ = s.widths[L];
-    const bool lp = tid < 16 * nout_;                    // this thread's element (sample tid / nout, output tid % nout) of the loss phase
-    long long lp_row = 0;
-    if (lp) {
-        const int row = unit * 16 + tid / nout_;
-        const int rowc = row < B ? row : B - 1;
-        lp_row = perm ? perm[rowc] : rowc;
-    }
-    float zv[TAIL_ZU];
+    const int r16 = tid >> 5, c32 = tid & 31;                   // 2-D element mapping: sample row, column (+ 32 i)
+    // ---- prologue: everything the first pass of every phase needs from memory is requested here, before the first wait
+    const int row_g = unit * 16 + r16;
+    const bool rvalid = row_g < B;
+    const long long lp_row = perm ? perm[rvalid ? row_g : B - 1] : (rvalid ? row_g : B - 1);     // this thread's sample
+    float zv[TAIL_ZI];
     {
-        const float* b1 = b.theta + s.off_b[0];
+        const float* b1 = b.theta + d.off_b0;
+        const float* zrow = b.a1 + (long long)row_g * H1p;
 #pragma unroll
-        for (int u = 0; u < TAIL_ZU; ++u) {
-            const int e = u * NTH + tid;
-            const int sidx = e / H1, o = e - sidx * H1;
-            // z1 = b1 + the KS K-slice partials of train_fwd1n.  Branch-free and fully unrolled (clamped addresses, masked
-            // adds): as a run-time loop every partial was a load -> wait -> add round trip of its own
-            const int ec = e < 16 * H1 ? e : 0;
-            const int sc_ = ec / H1, oc = ec - sc_ * H1;
-            (void)sidx; (void)o;
-            const float* zp = b.a1 + (long long)(unit * 16 + sc_) * H1p + oc;
+        for (int i = 0; i < TAIL_ZI; ++i) {
+            // z1 = b1 + the KS K-slice partials of train_fwd1n: branch-free and fully unrolled (clamped addresses, masked
+            // adds) -- as a run-time loop every partial was a load -> wait -> add round trip of its own
+            const int c = c32 + 32 * i;
+            const int cc = c < H1 ? c : H1 - 1;
             float pz[ISK_FWD1_MAXKS];
 #pragma unroll
-            for (int ks = 0; ks < ISK_FWD1_MAXKS; ++ks) pz[ks] = zp[(long long)(ks < b.KS ? ks : 0) * b.zstride];
-            float z = b1[oc];
+            for (int ks = 0; ks < ISK_FWD1_MAXKS; ++ks) pz[ks] = zrow[(long long)(ks < b.KS ? ks : 0) * b.zstride + cc];
+            float z = b1[cc];
 #pragma unroll
             for (int ks = 0; ks < ISK_FWD1_MAXKS; ++ks) z += ks < b.KS ? pz[ks] : 0.f;
-            zv[u] = z;
+            zv[i] = z;
         }
     }
-    // weights and biases of the first TAIL_PF tail layers (deeper tails stage the rest with plain loops below); clamped
-    // addresses instead of predicated loads: every branch around a load is code, and this kernel's size is latency
-    // (a chain of short phases, each starting on instruction-cache misses)
-    constexpr int TAIL_PF = 2;
+    constexpr int TAIL_PF = 2;          // tail layers whose weights / biases are prefetched (deeper tails: plain loops below)
     float wpre[TAIL_PF][TAIL_WU], bpre[TAIL_PF];
 #pragma unroll
     for (int i = 0; i < TAIL_PF; ++i) {
-        const int l = (1 + i < L) ? 1 + i : (L > 1 ? L - 1 : 0);       // a duplicate of the last layer when the tail is shorter
-        const float* Wg = b.theta + s.off_W[l];
-        const int n = s.widths[l + 1] * s.widths[l];
+        const TailLay y = d.lay[i < L ? i : (L > 0 ? L - 1 : 0)];    // a duplicate of the last layer when the tail is shorter
+        const float* Wg = b.theta + y.gW;
 #pragma unroll
-        for (int u = 0; u < TAIL_WU; ++u) { const int e = u * NTH + tid; wpre[i][u] = Wg[e < n ? e : n - 1]; }
-        bpre[i] = b.theta[s.off_b[l] + (tid < s.widths[l + 1] ? tid : 0)];
+        for (int u = 0; u < TAIL_WU; ++u) { const int e = u * NTH + tid; wpre[i][u] = Wg[e < y.nW ? e : (y.nW > 0 ? y.nW - 1 : 0)]; }
+        bpre[i] = b.theta[y.gb + (tid < y.N ? tid : 0)];
     }
-    const float lp_tgt = lp ? b.target[lp_row * nout_ + tid % nout_] : 0.f;
-    const float lp_w = (lp && !b.cot_mode) ? b.lossw[tid % nout_] : 0.f;
-    // stage the tail weights (Flux layout W[o + k*N]) in LDS
-#pragma unroll
-    for (int i = 0; i < TAIL_PF; ++i) {
-        const int l = 1 + i;
-        if (l < L) {
-            float* Wl = sm + tail_off_w(s, l);
-            const float* Wg = b.theta + s.off_W[l];
-            const int n = s.widths[l + 1] * s.widths[l];
-#pragma unroll
-            for (int u = 0; u < TAIL_WU; ++u) { const int e = u * NTH + tid; if (e < n) Wl[e] = wpre[i][u]; }
-            for (int e = TAIL_WU * NTH + tid; e < n; e += NTH) Wl[e] = Wg[e];    // tails beyond 2048 weights per layer
-            float* bl = sm + tail_off_b(s, l);
-            if (tid < s.widths[l + 1]) bl[tid] = bpre[i];
-            for (int e = NTH + tid; e < s.widths[l + 1]; e += NTH) bl[e] = b.theta[s.off_b[l] + e];
-        }
-    }
-    for (int l = 1 + TAIL_PF; l < L; ++l) {                                   // deeper tails: not prefetched
-        float* Wl = sm + tail_off_w(s, l);
-        const float* Wg = b.theta + s.off_W[l];
-        const int n = s.widths[l + 1] * s.widths[l];
-        for (int e = tid; e < n; e += NTH) Wl[e] = Wg[e];
-        float* bl = sm + tail_off_b(s, l);
-        for (int e = tid; e < s.widths[l + 1]; e += NTH) bl[e] = b.theta[s.off_b[l] + e];
-    }
+    const bool lp = c32 < nout;                          // loss phase: thread (r16, c32) owns output c32 of sample r16 (nout <= 32)
+    const float lp_tgt = lp ? b.target[lp_row * nout + c32] : 0.f;
+    const float lp_w = (lp && !b.cot_mode) ? b.lossw[c32] : 0.f;
     // Adam's bias corrections, kept on the device so that a step's launch arguments never change (hipGraph replay):
     // bt[0..1] = beta^t of the coming optimizer step; handed to opt_step in bt[2..3] and advanced at the END of the kernel
-    // (stores only: loaded here with everything else, so no wave waits for them in the middle of a phase)
     const bool bt_owner = b.bt && unit == 0 && tid == 0;
     double bt0 = 0.0, bt1 = 0.0;
     if (bt_owner) { bt0 = b.bt[0]; bt1 = b.bt[1]; }
+    // ---- LDS staging: Z_0 / A_0 (16 x H1), tail weights (Flux layout W[o + k*N]) and biases
     {
         float* A0 = sm;
         float* Z0 = sm + 16 * H1;
-        const int act0 = (L == 1) ? s.lastact : s.act;
-        const float* b1 = b.theta + s.off_b[0];
 #pragma unroll
-        for (int u = 0; u < TAIL_ZU; ++u) {
-            const int e = u * NTH + tid;
-            if (e < 16 * H1) { Z0[e] = zv[u]; A0[e] = t_act(act0, zv[u]); }
+        for (int i = 0; i < TAIL_ZI; ++i) {
+            const int c = c32 + 32 * i;
+            if (c < H1) { Z0[r16 * H1 + c] = zv[i]; A0[r16 * H1 + c] = t_act(d.act0, zv[i]); }
         }
-        for (int e = TAIL_ZU * NTH + tid; e < 16 * H1; e += NTH) {               // first hidden layers wider than 256
-            const int sidx = e / H1, o = e - sidx * H1;
-            const float* zp = b.a1 + (long long)(unit * 16 + sidx) * H1p + o;
-            float z = b1[o];
-            for (int ks = 0; ks < b.KS; ++ks) z += zp[(long long)ks * b.zstride];
-            Z0[e] = z;
-            A0[e] = t_act(act0, z);
+    }
+#pragma unroll
+    for (int i = 0; i < TAIL_PF; ++i) {
+        if (i < L) {
+            const TailLay y = d.lay[i];
+            float* Wl = sm + y.oW;
+#pragma unroll
+            for (int u = 0; u < TAIL_WU; ++u) { const int e = u * NTH + tid; if (e < y.nW) Wl[e] = wpre[i][u]; }
+            for (int e = TAIL_WU * NTH + tid; e < y.nW; e += NTH) Wl[e] = b.theta[y.gW + e];      // > 2048 weights in the layer
+            if (tid < y.N) sm[y.oB + tid] = bpre[i];
+            for (int e = NTH + tid; e < y.N; e += NTH) sm[y.oB + e] = b.theta[y.gb + e];
         }
+    }
+    for (int l = TAIL_PF; l < L; ++l) {                                   // deeper tails: not prefetched
+        const TailLay y = d.lay[l];
+        for (int e = tid; e < y.nW; e += NTH) sm[y.oW + e] = b.theta[y.gW + e];
+        for (int e = tid; e < y.N; e += NTH) sm[y.oB + e] = b.theta[y.gb + e];
     }
     __syncthreads();
     TSTAMP(1);
-    for (int l = 1; l < L; ++l) {
-        const int K = s.widths[l], N = s.widths[l + 1];
-        const float* Ap = sm + tail_off_act(s, l - 1);
-        float* Al = sm + tail_off_act(s, l);
-        float* Zl = Al + 16 * N;
-        const float* Wl = sm + tail_off_w(s, l);
-        const float* bias = sm + tail_off_b(s, l);
-        const int actl = (l == L - 1) ? s.lastact : s.act;
-        // Z_l (16 x N) = A_{l-1} (16 x K) * W_l' on the f32 MFMA: a wave per 16-column tile (the VALU version of this
-        // phase -- 2 LDS reads per multiply-add -- took 4 us of the kernel's 16)
-        // narrow layers (fewer tiles than waves: the C3 tail is ONE tile deep 142) also split the contraction over the
-        // waves, partial tiles meet in LDS
-        const int nsteps = (K + 3) / 4;
-        constexpr int NWV = NTH / 64;
-        const int tiles = (N + 15) / 16;
-        const int ksplit = tiles < NWV ? NWV / tiles : 1;
-        const int spp = (nsteps + ksplit - 1) / ksplit;               // steps per part
-        float* pbuf = sm + tail_off_b(s, L);                          // [NWV][256] partial tiles
-        const float* arow = Ap + li * K;
-        if (l == 1) TSTAMP(6);
-        for (int j = wv; j < tiles * ksplit; j += NWV) {
-            const int t = j / ksplit, part = j - t * ksplit;
+    float* pbuf = sm + d.oP;                                              // [NWV][256] partial tiles
+    // ---- forward through the tail: Z_l (16 x N) = A_{l-1} (16 x K) * W_l' on the f32 MFMA.  A wave per 16-column tile;
+    // narrow layers (fewer tiles than waves: the C3 tail is ONE tile, 142 deep) also split the contraction over the waves
+    for (int l = 0; l < L; ++l) {
+        const TailLay y = d.lay[l];
+        const int K = y.K, N = y.N;
+        const float* arow = sm + y.oAp + li * K;
+        const float* Wl = sm + y.oW;
+        float* Al = sm + y.oA;
+        float* Zl = sm + y.oZ;
+        const float* bias = sm + y.oB;
+        int t = 0, part = wv;                                             // job j = t * ksplit + part, dealt round-robin
+        while (part >= y.ksplit) { part -= y.ksplit; ++t; }
+        for (; t < y.tN;) {
             const int n = 16 * t + li;
             const bool nok = n < N;
             const float* wcol = Wl + (nok ? n : N - 1);
-            int s1 = (part + 1) * spp;
-            if (s1 > nsteps) s1 = nsteps;
-            const f32x4 acc = tail_tile_mma(s1, lq,
+            int s1 = (part + 1) * y.spp;
+            if (s1 > y.nsteps) s1 = y.nsteps;
+            const f32x4 acc = tail_tile_mma(part * y.spp, s1, lq,
                 [&](int k) { const float v = arow[k < K ? k : K - 1]; return k < K ? v : 0.f; },
-                [&](int k) { const float v = wcol[(k < K ? k : K - 1) * N]; return (k < K && nok) ? v : 0.f; }, part * spp);
-            if (ksplit > 1) {
-                *(f32x4*)(pbuf + (wv * 64 + (tid & 63)) * 4) = acc;  // job j runs on wave j (tiles * ksplit <= NWV)
+                [&](int k) { const float v = wcol[(k < K ? k : K - 1) * N]; return (k < K && nok) ? v : 0.f; });
+            if (y.ksplit > 1) {
+                *(f32x4*)(pbuf + (wv * 64 + (tid & 63)) * 4) = acc;      // tN * ksplit <= NWV: job j runs on wave j
             } else if (nok) {
                 const float bn = bias[n];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {                       // accumulator rows 4 lq + r = samples, column n
+                for (int r = 0; r < 4; ++r) {                            // accumulator rows 4 lq + r = samples, column n
                     const float z = acc[r] + bn;
                     Zl[(4 * lq + r) * N + n] = z;
-                    Al[(4 * lq + r) * N + n] = t_act(actl, z);
+                    Al[(4 * lq + r) * N + n] = t_act(y.act, z);
                 }
             }
+            part += NWV;
+            while (part >= y.ksplit) { part -= y.ksplit; ++t; }
         }
-        if (l == 1) TSTAMP(7);
-        if (ksplit > 1) {
+        if (y.ksplit > 1) {
             __syncthreads();
-            if (l == 1) TSTAMP(8);
-            for (int e = tid; e < tiles * 256; e += NTH) {            // element (tile, lane', r) of the accumulator layout
-                const int t = e >> 8, lp_ = (e >> 2) & 63, r = e & 3;
-                const int n = 16 * t + (lp_ & 15), row = 4 * (lp_ >> 4) + r;
+            for (int e = tid; e < y.tN * 256; e += NTH) {                 // element (tile, lane', r) of the accumulator layout
+                const int tt = e >> 8, lp_ = (e >> 2) & 63, r = e & 3;
+                const int n = 16 * tt + (lp_ & 15), row = 4 * (lp_ >> 4) + r;
                 if (n < N) {
                     float z = bias[n];
-                    for (int pp = 0; pp < ksplit; ++pp) z += pbuf[(t * ksplit + pp) * 256 + (e & 255)];
+                    for (int pp = 0; pp < y.ksplit; ++pp) z += pbuf[(tt * y.ksplit + pp) * 256 + (e & 255)];
                     Zl[row * N + n] = z;
-                    Al[row * N + n] = t_act(actl, z);
+                    Al[row * N + n] = t_act(y.act, z);
                 }
             }
-            if (l == 1) TSTAMP(9);
         }
         __syncthreads();
-        if (l == 1) TSTAMP(10);
-        TSTAMP(2);
     }
-    // loss + delta of the last layer (overwrites Z_{L-1})
-    const int nout = s.widths[L];
+    TSTAMP(2);
+    // ---- loss + delta of the last layer (overwrites Z_{L-1}; with no tail layers that is Z_0)
     float lsum = 0.f;
     {
-        float* AL = sm + tail_off_act(s, L - 1);
-        float* ZL = AL + 16 * nout;
-        for (int p = tid; p < 16 * nout; p += NTH) {
-            const int sidx = p / nout, o = p - sidx * nout;
-            const int row = unit * 16 + sidx;
-            const bool valid = row < B;
-            const int rowc = valid ? row : B - 1;
-            const bool first = p < NTH;                    // == tid: prefetched in the prologue
-            const long long prow = first ? lp_row : (perm ? perm[rowc] : rowc);
-            const float tg = first ? lp_tgt : b.target[prow * nout + o];
-            const float out = AL[p];
-            float d = 0.f;
-            if (b.cot_mode) {                              // pullback: delta_L = cotangent .* act'(z_L)
-                if (valid) d = tg * t_dact(s.lastact, ZL[p], out);
-            } else {
-                const float w = first ? lp_w : b.lossw[o];
-                const float r = (out - tg) * w;
-                if (valid) {
-                    lsum += r * r;
-                    d = 2.f * r * w * inv_div * t_dact(s.lastact, ZL[p], out);
+        float* AL = L > 0 ? sm + d.lay[L - 1].oA : sm;
+        float* ZL = L > 0 ? sm + d.lay[L - 1].oZ : sm + 16 * H1;
+        if (nout <= 32) {
+            if (lp) {
+                const int p = r16 * nout + c32;
+                const float out = AL[p];
+                float dl = 0.f;
+                if (b.cot_mode) {                              // pullback: delta_L = cotangent .* act'(z_L)
+                    if (rvalid) dl = lp_tgt * t_dact(d.lastact, ZL[p], out);
+                } else {
+                    const float r = (out - lp_tgt) * lp_w;
+                    if (rvalid) {
+                        lsum += r * r;
+                        dl = 2.f * r * lp_w * inv_div * t_dact(d.lastact, ZL[p], out);
+                    }
                 }
+                ZL[p] = dl;
             }
-            ZL[p] = d;
+        } else {
+            for (int p = tid; p < 16 * nout; p += NTH) {       // wide outputs: the plain loop
+                const int sidx = p / nout, o = p - sidx * nout;
+                const int row = unit * 16 + sidx;
+                const bool valid = row < B;
+                const int rowc = valid ? row : B - 1;
+                const long long prow = perm ? perm[rowc] : rowc;
+                const float tg = b.target[prow * nout + o];
+                const float out = AL[p];
+                float dl = 0.f;
+                if (b.cot_mode) {
+                    if (valid) dl = tg * t_dact(d.lastact, ZL[p], out);
+                } else {
+                    const float w = b.lossw[o];
+                    const float r = (out - tg) * w;
+                    if (valid) {
+                        lsum += r * r;
+                        dl = 2.f * r * w * inv_div * t_dact(d.lastact, ZL[p], out);
+                    }
+                }
+                ZL[p] = dl;
+            }
         }
     }
 #pragma unroll
@@ -549,61 +549,62 @@ __global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TrainShape 
     if ((tid & 63) == 0) lred[tid >> 6] = lsum;
     __syncthreads();
     TSTAMP(3);
-    float* part = b.part + (long long)unit * part_size(s);
+    float* part_out = b.part + (long long)unit * d.PS;
     if (tid == 0) {
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < NTH / 64; ++w) t += lred[w];
-        part[0] = t;
+        for (int w = 0; w < NWV; ++w) t += lred[w];
+        part_out[0] = t;
     }
-    // backward through the tail
-    for (int l = L - 1; l >= 1; --l) {
-        const int K = s.widths[l], N = s.widths[l + 1];
-        float* Ap = sm + tail_off_act(s, l - 1);
-        float* Zp = Ap + 16 * K;
-        const float* Zl = sm + tail_off_act(s, l) + 16 * N;
-        const float* Wl = sm + tail_off_w(s, l);
-        long long poff = 1 + H1;
-        for (int i = 1; i < l; ++i) poff += (long long)s.widths[i + 1] * s.widths[i] + s.widths[i + 1];
-        float* pW = part + poff;
-        float* pb = pW + (long long)N * K;
-        // Both products of the layer as MFMA tile jobs dealt to the waves (they read A_{l-1}, delta_l, W_l and write the
-        // partial dW_l / Z_{l-1}: no barrier between them):
-        //   dW_l (N x K)       = delta_l' (N x 16) * A_{l-1} (16 x K)          jobs [0, tN*tK)
-        //   delta_{l-1} (16xK) = (delta_l (16 x N) * W_l (N x K)) .* act'      jobs [tN*tK, tN*tK + tK)
-        const int tN = (N + 15) / 16, tK = (K + 15) / 16;
-        for (int j = wv; j < tN * tK + tK; j += NTH / 64) {
-            if (j < tN * tK) {
-                const int to = j / tK, tk = j - to * tK;
-                const int o = 16 * to + li, kk = 16 * tk + li;           // A' row index (output), B' column index (input)
-                const bool ook = o < N, kok = kk < K;
-                const int oc = ook ? o : N - 1, kc = kok ? kk : K - 1;
-                const f32x4 acc = tail_tile_mma(4, lq,
+    // ---- backward through the tail.  Both products of a layer as MFMA tile jobs dealt to the waves (they read A_{l-1},
+    // delta_l, W_l and write the partial dW_l / Z_{l-1}: no barrier between them):
+    //   dW_l (N x K)       = delta_l' (N x 16) * A_{l-1} (16 x K)          jobs [0, tN*tK)
+    //   delta_{l-1} (16xK) = (delta_l (16 x N) * W_l (N x K)) .* act'      jobs [tN*tK, tN*tK + tK)
+    for (int l = L - 1; l >= 0; --l) {
+        const TailLay y = d.lay[l];
+        const int K = y.K, N = y.N;
+        const float* Ap = sm + y.oAp;
+        float* Zp = sm + y.oZp;
+        const float* Zl = sm + y.oZ;
+        const float* Wl = sm + y.oW;
+        float* pW = part_out + y.pW;
+        float* pb = part_out + y.pb;
+        const int pact = l > 0 ? d.hidden_act : d.act0;                  // activation that produced A_{l-1}
+        const int njobs = y.tN * y.tK + y.tK;
+        int to = 0, tk = wv;                                             // job (to, tk); to == tN: the delta_{l-1} jobs
+        while (tk >= y.tK) { tk -= y.tK; ++to; }
+        for (int j = wv; j < njobs; j += NWV) {
+            const int kk = 16 * tk + li;                                 // input index of this lane's column
+            const bool kok = kk < K;
+            const int kc = kok ? kk : K - 1;
+            if (to < y.tN) {
+                const int o = 16 * to + li;
+                const bool ook = o < N;
+                const int oc = ook ? o : N - 1;
+                const f32x4 acc = tail_tile_mma(0, 4, lq,
                     [&](int q) { const float v = Zl[q * N + oc]; return ook ? v : 0.f; },
                     [&](int q) { const float v = Ap[q * K + kc]; return kok ? v : 0.f; });
                 if (kok) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {                    // accumulator rows = outputs 16 to + 4 lq + r, column = input kk
+                    for (int r = 0; r < 4; ++r) {                        // accumulator rows = outputs 16 to + 4 lq + r, column = input kk
                         const int oo = 16 * to + 4 * lq + r;
                         if (oo < N) pW[oo + (long long)kk * N] = acc[r];
                     }
                 }
             } else {
-                const int tk = j - tN * tK;
-                const int kk = 16 * tk + li;
-                const bool kok = kk < K;
-                const int kc = kok ? kk : K - 1;
-                const f32x4 acc = tail_tile_mma((N + 3) / 4, lq,
+                const f32x4 acc = tail_tile_mma(0, (N + 3) >> 2, lq,
                     [&](int o) { const float v = Zl[li * N + (o < N ? o : N - 1)]; return o < N ? v : 0.f; },
                     [&](int o) { const float v = Wl[(o < N ? o : N - 1) + kc * N]; return (o < N && kok) ? v : 0.f; });
                 if (kok) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {                    // rows = samples 4 lq + r, column = input kk; in place
+                    for (int r = 0; r < 4; ++r) {                        // rows = samples 4 lq + r, column = input kk; in place
                         const int p = (4 * lq + r) * K + kk;
-                        Zp[p] = acc[r] * t_dact(s.act, Zp[p], Ap[p]);
+                        Zp[p] = acc[r] * t_dact(pact, Zp[p], Ap[p]);
                     }
                 }
             }
+            tk += NWV;
+            while (tk >= y.tK) { tk -= y.tK; ++to; }
         }
         for (int o = tid; o < N; o += NTH) {
             float acc = 0.f;
@@ -612,16 +613,14 @@ __global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TrainShape 
             pb[o] = acc;
         }
         __syncthreads();
-        TSTAMP(4);
     }
-    // delta1 -> global (zero padded), columns in the order train_grad1n loads them: one dwordx4 per row covers FOUR
+    TSTAMP(4);
+    // ---- delta1 -> global (zero padded), columns in the order train_grad1n loads them: one dwordx4 per row covers FOUR
     // output tiles (position 64 q + 4 c + u holds output 16 (4 q + u) + c), see isk_delta1_pos
     {
         const float* Z0 = sm + 16 * H1;
-        for (int e = tid; e < 16 * H1p; e += NTH) {
-            const int sidx = e / H1p, o = e - sidx * H1p;
-            b.delta1[(long long)(unit * 16 + sidx) * H1p + isk_delta1_pos(o, H1p)] = (o < H1) ? Z0[sidx * H1 + o] : 0.f;
-        }
+        float* drow = b.delta1 + (long long)row_g * H1p;
+        for (int c = c32; c < H1p; c += 32) drow[isk_delta1_pos(c, H1p)] = (c < H1) ? Z0[r16 * H1 + c] : 0.f;
     }
     if (bt_owner) {
         b.bt[2] = bt0; b.bt[3] = bt1;
@@ -630,15 +629,44 @@ __global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TrainShape 
     TSTAMP(5);
 }
 
-static size_t tail_lds_bytes(const TrainShape& s) { return ((size_t)tail_off_b(s, s.nlayers) + (TAIL_THREADS / 64) * 256) * sizeof(float); }
+static TailDesc tail_desc(const TrainShape& s, size_t* lds_bytes) {
+    TailDesc d = {};
+    const int L = s.nlayers - 1;
+    d.L = L; d.H1 = s.widths[1]; d.H1p = isk_pad16(s.widths[1]); d.nout = s.widths[s.nlayers];
+    d.act0 = (s.nlayers == 1) ? s.lastact : s.act; d.lastact = s.lastact; d.hidden_act = s.act;
+    d.off_b0 = s.off_b[0]; d.PS = part_size(s);
+    long long poff = 1 + s.widths[1];
+    for (int i = 0; i < L; ++i) {
+        const int l = i + 1;                       // model layer index
+        TailLay& y = d.lay[i];
+        y.K = s.widths[l]; y.N = s.widths[l + 1];
+        y.act = (l == s.nlayers - 1) ? s.lastact : s.act;
+        y.tN = (y.N + 15) / 16; y.tK = (y.K + 15) / 16;
+        y.nsteps = (y.K + 3) / 4;
+        y.ksplit = y.tN < TAIL_THREADS / 64 ? (TAIL_THREADS / 64) / y.tN : 1;
+        if (y.ksplit > y.nsteps) y.ksplit = y.nsteps;
+        y.spp = (y.nsteps + y.ksplit - 1) / y.ksplit;
+        y.oAp = tail_off_act(s, l - 1); y.oZp = y.oAp + 16 * y.K;
+        y.oA = tail_off_act(s, l); y.oZ = y.oA + 16 * y.N;
+        y.oW = tail_off_w(s, l); y.oB = tail_off_b(s, l);
+        y.nW = y.K * y.N;
+        y.gW = s.off_W[l]; y.gb = s.off_b[l];
+        y.pW = poff; y.pb = poff + (long long)y.N * y.K;
+        poff = y.pb + y.N;
+    }
+    d.oP = tail_off_b(s, s.nlayers);
+    *lds_bytes = ((size_t)d.oP + (TAIL_THREADS / 64) * 256) * sizeof(float);
+    return d;
+}
 
 void isk_launch_train_tail(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div,
                            hipStream_t st) {
     const int units = (B + 15) / 16;
-    const size_t lds = tail_lds_bytes(s);
+    size_t lds;
+    const TailDesc d = tail_desc(s, &lds);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)train_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(train_tail_kernel, dim3(units), dim3(TAIL_THREADS), lds, st, s, b, perm, B, inv_div);
+    hipLaunchKernelGGL(train_tail_kernel, dim3(units), dim3(TAIL_THREADS), lds, st, d, b, perm, B, inv_div);
 }
 
 // ------------------------------------------------------------------ train_grad1n -----

@@ -20,6 +20,4 @@ t = np.array(list(buf), dtype=np.int64)
 names = ["prologue loads + LDS staging", "forward layers", "loss + reduce", "backward", "delta1 store"]
 for i, n in enumerate(names):
     print(f"{n:32s} {(t[i + 1] - t[i]) / 100.0:7.2f} us")
-for a, bb, n in [(1, 6, "fwd l=1 setup"), (6, 7, "fwd l=1 mfma jobs"), (7, 8, "barrier"), (8, 9, "reduce+act"), (9, 10, "barrier"), (10, 2, "fwd l=2 (all)")]:
-    print(f"   {n:29s} {(t[bb] - t[a]) / 100.0:7.2f} us")
 print(f"{'total':32s} {(t[5] - t[0]) / 100.0:7.2f} us   shader clock {(t[21] - t[16]) / ((t[5] - t[0]) / 100.0) / 1e3:.2f} GHz")
