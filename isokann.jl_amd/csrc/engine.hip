@@ -130,6 +130,7 @@ struct isk_engine {
     float* d_xscale = nullptr;       // [(N*K + N)] inverse row scales of d_xhat
     float* d_xscale_alt = nullptr;   //             ... of d_xhat_alt
     float* d_xs32 = nullptr;         // [N][Fp] f32 standardised xs rows (training kernels)
+    float* d_xs32_alt = nullptr;     //         the copy the side-stream featurizer writes for the next iteration
     // layered path (networks too wide for the fused kernels): per-layer images and HBM activations
     bool layered = false;
     void* d_W16L[ISK_MAX_LAYERS] = {nullptr};     // bf16 planes per layer (forward_mode 1)
@@ -153,14 +154,19 @@ struct isk_engine {
     // so a training step's launch arguments never change and an epoch can be replayed as ONE hipGraph (train_epoch_graph)
     double* d_bt = nullptr;
     bool bt_dev_valid = false;
-    hipGraphExec_t tg_exec = nullptr;    // the captured epoch: nb x (train_fwd1, train_tail, train_grad1, opt_step, fold)
-    long long tg_bs = 0, tg_nb = 0;
-    int tg_flags = -1;
-    const float* tg_xs = nullptr;        // the xs feature rows the captured launches read (the per-iteration buffer pair swaps)
+    // the captured epoch: nb x (train_fwd1n, train_tail, train_grad1n, opt_step).  TWO slots: with per-iteration
+    // featurization the xs feature rows the launches read alternate between d_xs32 and d_xs32_alt
+    struct TrainGraph {
+        hipGraphExec_t exec = nullptr;
+        long long bs = 0, nb = 0;
+        int flags = -1;
+        const float* xs = nullptr;
+    } tg[2];
     bool tg_disabled = false;
+    hipEvent_t ev_loss = nullptr;        // recorded behind the epoch's loss read-back: the host waits for IT, not for the stream
     // data
     long long N = 0, K = 0, D = 0;
-    float *d_in_xs = nullptr, *d_in_ys = nullptr;   // raw coords / raw features
+    float *d_in_xs = nullptr, *d_in_ys = nullptr;   // raw coords / raw features: ONE allocation, ys rows then xs rows (d_in_xs points inside)
     float* d_xhat = nullptr;                         // CURRENT [(N*K + N)][Fp] buffer: ys rows first, then xs rows
     float* d_xhat_alt = nullptr;                     // the other buffer of the pair (per-iteration featurize mode)
     float* d_out = nullptr;                          // [(N*K + N)][nout]
@@ -207,8 +213,8 @@ static void free_dev(void* p) { if (p) (void)hipFree(p); }
 static void free_data(isk_engine* e) {
     if (e->side) (void)hipStreamSynchronize(e->side);
     e->ys_ahead = false;
-    if (e->tg_exec) { (void)hipGraphExecDestroy(e->tg_exec); e->tg_exec = nullptr; }
-    free_dev(e->d_in_xs); free_dev(e->d_in_ys); free_dev(e->d_xhat); free_dev(e->d_xhat_alt); free_dev(e->d_out); free_dev(e->d_ks);
+    for (auto& g : e->tg) { if (g.exec) (void)hipGraphExecDestroy(g.exec); g = isk_engine::TrainGraph(); }
+    free_dev(e->d_in_ys); free_dev(e->d_xs32_alt); e->d_xs32_alt = nullptr; free_dev(e->d_xhat); free_dev(e->d_xhat_alt); free_dev(e->d_out); free_dev(e->d_ks);
     free_dev(e->d_xscale); free_dev(e->d_xscale_alt); free_dev(e->d_xs32);
     e->d_xscale = e->d_xscale_alt = e->d_xs32 = nullptr;
     free_dev(e->d_target); free_dev(e->d_kw); e->d_kw = nullptr; free_dev(e->d_z1); free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm); free_dev(e->d_isa_work);
@@ -487,7 +493,8 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
         hipStreamCreateWithFlags(&e->copy, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fwd_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_ys_ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_perm, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_perm, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_loss, hipEventDisableTiming) != hipSuccess) {
         isk_destroy(e);
         return fail(ISK_EHIP, "side stream / event creation failed");
     }
@@ -574,6 +581,7 @@ extern "C" void isk_destroy(isk_engine* e) {
     if (e->ev_fwd_done) (void)hipEventDestroy(e->ev_fwd_done);
     if (e->ev_ys_ready) (void)hipEventDestroy(e->ev_ys_ready);
     if (e->ev_perm) (void)hipEventDestroy(e->ev_perm);
+    if (e->ev_loss) (void)hipEventDestroy(e->ev_loss);
     if (e->h_res) (void)hipHostFree(e->h_res);
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->copy) (void)hipStreamDestroy(e->copy);
@@ -591,7 +599,7 @@ extern "C" int isk_set_stream(isk_engine* e, void* s) {
     if (!e) return fail(ISK_EINVAL, "null engine");
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->own_stream) { (void)hipStreamDestroy(e->stream); e->own_stream = false; }
-    if (e->tg_exec) { (void)hipGraphExecDestroy(e->tg_exec); e->tg_exec = nullptr; }
+    for (auto& g : e->tg) { if (g.exec) (void)hipGraphExecDestroy(g.exec); g = isk_engine::TrainGraph(); }
     e->stream = (hipStream_t)s;
     return ISK_OK;
 }
@@ -669,12 +677,12 @@ extern "C" int isk_reset_opt_state(isk_engine* e) {
 // ---------------------------------------------------------------------------------------
 // xscale != nullptr: split-f16 planes (forward_mode 3) with the inverse row scales there; xs32: the same rows in f32 as well
 static void featurize_rows(isk_engine* e, const float* in, long long S, float* xhat, hipStream_t st = nullptr, float* xscale = nullptr,
-                           float* xs32 = nullptr) {
+                           float* xs32 = nullptr, long long x32_first = 0) {
     FeatArgs a = {};
     a.in = in; a.pairs = e->d_pairs; a.packed_pairs = e->d_packed; a.xhat = xhat; a.S = S; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
     a.background = (st != nullptr);
-    a.planes = xscale != nullptr; a.xscale = xscale; a.xhat32 = xs32;
+    a.planes = xscale != nullptr; a.xscale = xscale; a.xhat32 = xs32; a.x32_first = x32_first;
     isk_launch_featurize(a, st ? st : e->stream);
 }
 static float* xs_scale_of(const isk_engine* e, float* xscale) { return xscale ? xscale + e->N * e->K : nullptr; }
@@ -687,14 +695,13 @@ static void featurize_resident(isk_engine* e) {
     if (e->ys_ahead) {
         // the xs rows of the other buffer do not depend on the side stream: featurize them BEFORE waiting for it, so
         // the (un-throttled) xs launch runs under the tail of the throttled ys featurization instead of after it
+        // the side-stream launch covered the ys AND the xs rows (one launch over the contiguous input slab), the f32 xs
+        // copy for the training kernels included: swap the three buffer pairs
         std::swap(e->d_xhat, e->d_xhat_alt);
         std::swap(e->d_xscale, e->d_xscale_alt);
+        std::swap(e->d_xs32, e->d_xs32_alt);
         e->ys_ahead = false;
-        {
-            ScopedTimer t(e, ISK_T_FEATURIZE);
-            featurize_rows(e, e->d_in_xs, e->N, e->d_xhat + (long long)e->N * e->K * e->Fp, nullptr, xs_scale_of(e, e->d_xscale), e->d_xs32);
-        }
-        fold_ahead(e);                  // the weight planes of the coming forward: also ahead of the wait
+        fold_ahead(e);                  // the weight planes of the coming forward (normally already built behind the last epoch)
         (void)hipStreamWaitEvent(e->stream, e->ev_ys_ready, 0);
         return;
     } else {
@@ -729,7 +736,7 @@ static void featurize_ys_ahead(isk_engine* e) {
     (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
     {
         ScopedTimer t(e, ISK_T_FEATURIZE, e->side);
-        featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat_alt, e->side, e->d_xscale_alt);
+        featurize_rows(e, e->d_in_ys, e->N * e->K + e->N, e->d_xhat_alt, e->side, e->d_xscale_alt, e->d_xs32_alt, e->N * e->K);
     }
     (void)hipEventRecord(e->ev_ys_ready, e->side);
     e->ys_ahead = true;
@@ -746,7 +753,7 @@ static void featurize_ys_beside_training(isk_engine* e, long long train_launch_s
     (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
     {
         ScopedTimer t(e, ISK_T_FEATURIZE, e->side);
-        featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat_alt, e->side, e->d_xscale_alt);
+        featurize_rows(e, e->d_in_ys, e->N * e->K + e->N, e->d_xhat_alt, e->side, e->d_xscale_alt, e->d_xs32_alt, e->N * e->K);
     }
     (void)hipEventRecord(e->ev_ys_ready, e->side);
     e->ys_ahead = true;
@@ -773,11 +780,12 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
     const long long S = N * K + N;
     const long long Bpad = ((N + 15) / 16) * 16;
     const int H1p = isk_pad16(e->cfg.widths[1]);
-    HIPCHK(hipMalloc((void**)&e->d_in_xs, (size_t)N * D * sizeof(float)));
-    HIPCHK(hipMalloc((void**)&e->d_in_ys, (size_t)N * K * D * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&e->d_in_ys, (size_t)(N * K + N) * D * sizeof(float)));
+    e->d_in_xs = e->d_in_ys + (size_t)N * K * D;
     HIPCHK(hipMalloc((void**)&e->d_xhat, (size_t)S * e->Fp * sizeof(float)));
     if (e->cfg.featurize_every_iteration) HIPCHK(hipMalloc((void**)&e->d_xhat_alt, (size_t)S * e->Fp * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_xs32, (size_t)N * e->Fp * sizeof(float)));
+    if (e->cfg.featurize_every_iteration) HIPCHK(hipMalloc((void**)&e->d_xs32_alt, (size_t)N * e->Fp * sizeof(float)));
     if (e->planes) {
         HIPCHK(hipMalloc((void**)&e->d_xscale, (size_t)S * sizeof(float)));
         if (e->cfg.featurize_every_iteration) HIPCHK(hipMalloc((void**)&e->d_xscale_alt, (size_t)S * sizeof(float)));
@@ -1773,9 +1781,15 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
     const int nslab = pick_slabs((int)bs);
     const int flags = nslab | (e->ys_ahead ? 0x100 : 0);
     if (!prepare_dev_bt(e)) return false;
-    const float* xs_rows = e->d_xs32;                    // part of the key: set_data re-allocates it
-    if (!e->tg_exec || e->tg_bs != bs || e->tg_nb != nb || e->tg_flags != flags || e->tg_xs != xs_rows) {
-        if (e->tg_exec) { (void)hipGraphExecDestroy(e->tg_exec); e->tg_exec = nullptr; }
+    const float* xs_rows = e->d_xs32;                    // part of the key: the buffer pair swaps every iteration
+    isk_engine::TrainGraph* tg = nullptr;
+    for (auto& g : e->tg)
+        if (g.exec && g.xs == xs_rows) tg = &g;
+    if (!tg) {                                           // a free slot, else the one that does not belong to the other live buffer
+        tg = !e->tg[0].exec ? &e->tg[0] : (!e->tg[1].exec ? &e->tg[1] : (e->tg[0].xs == e->d_xs32_alt ? &e->tg[1] : &e->tg[0]));
+    }
+    if (!tg->exec || tg->bs != bs || tg->nb != nb || tg->flags != flags || tg->xs != xs_rows) {
+        if (tg->exec) { (void)hipGraphExecDestroy(tg->exec); tg->exec = nullptr; }
         const double s1 = e->bt1, s2 = e->bt2;
         if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             (void)hipGetLastError();
@@ -1788,16 +1802,16 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
         }
         hipGraph_t g = nullptr;
         hipError_t r = hipStreamEndCapture(e->stream, &g);
-        if (r == hipSuccess) r = hipGraphInstantiate(&e->tg_exec, g, nullptr, nullptr, 0);
+        if (r == hipSuccess) r = hipGraphInstantiate(&tg->exec, g, nullptr, nullptr, 0);
         if (g) (void)hipGraphDestroy(g);
         if (r != hipSuccess || !e->bt_dev_valid) {       // nothing has run: undo the host-side step bookkeeping
             (void)hipGetLastError();
-            if (e->tg_exec) { (void)hipGraphExecDestroy(e->tg_exec); e->tg_exec = nullptr; }
+            if (tg->exec) { (void)hipGraphExecDestroy(tg->exec); tg->exec = nullptr; }
             e->bt1 = s1; e->bt2 = s2; e->bt_dev_valid = false;
             e->tg_disabled = true;
             return false;
         }
-        e->tg_bs = bs; e->tg_nb = nb; e->tg_flags = flags; e->tg_xs = xs_rows;
+        tg->bs = bs; tg->nb = nb; tg->flags = flags; tg->xs = xs_rows;
     } else {
         // what the launch functions keep track of on the host
         for (long long b = 0; b < nb; ++b) { e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2; }
@@ -1805,7 +1819,7 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
         e->w16_dirty = true;
         e->wt_dirty = true;
     }
-    if (hipGraphLaunch(e->tg_exec, e->stream) != hipSuccess) {
+    if (hipGraphLaunch(tg->exec, e->stream) != hipSuccess) {
         // cannot happen after a successful instantiate; if it does the epoch has not run and the state says so
         (void)hipGetLastError();
         e->tg_disabled = true;
@@ -1815,8 +1829,11 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
     return true;
 }
 
+// fold_behind: the iteration's last epoch -- the forward weight images of the NEXT iteration are rebuilt right behind the
+// loss read-back, i.e. while the host turns around (it waits for the read-back's event, not for the stream)
+static void fold_ahead(isk_engine* e);
 static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, double* loss, int* status_word = nullptr,
-                       bool perm_staged = false) {
+                       bool perm_staged = false, bool fold_behind = false) {
     const long long N = e->N;
     const int mb = minibatch < 0 ? e->cfg.minibatch : minibatch;
     const long long bs = (mb == 0 || N < mb) ? N : mb;          // src/iso.jl:180
@@ -1851,7 +1868,9 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
     double* acc = e->h_res;
     HIPCHK(hipMemcpyAsync(acc, e->d_loss_acc, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     if (status_word) HIPCHK(hipMemcpyAsync(acc + 2, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));                     // also keeps `p` alive until the copy is done
+    HIPCHK(hipEventRecord(e->ev_loss, e->stream));
+    if (fold_behind) fold_ahead(e);
+    HIPCHK(hipEventSynchronize(e->ev_loss));                     // the shuffle order's copy (pinned staging) precedes it on the stream
     HIPCHK(hipGetLastError());
     if (status_word) std::memcpy(status_word, acc + 2, sizeof(int));
     if (acc[1] != 0.0) return fail(ISK_ECOLLAPSED, isk_status_string(ISK_ECOLLAPSED));
@@ -1912,7 +1931,7 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
             double l = 0;
             const int32_t* p = perms ? perms + k * e->N : nullptr;
             int st = 0;
-            int r = train_epoch(e, -1, p, &l, &st, ep == 0);
+            int r = train_epoch(e, -1, p, &l, &st, ep == 0, ep == epochs - 1);
             if (st) {   // the target's DomainError (constant chi / singular simplex) outranks the loss check
                 const int sr = check_status(e);
                 if (sr != ISK_OK) return sr;

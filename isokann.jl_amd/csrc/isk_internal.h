@@ -31,7 +31,8 @@ struct FeatArgs {
     // [Fp/32 chunks][32 x f16 hi | 32 x f16 lo] of xhat * 2^s (same 4*Fp bytes per row), 2^-s goes to xscale[row]
     int planes;
     float* xscale;          // [S] inverse row scales (planes only)
-    float* xhat32;          // optional [S][Fp]: a second copy of the rows, always f32 (the xs rows the training kernels read)
+    float* xhat32;          // optional: a second copy, always f32, of rows >= x32_first at xhat32[(row - x32_first)][Fp] (the xs rows the
+    long long x32_first;    //           training kernels read)
 };
 void isk_launch_featurize(const FeatArgs& a, hipStream_t st);
 bool isk_featurize_reg_ok(const FeatArgs& a);

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeatArgs a) {
                     for (int j = 0; j < 4; ++j) v[j] = (c + j < a.F) ? (v[j] - mu) * rstd : 0.f;
                 }
                 *(f32x4*)(orow + c) = v;
-                if (a.xhat32) *(f32x4*)(a.xhat32 + s * (long long)a.Fp + c) = v;
+                if (a.xhat32 && s >= a.x32_first) *(f32x4*)(a.xhat32 + (s - a.x32_first) * (long long)a.Fp + c) = v;
             }
         }
         __syncthreads();
@@ -279,8 +279,8 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
             for (int pb = 0; pb < NPB; ++pb)
                 isk_raw_buffer_store_f32x2((isk_f32x2){xh[2 * pb], xh[2 * pb + 1]}, ro, (128 * pb + 2 * lane) * 4, 0, FEAT_AUX);
         }
-        if (a.xhat32) {                                      // wave-uniform: a second, f32 copy (the xs rows the training kernels read)
-            const isk_i32x4 r32 = row_rv(a.xhat32, srow, a.Fp, a.Fp);
+        if (a.xhat32 && srow >= a.x32_first) {               // wave-uniform: a second, f32 copy (the xs rows the training kernels read)
+            const isk_i32x4 r32 = row_rv(a.xhat32, srow - a.x32_first, a.Fp, srow < a.S ? a.Fp : 0);
 #pragma unroll
             for (int pb = 0; pb < NPB; ++pb)
                 isk_raw_buffer_store_f32x2((isk_f32x2){xh[2 * pb], xh[2 * pb + 1]}, r32, (128 * pb + 2 * lane) * 4, 0, 0);
