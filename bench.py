@@ -150,8 +150,10 @@ def main():
     nb_rows = (N // bs) * bs
 
     if not use_dp:
-        def step():
-            pkg.run(iso, 1, 1)
+        def step(k=1):
+            # run!(iso, k): k iterations inside the engine, as the reference's users call it -- one host round trip per
+            # iteration for the loss (src/iso.jl:81), no Python between two iterations
+            pkg.run(iso, k, 1)
 
         def sync():
             pkg.capi.check(iso._lib.isk_synchronize(iso._h))
@@ -167,10 +169,10 @@ def main():
         gmb = 0 if args.minibatch == 0 else args.minibatch * world       # fixed per-rank batch
         counts = dp.shard_counts(local, comm)
 
-        def step():
+        def step(k=1):
             # rng=None: the engine draws the shuffle orders itself (seeded), hidden behind the forward, instead of ~0.15 ms of
             # host work between two iterations
-            iso.losses.extend(dp.dp_run(local, comm, 1, 1, gmb, None, counts=counts))
+            iso.losses.extend(dp.dp_run(local, comm, k, 1, gmb, None, counts=counts))
 
         def sync():
             torch.cuda.synchronize()
@@ -192,12 +194,11 @@ def main():
         dist.all_reduce(f, op=dist.ReduceOp.MAX)
         if int(f.item()):
             local._native_agreed = False
-    for _ in range(args.warmup):
-        step()
+    if args.warmup:
+        step(args.warmup)
     sync(); barrier(); sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    step(args.steps)
     sync(); barrier(); sync()
     dt = time.perf_counter() - t0
     if use_dp:
@@ -224,8 +225,7 @@ def main():
     roof = None
     if rank == 0:
         iso.timers(enable=True, reset=True)
-        for _ in range(args.profile_steps):
-            step()
+        step(args.profile_steps)
         sync()
         tm = iso.timers(enable=False)
         ffwd, fwd_flops, step_flops = algorithmic_flops(widths, N, K, nb_rows)

@@ -2303,7 +2303,9 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
             double* acc = e->h_res;
             HIPCHK(hipMemcpyAsync(acc, e->d_loss_acc, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
             HIPCHK(hipMemcpyAsync(acc + 2, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-            HIPCHK(hipStreamSynchronize(e->stream));
+            HIPCHK(hipEventRecord(e->ev_loss, e->stream));
+            if (ep == epochs - 1) fold_ahead(e);         // the next forward's weight images, while the host turns around (see train_epoch)
+            HIPCHK(hipEventSynchronize(e->ev_loss));
             HIPCHK(hipGetLastError());
             int st = 0;
             std::memcpy(&st, acc + 2, sizeof(int));
