@@ -191,6 +191,8 @@ int  isk_batch_grads(isk_engine* e, const float* target, const int32_t* idx, int
 /* ---- run!(iso, n, epochs)   src/iso.jl:72-94 ----------------------------------- */
 /* perms: n*epochs permutations of N (consumed in order) or NULL.  losses: n*epochs. */
 int  isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* perms, double* losses);
+/* iso.minibatch = mb on the reference's mutable Iso (src/iso.jl:10): the batch size isk_run uses from now on (0 = full batch) */
+int  isk_set_minibatch(isk_engine* e, int32_t minibatch);
 
 /* ---- data-parallel hooks (one process per GPU; collectives stay with the host) -- */
 /* local (unreduced) statistics the target needs across shards */

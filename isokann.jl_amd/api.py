@@ -373,7 +373,9 @@ class Iso:
         if target is None:                                                        # src/iso.jl:28-34
             target = TransformShiftscale() if outputdim(self.modelspec) == 1 else TransformISA()
         self.target = target
-        self.minibatch = minibatch
+        self._minibatch = int(minibatch)
+        self.seed, self.forward_mode, self.featurize_every_iteration = int(seed), int(forward_mode), bool(featurize_every_iteration)
+        self.koopman_weights = None
         self.losses: List[float] = []
         self.loggers = list(loggers or [])
         self.nout = outputdim(self.modelspec)
@@ -391,6 +393,17 @@ class Iso:
         xs, ys = data.coords
         d, k, n = ys.shape
         capi.check(self._lib.isk_set_data(self._h, capi.ptr_f32(xs), capi.ptr_f32(ys), d, k, n))
+
+    @property
+    def minibatch(self) -> int:
+        """Iso.minibatch is a mutable field in the reference (src/iso.jl:10): assigning it re-plans the engine's run!()"""
+        return self._minibatch
+
+    @minibatch.setter
+    def minibatch(self, mb: int):
+        self._minibatch = int(mb)
+        if getattr(self, "_h", None):
+            capi.check(self._lib.isk_set_minibatch(self._h, int(mb)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -669,7 +682,11 @@ def save(path: str, iso: Iso) -> None:
              target_kind=type(t).__name__,
              target_args=np.asarray([getattr(t, "permute", True), getattr(t, "whitening", False), getattr(t, "normalize", True),
                                      getattr(t, "direct", True), getattr(t, "eigenvecs", True)]),
-             minibatch=iso.minibatch, losses=np.asarray(iso.losses, np.float64))
+             minibatch=iso.minibatch, losses=np.asarray(iso.losses, np.float64),
+             # engine configuration of this host (no counterpart in the reference's Iso): without it a reloaded Iso would run
+             # another forward arithmetic / featurization mode / shuffle stream
+             seed=iso.seed, forward_mode=iso.forward_mode, featurize_every_iteration=iso.featurize_every_iteration,
+             koopman_weights=np.zeros((0, 0), np.float32) if iso.koopman_weights is None else iso.koopman_weights)
 
 
 def load(path: str, **iso_kwargs) -> Iso:
@@ -689,8 +706,13 @@ def load(path: str, **iso_kwargs) -> Iso:
         target = TransformPseudoInv(bool(ta[2]), bool(ta[3]), bool(ta[4]), bool(ta[0]))
     else:
         target = TransformShiftscale()
+    for k in ("seed", "forward_mode", "featurize_every_iteration"):          # keyword arguments override what the file holds
+        if k in z.files and k not in iso_kwargs:
+            iso_kwargs[k] = z[k].item()
     iso = Iso(SimulationData(z["xs"], z["ys"], feat), opt=opt, model=model, target=target, minibatch=int(z["minibatch"]), **iso_kwargs)
     iso.set_opt_state(z["opt_m"], z["opt_v"], z["opt_bt"])
+    if "koopman_weights" in z.files and z["koopman_weights"].size:
+        set_koopman_weights(iso, np.asarray(z["koopman_weights"]).reshape(-1, order="F"))
     iso.losses = [float(l) for l in z["losses"]]
     return iso
 
@@ -751,6 +773,8 @@ def set_koopman_weights(iso: Iso, weights) -> None:
     """use the weighted expectation (src/data.jl:215) for the resident ys: sum_k w f(y_k) / K; None resets"""
     if weights is None:
         capi.check(iso._lib.isk_set_koopman_weights(iso._h, None, 0, 0))
+        iso.koopman_weights = None
         return
     w = capi.f32(np.asarray(weights).reshape(iso.data.nk, len(iso.data), order="F"))
     capi.check(iso._lib.isk_set_koopman_weights(iso._h, capi.ptr_f32(w), w.shape[0], w.shape[1]))
+    iso.koopman_weights = np.array(w, copy=True)

@@ -97,6 +97,7 @@ PROTOTYPES = {
     "isk_train_batch": (C.c_int, [_H, _f32p, C.c_int32, _i32p, _f64p]),
     "isk_batch_grads": (C.c_int, [_H, _f32p, _i32p, C.c_int32, _f32p, _f64p]),
     "isk_run": (C.c_int, [_H, C.c_int32, C.c_int32, _i32p, _f64p]),
+    "isk_set_minibatch": (C.c_int, [_H, C.c_int32]),
     "isk_dp_koopman_local": (C.c_int, [_H]),
     "isk_dp_minmax_local": (C.c_int, [_H, _f32p]),
     "isk_dp_shiftscale_apply": (C.c_int, [_H, C.c_float, C.c_float]),

@@ -1903,6 +1903,13 @@ extern "C" int isk_batch_grads(isk_engine* e, const float* target, const int32_t
     return ISK_OK;
 }
 
+extern "C" int isk_set_minibatch(isk_engine* e, int32_t minibatch) {
+    if (!e) return fail(ISK_EINVAL, "null engine");
+    if (minibatch < 0) return fail(ISK_EINVAL, "negative minibatch");
+    e->cfg.minibatch = minibatch;
+    return ISK_OK;
+}
+
 extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* perms, double* losses) {
     CHK(need_data(e));
     if (n < 0 || epochs < 0) return fail(ISK_EINVAL, "negative iteration count");

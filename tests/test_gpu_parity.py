@@ -527,6 +527,36 @@ def test_data_slicing_and_reupload(gpu_pkg):
     a.close()
 
 
+@pytest.mark.own_fwd_mode
+def test_minibatch_is_mutable_and_save_load_keeps_the_engine_configuration(gpu_pkg, tmp_path):
+    """Iso.minibatch is a mutable field in the reference (src/iso.jl:10): assigning it changes what run!() does (the engine
+    re-plans its epochs); save / load carry this host's engine configuration (seed, forward mode, per-iteration
+    featurization, Koopman sample weights), so a reloaded Iso continues with the same arithmetic and shuffle stream"""
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 12, 30, 96, 3, 1, seed=8)
+    perms = np.stack([np.random.default_rng(1).permutation(96) for _ in range(2)])
+    a = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(1e-2, 1e-3), minibatch=96)
+    b = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(1e-2, 1e-3), minibatch=24)
+    a.minibatch = 24                                   # run() must now take 4 optimizer steps per epoch, like b
+    pkg.run(a, 2, 1, perms=perms)
+    pkg.run(b, 2, 1, perms=perms)
+    np.testing.assert_array_equal(a.model.get_params(), b.model.get_params())
+    assert a.losses == b.losses
+    a.close(); b.close()
+    rng = np.random.default_rng(3)
+    w = rng.uniform(0.5, 1.5, size=(1, 3, 96))
+    iso = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(1e-2, 1e-3), minibatch=32, seed=11, forward_mode=3,
+                  featurize_every_iteration=True)
+    pkg.set_koopman_weights(iso, w)
+    pkg.run(iso, 2)
+    path = str(tmp_path / "cfg.npz")
+    pkg.save(path, iso)
+    isol = pkg.load(path)
+    assert (isol.seed, isol.forward_mode, isol.featurize_every_iteration) == (11, 3, True)
+    np.testing.assert_array_equal(pkg.koopman(isol), pkg.koopman(iso))          # same weights, same forward arithmetic
+    iso.close(); isol.close()
+
+
 def test_save_load_roundtrip_and_data_growth(gpu_pkg, tmp_path):
     """the reference's own ops test: save / load with coords equality, then keep training
     (test/runtests.jl:69-78); plus mergedata + set_data (src/simulation.jl:162-171)"""
