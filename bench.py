@@ -144,6 +144,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if args.forward_mode == 3 and args.workload == "c5shard":
+        args.forward_mode = 1      # 512-wide layers run on the layered path, where a split-f16 request means the split-bf16 kernels
     iso, c, widths = build_iso(pkg, args.workload, seed=rank, device=local_rank, args=args)
     N, K = c["N"], c["K"]
     bs = N if (args.minibatch == 0 or N < args.minibatch) else args.minibatch

@@ -693,10 +693,16 @@ __device__ __forceinline__ long long part_to_grad(const TrainShape& s, long long
     return -1;
 }
 
+#ifdef ISK_TAIL_STAMP
+#define GSTAMP(k) do { if (blockIdx.x == 5 && blockIdx.y == 0 && threadIdx.x == 0) g_tail_stamps[8 + k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GSTAMP(k) do { } while (0)
+#endif
 template <int NT, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm,
                                                               int B, int nparts) {
     ISK_LATENCY_CHAIN_PRIO();
+    GSTAMP(0);
     constexpr int NB4 = NT / 4, NR = NT % 4;
     constexpr int CB = 4;                          // chunks per batch: their row indices are fetched together
     constexpr int NTH = NW * 64;
@@ -738,6 +744,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(
             if (li == 0 && gi >= 0) gout[gi] = acc;
         }
     }
+    GSTAMP(1);
     f32x4 acc[NT];
     float dsum[NT];
 #pragma unroll
@@ -790,6 +797,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(
             }
         }
     }
+    GSTAMP(2);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         *(f32x4*)(red + ((wave * NT + t) * 64 + lane) * 4) = acc[t];
@@ -813,6 +821,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(
         if (ft == 0 && tid < H1) gout[s.off_b[0] + tid] = d;            // db1 == D (this slab's rows)
     }
     __syncthreads();
+    GSTAMP(3);
     // Epilogue.  Thread tid keeps accumulator slot (lane' = (tid/4) % 64, r = tid % 4) for the tiles t = tid/256 + (NTH/256) i:
     // feature k = 16 ft + 4 (lane'/16) + r, output 16 t + lane'%16.  Element e = 256 t + 4 lane' + r of the workgroup's
     // contiguous share of the (fragment-linear) layer-1 gradient.
@@ -851,6 +860,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(
             gout[(which ? s.off_lnb : s.off_lns) + ft * 16 + kl] = v;
         }
     }
+    GSTAMP(4);
 }
 
 template <int NT, int NW>

@@ -1,11 +1,12 @@
 #!/bin/bash
 # regenerate the committed evidence under profiles/ (run on the GPU box): scripts/refresh_profiles.sh r01
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
 mkdir -p gpurun_out/ref
 b() { name=$1; shift; python3 bench.py "$@" 2> gpurun_out/ref/$name.err | tail -1 > gpurun_out/ref/${tag}_bench_$name.json; python3 -c "
 import json,sys; d=json.load(open('gpurun_out/ref/${tag}_bench_$name.json')); print('$name', round(d['ms_per_step'],3), 'ms', round(d['value']/1e6,1), 'M/s frac', round(d['roofline']['frac'],3))"; }
 b c3
+b c3_bf16x3fwd --forward-mode 1
 b c3_f32fwd --forward-mode 0
 b c3_cached --cached-features
 b c3_mb0 --minibatch 0
@@ -18,5 +19,10 @@ b c3_bf16fwd --forward-mode 2 --no-cpu-baseline
 bash scripts/prof_bench.sh c3stats > gpurun_out/ref/prof.txt 2>&1 || true
 cp gpurun_out/prof_c3stats/c3stats_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c3.csv
 bash scripts/pmc.sh > gpurun_out/ref/pmc.txt 2>&1 || true
-cp gpurun_out/pmc_summary.json gpurun_out/ref/${tag}_pmc_summary.json
+python3 - <<PY
+import json
+d = json.load(open("gpurun_out/pmc_summary.json"))
+d["mlp_fwd_traffic_bytes_per_launch"] = {"f16x2": d["mlp_fwd_traffic_bytes_per_launch"]}     # bench.py looks the forward mode up
+json.dump(d, open("gpurun_out/ref/${tag}_pmc_summary.json", "w"), indent=1)
+PY
 tail -3 gpurun_out/ref/pmc.txt

@@ -20,4 +20,8 @@ t = np.array(list(buf), dtype=np.int64)
 names = ["prologue loads + LDS staging", "forward layers", "loss + reduce", "backward", "delta1 store"]
 for i, n in enumerate(names):
     print(f"{n:32s} {(t[i + 1] - t[i]) / 100.0:7.2f} us")
+g = t[8:13]
+if g[4] > g[0] > 0:
+    for i, n in enumerate(["grad1n: partial-vector reduction", "grad1n: main loop", "grad1n: LDS combine + D", "grad1n: epilogue"]):
+        print(f"{n:36s} {(g[i + 1] - g[i]) / 100.0:7.2f} us")
 print(f"{'total':32s} {(t[5] - t[0]) / 100.0:7.2f} us   shader clock {(t[21] - t[16]) / ((t[5] - t[0]) / 100.0) / 1e3:.2f} GHz")
