@@ -1915,10 +1915,10 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
     if (n < 0 || epochs < 0) return fail(ISK_EINVAL, "negative iteration count");
     long long k = 0;
     for (int it = 0; it < n; ++it) {
-        // launch order = what the GPU can start first: the xs featurization (it runs under the tail of the side-stream ys
-        // featurization) goes out before the host spends ~50 us drawing and staging the epoch's shuffle order
+        // launch order = what the GPU can start first: the forward (and the short target chain behind it) goes out BEFORE
+        // the host spends ~50 us drawing and staging the epoch's shuffle order -- the draw then runs under the forward
+        // instead of in front of it with the GPU idle (the copy is on a stream of its own, the training waits for its event)
         if (e->cfg.featurize_every_iteration) featurize_resident(e);
-        if (epochs > 0) CHK(stage_perm_ahead(e, perms ? perms + k * e->N : nullptr));
         {
             const int mb = e->cfg.minibatch;
             const long long bs = (mb == 0 || e->N < mb) ? e->N : mb;
@@ -1929,6 +1929,7 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
         const int tr = compute_target(e, false, e->cfg.featurize_every_iteration != 0);
         e->side_after_forward = 0;
         CHK(tr);
+        if (epochs > 0) CHK(stage_perm_ahead(e, perms ? perms + k * e->N : nullptr));
         {
             const int mb = e->cfg.minibatch;
             const long long bs = (mb == 0 || e->N < mb) ? e->N : mb;
