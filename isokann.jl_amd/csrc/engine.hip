@@ -125,7 +125,8 @@ struct isk_engine {
     bool w16_dirty = true;
     // forward_mode 3 (split-f16 x2): the featurizer writes pre-split f16 planes + inverse row scales, the xs rows also in f32
     bool planes = false;             // effective: mode 3 requested AND the register featurizer / fused kernels cover the shape
-    unsigned* d_wmax = nullptr;      // scratch word for the weight-tensor maximum
+    unsigned* d_wmax = nullptr;      // [2] weight-tensor maximum of the folded layer-1 image: fold_kernel builds it in one slot and clears the
+    int wmax_par = 0, wmax_last = 0; //     other for the next fold (no memset node), fold_f16 reads the slot of the latest fold
     float* d_wscale = nullptr;       // [1] inverse scale of the weight planes
     float* d_xscale = nullptr;       // [(N*K + N)] inverse row scales of d_xhat
     float* d_xscale_alt = nullptr;   //             ... of d_xhat_alt
@@ -177,7 +178,9 @@ struct isk_engine {
     float *d_z1 = nullptr, *d_delta1 = nullptr, *d_part = nullptr;
     int* d_perm = nullptr;
     hipEvent_t ev_perm = nullptr;   // the shuffle order of the coming epoch was uploaded on the side stream (isk_run)
-    double* h_res = nullptr;     // pinned: [loss sum, collapsed flag] + status word read back once per epoch
+    double* h_res = nullptr;     // pinned + mapped: [loss sum, collapsed flag, status word], published by opt_step (d_hres = its device address)
+    double* d_hres = nullptr;
+    bool loss_acc_zeroed = false; // the K-mean kernel of this iteration already zeroed d_loss_acc
     int* h_perm = nullptr;       // pinned staging for the shuffle order: an async copy from pageable memory waits for the stream
     double* d_At = nullptr;      // host-driven data-parallel ISA: the Float64 simplex inverse (applied in Float64, as on the device path)
     int* d_rowperm = nullptr;
@@ -344,6 +347,10 @@ static void launch_fold(isk_engine* e) {
     FoldArgs a;
     std::memset(&a, 0, sizeof(a));
     a.native = e->native;
+    if (e->planes) {
+        a.wmax = e->d_wmax + e->wmax_par; a.wmax_clear = e->d_wmax + (e->wmax_par ^ 1);
+        e->wmax_last = e->wmax_par; e->wmax_par ^= 1;
+    }
     a.theta = e->d_theta; a.nlayers = e->L;
     for (int l = 0; l < e->L; ++l) a.Kp[l] = layer_kp(e, l);
     for (int i = 0; i <= e->L; ++i) a.widths[i] = e->cfg.widths[i];
@@ -498,12 +505,14 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
         isk_destroy(e);
         return fail(ISK_EHIP, "side stream / event creation failed");
     }
-    if (hipHostMalloc((void**)&e->h_res, 4 * sizeof(double), hipHostMallocDefault) != hipSuccess) { isk_destroy(e); return fail(ISK_ENOMEM, "hipHostMalloc"); }
+    if (hipHostMalloc((void**)&e->h_res, 4 * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&e->d_hres, e->h_res, 0) != hipSuccess) { isk_destroy(e); return fail(ISK_ENOMEM, "hipHostMalloc (mapped)"); }
     const size_t pb = (size_t)(e->nparams + 2) * sizeof(float);
     ALLOC(e->d_theta, pb); ALLOC(e->d_grad, pb * ISK_MAX_SLABS); ALLOC(e->d_m, pb); ALLOC(e->d_v, pb);
     ALLOC(e->d_loss_acc, 2 * sizeof(double)); ALLOC(e->d_status, sizeof(int)); ALLOC(e->d_mm, 2 * sizeof(float));
     ALLOC(e->d_bt, 4 * sizeof(double));
-    ALLOC(e->d_wmax, sizeof(unsigned)); ALLOC(e->d_wscale, sizeof(float));
+    ALLOC(e->d_wmax, 2 * sizeof(unsigned)); ALLOC(e->d_wscale, sizeof(float));
+    (void)hipMemset(e->d_wmax, 0, 2 * sizeof(unsigned));
     ALLOC(e->d_lossw, (size_t)nout * sizeof(float));
     ALLOC(e->d_At, (size_t)nout * nout * sizeof(double)); ALLOC(e->d_rowperm, (size_t)nout * sizeof(int));
     ALLOC(e->d_W16, (size_t)isk_bf16_chunks(e->Fp) * 32 * isk_pad16(cfg->widths[1]) * 3 * sizeof(uint16_t));
@@ -946,7 +955,7 @@ static void fold_ahead(isk_engine* e) {
     ensure_folded(e);
     const int planes = bf16_planes(e);
     if (e->layered || !(planes || e->planes) || !e->w16_dirty) return;
-    if (e->planes) isk_launch_fold_f16(e->d_Wt[0], e->d_W16, e->Fp, isk_pad16(e->cfg.widths[1]) / 16, e->d_wmax, e->d_wscale, e->stream);
+    if (e->planes) isk_launch_fold_f16(e->d_Wt[0], e->d_W16, e->Fp, isk_pad16(e->cfg.widths[1]) / 16, e->d_wmax + e->wmax_last, e->d_wscale, e->stream);
     else isk_launch_fold_bf16(e->d_Wt[0], e->d_W16, e->Fp, isk_pad16(e->cfg.widths[1]) / 16, planes, e->stream);
     e->w16_dirty = false;
 }
@@ -1108,7 +1117,9 @@ static int forward_resident(isk_engine* e, int which, bool ahead = false) {
 static void launch_kmean(isk_engine* e) {
     KmeanArgs k;
     k.out_ys = e->d_out; k.ks = e->d_ks; k.w = e->d_kw; k.N = e->N; k.K = (int)e->K; k.nout = e->nout;
+    k.zero2 = e->d_loss_acc;             // the coming epoch's loss accumulator: zeroed here instead of by a memset node of its own
     isk_launch_kmean(k, e->stream);
+    e->loss_acc_zeroed = true;
     e->have_ks = true;
 }
 
@@ -1389,7 +1400,7 @@ static int koopman_cols(isk_engine* e, const float* ys, int64_t D, int64_t K, in
     f.xscale = (const float*)xsc.p;
     if (launch_forward(e, f) != 0) return fail(ISK_EUNSUPPORTED, "model shape not covered by the forward kernel");
     KmeanArgs k;
-    k.out_ys = (const float*)o.p; k.ks = (float*)ks.p; k.w = nullptr; k.N = ncols; k.K = (int)K; k.nout = e->nout;
+    k.out_ys = (const float*)o.p; k.ks = (float*)ks.p; k.w = nullptr; k.N = ncols; k.K = (int)K; k.nout = e->nout; k.zero2 = nullptr;
     isk_launch_kmean(k, e->stream);
     HIPCHK(hipMemcpyAsync(out_host, ks.p, (size_t)ncols * e->nout * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1730,9 +1741,11 @@ static void launch_opt(isk_engine* e, float gscale, bool fold = true, bool captu
     (void)capturing;
     a.bt = dev ? e->d_bt + 2 : nullptr;
     a.gscale = gscale; a.loss_acc = e->d_loss_acc;
+    a.host_pub = e->d_hres; a.status = e->d_status;
     a.nslab = e->last_nslab;
     a.slab_prefix = e->off_b[0] + e->cfg.widths[1];          // [LN | W1 | b1]: the blocks train_grad1n writes per row slab
     isk_launch_opt_step(a, e->stream);
+    e->loss_acc_zeroed = false;
     e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2;
     if (!dev) e->bt_dev_valid = false;           // this step advanced only the host copy
     if (e->native) { e->wt_dirty = true; e->w16_dirty = true; }      // the training steps read theta; forwards re-fold on demand
@@ -1818,6 +1831,7 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
         e->last_nslab = nslab;
         e->w16_dirty = true;
         e->wt_dirty = true;
+        e->loss_acc_zeroed = false;
     }
     if (hipGraphLaunch(tg->exec, e->stream) != hipSuccess) {
         // cannot happen after a successful instantiate; if it does the epoch has not run and the state says so
@@ -1853,7 +1867,8 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
         std::memcpy(e->h_perm, perm, (size_t)N * sizeof(int));      // the previous epoch's copy completed before its final sync
         HIPCHK(hipMemcpyAsync(e->d_perm, e->h_perm, (size_t)N * sizeof(int), hipMemcpyHostToDevice, e->stream));
     }
-    HIPCHK(hipMemsetAsync(e->d_loss_acc, 0, 2 * sizeof(double), e->stream));
+    if (!e->loss_acc_zeroed) HIPCHK(hipMemsetAsync(e->d_loss_acc, 0, 2 * sizeof(double), e->stream));
+    e->loss_acc_zeroed = false;
     {
         ScopedTimer t(e, ISK_T_TRAIN);
         const bool lazy_fold = e->layered && !e->cfg.layernorm && blas_ready(e);
@@ -1865,9 +1880,12 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
         }
     }
     // one round trip per epoch: loss, collapse flag and (for isk_run) the target's status word, into pinned memory
+    // loss, collapse flag and the target's status word were published into mapped pinned memory by the last opt_step
     double* acc = e->h_res;
-    HIPCHK(hipMemcpyAsync(acc, e->d_loss_acc, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    if (status_word) HIPCHK(hipMemcpyAsync(acc + 2, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    if (nb < 1) {                        // no optimizer step ran (cannot happen: bs <= N), keep the read-back well defined
+        HIPCHK(hipMemcpyAsync(acc, e->d_loss_acc, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(acc + 2, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    }
     HIPCHK(hipEventRecord(e->ev_loss, e->stream));
     if (fold_behind) fold_ahead(e);
     HIPCHK(hipEventSynchronize(e->ev_loss));                     // the shuffle order's copy (pinned staging) precedes it on the stream
@@ -2299,7 +2317,8 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
                 std::memcpy(e->h_perm, p, (size_t)e->N * sizeof(int));     // validated before the first collective
                 HIPCHK(hipMemcpyAsync(e->d_perm, e->h_perm, (size_t)e->N * sizeof(int), hipMemcpyHostToDevice, e->stream));
             }
-            HIPCHK(hipMemsetAsync(e->d_loss_acc, 0, 2 * sizeof(double), e->stream));
+            if (!e->loss_acc_zeroed) HIPCHK(hipMemsetAsync(e->d_loss_acc, 0, 2 * sizeof(double), e->stream));
+            e->loss_acc_zeroed = false;
             {
                 ScopedTimer t(e, ISK_T_TRAIN);
                 for (int b = 0; b < nbatches; ++b) {
@@ -2308,9 +2327,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
                     launch_opt(e, 1.0f);
                 }
             }
-            double* acc = e->h_res;
-            HIPCHK(hipMemcpyAsync(acc, e->d_loss_acc, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-            HIPCHK(hipMemcpyAsync(acc + 2, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+            double* acc = e->h_res;          // published by the last opt_step (mapped pinned memory)
             HIPCHK(hipEventRecord(e->ev_loss, e->stream));
             if (ep == epochs - 1) fold_ahead(e);         // the next forward's weight images, while the host turns around (see train_epoch)
             HIPCHK(hipEventSynchronize(e->ev_loss));

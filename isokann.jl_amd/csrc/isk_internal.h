@@ -92,8 +92,8 @@ void isk_launch_fold_bf16(const float* Wt, void* out, int Kp, int nt, int planes
 // split-f16 variant (forward_mode 3): W16 = two scaled f16 planes from isk_launch_fold_f16, samples pre-split by the featurizer
 int  isk_launch_mlp_fwd_f16x2(const MlpFwdArgs& a, const void* W16, hipStream_t st);
 int  isk_mlp_fwd_f16x2_fits(const MlpFwdArgs& a);   // 1 when the shape's LDS footprint fits the split-f16 kernel (a.xscale / a.wscale set)
-// wmax: one zero-initialised word (scratch for the tensor maximum), wscale_inv[0] <- inverse scale of the planes
-void isk_launch_fold_f16(const float* Wt, void* out, int Kp, int nt, unsigned* wmax, float* wscale_inv, hipStream_t st);
+// wmax: the tensor maximum max |Wt| as float bits (built by fold_kernel), wscale_inv[0] <- inverse scale of the planes
+void isk_launch_fold_f16(const float* Wt, void* out, int Kp, int nt, const unsigned* wmax, float* wscale_inv, hipStream_t st);
 #define ISK_MAX_NT_BF16 16   // output tiles per workgroup of the plain-bf16 forward
 int  isk_bf16_chunks(int Kp);     // 32-feature chunks in the plane image (padded to the kernel's ring size)
 
@@ -134,6 +134,8 @@ struct FoldArgs {
     float* bias[ISK_MAX_LAYERS];          // padded per layer (layer 0: folded)
     double* bt; double beta1, beta2;      // optional: advance the device copy of [beta1^t, beta2^t] (one thread; see OptArgs)
     int native;                           // 1: theta is in the fused path's engine layout (layer 0 fragment-linear, LayerNorm blocks padded)
+    unsigned* wmax;                       // optional (native): max |W1g| of the folded layer-1 image as float bits, built with one atomic per
+    unsigned* wmax_clear;                 //   workgroup; the OTHER slot is cleared for the next fold (forward_mode 3: scale of the f16 planes)
 };
 void isk_launch_fold(const FoldArgs& a, hipStream_t st);
 
@@ -143,6 +145,7 @@ struct KmeanArgs {
     float* ks;              // [N][nout]
     const float* w;         // optional [N][K] sample weights (WeightedSamples / Girsanov): sum_k w*f / K
     long long N; int K, nout;
+    double* zero2;          // optional: two doubles zeroed by the first thread (the coming epoch's loss accumulator: saves a memset node)
 };
 void isk_launch_kmean(const KmeanArgs& a, hipStream_t st);
 void isk_launch_minmax(const float* v, long long n, float* mm /*[2] device*/, hipStream_t st);
@@ -234,6 +237,8 @@ struct OptArgs {
     int nslab; long long slab_prefix;   // gradient slabs to sum for parameter indices < slab_prefix
     float gscale;           // gradient multiplier (1, or 1/global_batch in data-parallel mode)
     const double* loss_acc; // collapsed flag at [1]: skip the update when set (src/iso.jl:186-189 throws before update!)
+    double* host_pub;       // optional device pointer to MAPPED pinned host memory: [loss sum, collapsed flag, status word]
+    const int* status;      //          the target's status word published with them
 };
 void isk_launch_opt_step(const OptArgs& a, hipStream_t st);
 

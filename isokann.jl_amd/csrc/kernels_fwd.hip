@@ -407,10 +407,21 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldArgs a) {
         const int t0 = threadIdx.x;
         if ((int)blockIdx.x < nch0) {
             const int c = blockIdx.x;
+            float m = 0.f;
             for (int idx = t0; idx < nt0 * 256; idx += 256) {
                 const int j = idx & 3, ln_ = (idx >> 2) & 63;
                 const long long e = (long long)c * nt0 * 256 + idx;
-                a.Wt[0][e] = W[e] * (ln0 ? a.theta[a.off_lns + c * 16 + 4 * (ln_ >> 4) + j] : 1.f);
+                const float w = W[e] * (ln0 ? a.theta[a.off_lns + c * 16 + 4 * (ln_ >> 4) + j] : 1.f);
+                a.Wt[0][e] = w;
+                m = fmaxf(m, fabsf(w));
+            }
+            if (a.wmax) {                                   // tensor maximum for the f16 plane scale: one atomic per workgroup
+                if (c == 0 && t0 == 0) a.wmax_clear[0] = 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
+                if ((t0 & 63) == 0) tile[t0 >> 6] = m;
+                __syncthreads();
+                if (t0 == 0) atomicMax(a.wmax, __builtin_bit_cast(unsigned, fmaxf(fmaxf(tile[0], tile[1]), fmaxf(tile[2], tile[3]))));
             }
             return;
         }
@@ -664,6 +675,7 @@ __global__ __launch_bounds__(256) void kmean_kernel(KmeanArgs a) {
     ISK_LATENCY_CHAIN_PRIO();
     const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    if (a.zero2 && blockIdx.x == 0 && threadIdx.x == 0) { a.zero2[0] = 0.0; a.zero2[1] = 0.0; }
     if (n >= a.N) return;
     const float* base = a.out_ys + n * (long long)a.K * a.nout;
     const float* w = a.w ? a.w + n * (long long)a.K : nullptr;

@@ -33,30 +33,10 @@ __global__ __launch_bounds__(256) void fold_bf16_kernel(const float* __restrict_
 }
 
 // split-f16 x2 weight planes (forward_mode 3): fp32 fragment-linear [chunk16][nt][64][4] -> f16 [chunk32][2][nt][64][8],
-// every weight scaled by the power of two that brings the tensor maximum into [2^14, 2^15) (isk_f16_scale):
+// every weight scaled by the power of two that brings the tensor maximum (from fold_kernel) into [2^14, 2^15) (isk_f16_scale):
 //   hi = f16(w 2^s), lo = f16(w 2^s - hi);   wscale_inv[0] = 2^-s for the forward epilogue
-__global__ __launch_bounds__(1024) void wmax_kernel(const float* __restrict__ Wt, long long n4, unsigned* __restrict__ slot) {
-    // one atomic per workgroup: a thousand same-address atomics cost ~12 ns each, serialised (measured 13.7 us with one per wave)
-    __shared__ float red[16];
-    const f32x4* W4 = (const f32x4*)Wt;
-    float m = 0.f;
-    for (long long e = (long long)blockIdx.x * 1024 + threadIdx.x; e < n4; e += (long long)gridDim.x * 1024) {
-        const f32x4 v = W4[e];
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
-        atomicMax(slot, __builtin_bit_cast(unsigned, m));     // non-negative floats order like their bit patterns
-    }
-}
-
 __global__ __launch_bounds__(256) void fold_f16_kernel(const float* __restrict__ Wt, _Float16* __restrict__ out, int nchunk32, int nt,
-                                                       int nchunk16, unsigned* __restrict__ wmax, float* __restrict__ wscale_inv) {
+                                                       int nchunk16, const unsigned* __restrict__ wmax, float* __restrict__ wscale_inv) {
     float sc, inv;
     isk_f16_scale(__builtin_bit_cast(float, wmax[0]), sc, inv);
     if (blockIdx.x == 0 && threadIdx.x == 0) wscale_inv[0] = inv;
@@ -80,13 +60,8 @@ __global__ __launch_bounds__(256) void fold_f16_kernel(const float* __restrict__
     }
 }
 
-void isk_launch_fold_f16(const float* Wt, void* out, int Kp, int nt, unsigned* wmax, float* wscale_inv, hipStream_t st) {
+void isk_launch_fold_f16(const float* Wt, void* out, int Kp, int nt, const unsigned* wmax, float* wscale_inv, hipStream_t st) {
     const int nchunk32 = isk_bf16_chunks(Kp), nchunk16 = Kp / 16;
-    const long long nw = (long long)nchunk16 * nt * 256;
-    (void)hipMemsetAsync(wmax, 0, sizeof(unsigned), st);
-    int mb = (int)((nw / 4 + 1023) / 1024);              // the image is a whole number of 1 KiB fragments
-    if (mb > 64) mb = 64;
-    hipLaunchKernelGGL(wmax_kernel, dim3(mb), dim3(1024), 0, st, Wt, nw / 4, wmax);
     const long long total = (long long)nchunk32 * nt * 64 * 8;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;

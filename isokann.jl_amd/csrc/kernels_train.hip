@@ -895,8 +895,16 @@ __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a, double* loss_a
     const float lstep = a.grad[a.n];
     const bool bad = (loss_acc[1] != 0.0) || !isfinite(lstep);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double acc0 = loss_acc[0];
         if (bad) loss_acc[1] = 1.0;
-        else loss_acc[0] += (double)lstep;
+        else { acc0 += (double)lstep; loss_acc[0] = acc0; }
+        if (a.host_pub) {
+            // the epoch's result goes to the host as three stores into mapped pinned memory (every step publishes, the last
+            // one counts): no copy kernels behind the epoch, the host only waits for an event
+            a.host_pub[0] = acc0;
+            a.host_pub[1] = bad ? 1.0 : 0.0;
+            ((int*)(a.host_pub + 2))[0] = a.status ? a.status[0] : 0;
+        }
     }
     if (bad) return;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
