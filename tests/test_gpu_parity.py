@@ -235,6 +235,9 @@ def test_nan_model_isa_raises_domain_error(gpu_pkg, nout, N):
     ([33, 100, 20, 9, 2], True, "tanh", 64),
     ([20, 4], True, "sigmoid", 16),
     ([24, 9, 2], True, "swish", 33),
+    ([64, 160, 12, 3], True, "sigmoid", 48),            # widest fused first layer: two groups of five output tiles in train_fwd1n
+    ([40, 24, 50, 30, 20, 40], True, "tanh", 37),       # four tail layers (two beyond the prefetched ones), 40 outputs (> 32: plain loss loop)
+    ([300, 70, 8, 2], False, "relu", 128),              # 19 feature chunks: K slices of unequal length, no LayerNorm
 ])
 def test_batch_gradients(gpu_pkg, widths, ln, act, B):
     pkg = gpu_pkg
@@ -245,7 +248,7 @@ def test_batch_gradients(gpu_pkg, widths, ln, act, B):
     ys = rng.normal(size=(widths[0], 2, N)) + 1.0
     nout = widths[-1]
     tgt = np.asarray(rng.uniform(size=(nout, N)), np.float32)
-    tr = pkg.TransformShiftscale() if nout == 1 else pkg.TransformISA()
+    tr = pkg.TransformShiftscale() if nout == 1 else (pkg.TransformISA() if nout <= 8 else pkg.TransformPseudoInv())
     iso = pkg.Iso(pkg.SimulationData(xs, ys), model=_mk_model(pkg, om), target=tr, minibatch=0)
     idx = rng.permutation(N)[:B]
     g, l = pkg.batch_grads(iso, tgt, idx)
