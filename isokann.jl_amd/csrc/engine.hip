@@ -509,7 +509,8 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
         hipHostGetDevicePointer((void**)&e->d_hres, e->h_res, 0) != hipSuccess) { isk_destroy(e); return fail(ISK_ENOMEM, "hipHostMalloc (mapped)"); }
     const size_t pb = (size_t)(e->nparams + 2) * sizeof(float);
     ALLOC(e->d_theta, pb); ALLOC(e->d_grad, pb * ISK_MAX_SLABS); ALLOC(e->d_m, pb); ALLOC(e->d_v, pb);
-    ALLOC(e->d_loss_acc, 2 * sizeof(double)); ALLOC(e->d_status, sizeof(int)); ALLOC(e->d_mm, 2 * sizeof(float));
+    ALLOC(e->d_loss_acc, 4 * sizeof(double)); ALLOC(e->d_mm, 2 * sizeof(float));
+    e->d_status = (int*)(e->d_loss_acc + 2);         // the target's status word lives behind the loss accumulator (opt_step publishes both)
     ALLOC(e->d_bt, 4 * sizeof(double));
     ALLOC(e->d_wmax, 2 * sizeof(unsigned)); ALLOC(e->d_wscale, sizeof(float));
     (void)hipMemset(e->d_wmax, 0, 2 * sizeof(unsigned));
@@ -556,7 +557,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     }
     (void)hipMemset(e->d_theta, 0, pb); (void)hipMemset(e->d_grad, 0, pb * ISK_MAX_SLABS);
     (void)hipMemset(e->d_m, 0, pb); (void)hipMemset(e->d_v, 0, pb);
-    (void)hipMemset(e->d_loss_acc, 0, 2 * sizeof(double)); (void)hipMemset(e->d_status, 0, sizeof(int));
+    (void)hipMemset(e->d_loss_acc, 0, 4 * sizeof(double));
     std::vector<float> ones(nout, 1.0f);
     (void)hipMemcpy(e->d_lossw, ones.data(), nout * sizeof(float), hipMemcpyHostToDevice);
     launch_fold(e);
@@ -576,7 +577,7 @@ extern "C" void isk_destroy(isk_engine* e) {
     if (e->copy) (void)hipStreamSynchronize(e->copy);
     free_data(e);
     free_dev(e->d_theta); free_dev(e->d_grad); free_dev(e->d_m); free_dev(e->d_v); free_dev(e->d_bt);
-    free_dev(e->d_loss_acc); free_dev(e->d_status); free_dev(e->d_mm); free_dev(e->d_lossw);
+    free_dev(e->d_loss_acc); free_dev(e->d_mm); free_dev(e->d_lossw);
     free_dev(e->d_At); free_dev(e->d_rowperm); free_dev(e->d_pairs); free_dev(e->d_packed); free_dev(e->d_isa_work_dp);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_Wt[l]); free_dev(e->d_bias[l]); }
     free_dev(e->d_W16); free_dev(e->d_wmax); free_dev(e->d_wscale);
@@ -1730,7 +1731,9 @@ static void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, 
 // fold: refresh the weight images the forward / training kernels read.  The rocBLAS variant of the layered training
 // path reads theta itself (only layer 0's folded bias comes from an image, and only with LayerNorm), so inside an
 // epoch it skips the refresh and folds once at the end.
-static void launch_opt(isk_engine* e, float gscale, bool fold = true, bool capturing = false) {
+// publish: this is the epoch's LAST step -- it writes the result into mapped pinned host memory (a kernel ends only when its
+// stores are acknowledged: publishing from every step cost ~2 us per step, 0.2 ms per iteration at minibatch = 100)
+static void launch_opt(isk_engine* e, float gscale, bool fold = true, bool capturing = false, bool publish = true) {
     OptArgs a;
     a.theta = e->d_theta; a.grad = e->d_grad; a.m = e->d_m; a.v = e->d_v; a.n = e->nparams;
     a.kind = e->cfg.opt_kind; a.lr = e->cfg.lr; a.reg = e->cfg.reg; a.beta1 = e->cfg.beta1; a.beta2 = e->cfg.beta2;
@@ -1741,7 +1744,7 @@ static void launch_opt(isk_engine* e, float gscale, bool fold = true, bool captu
     (void)capturing;
     a.bt = dev ? e->d_bt + 2 : nullptr;
     a.gscale = gscale; a.loss_acc = e->d_loss_acc;
-    a.host_pub = e->d_hres; a.status = e->d_status;
+    a.host_pub = publish ? e->d_hres : nullptr;
     a.nslab = e->last_nslab;
     a.slab_prefix = e->off_b[0] + e->cfg.widths[1];          // [LN | W1 | b1]: the blocks train_grad1n writes per row slab
     isk_launch_opt_step(a, e->stream);
@@ -1811,7 +1814,7 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
         }
         for (long long b = 0; b < nb; ++b) {
             launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, nslab, true, true);
-            launch_opt(e, 1.0f, true, true);
+            launch_opt(e, 1.0f, true, true, b == nb - 1);
         }
         hipGraph_t g = nullptr;
         hipError_t r = hipStreamEndCapture(e->stream, &g);
@@ -1846,8 +1849,21 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
 // fold_behind: the iteration's last epoch -- the forward weight images of the NEXT iteration are rebuilt right behind the
 // loss read-back, i.e. while the host turns around (it waits for the read-back's event, not for the stream)
 static void fold_ahead(isk_engine* e);
+// the host side of an epoch's end: wait for the event behind its last optimizer step, then read what that step published
+static int finish_epoch(isk_engine* e, double* loss, int* status_word) {
+    HIPCHK(hipEventSynchronize(e->ev_loss));                     // the shuffle order's copy (pinned staging) precedes it on the stream
+    HIPCHK(hipGetLastError());
+    const double* acc = e->h_res;
+    if (status_word) std::memcpy(status_word, acc + 2, sizeof(int));
+    if (acc[1] != 0.0) return fail(ISK_ECOLLAPSED, isk_status_string(ISK_ECOLLAPSED));
+    if (loss) *loss = acc[0] / (double)e->N;                     // src/iso.jl:193
+    return ISK_OK;
+}
+
+// defer: return as soon as the epoch is enqueued; the caller collects its result with finish_epoch (isk_run does so after
+// it has launched the NEXT iteration's forward, so the host's turn-around runs under that kernel)
 static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, double* loss, int* status_word = nullptr,
-                       bool perm_staged = false, bool fold_behind = false) {
+                       bool perm_staged = false, bool fold_behind = false, bool defer = false) {
     const long long N = e->N;
     const int mb = minibatch < 0 ? e->cfg.minibatch : minibatch;
     const long long bs = (mb == 0 || N < mb) ? N : mb;          // src/iso.jl:180
@@ -1875,7 +1891,7 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
         if (!train_epoch_graph(e, bs, nb)) {
             for (long long b = 0; b < nb; ++b) {
                 launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, pick_slabs((int)bs));
-                launch_opt(e, 1.0f, !lazy_fold || b == nb - 1);
+                launch_opt(e, 1.0f, !lazy_fold || b == nb - 1, false, b == nb - 1);
             }
         }
     }
@@ -1888,12 +1904,8 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
     }
     HIPCHK(hipEventRecord(e->ev_loss, e->stream));
     if (fold_behind) fold_ahead(e);
-    HIPCHK(hipEventSynchronize(e->ev_loss));                     // the shuffle order's copy (pinned staging) precedes it on the stream
-    HIPCHK(hipGetLastError());
-    if (status_word) std::memcpy(status_word, acc + 2, sizeof(int));
-    if (acc[1] != 0.0) return fail(ISK_ECOLLAPSED, isk_status_string(ISK_ECOLLAPSED));
-    if (loss) *loss = acc[0] / (double)N;                        // src/iso.jl:193
-    return ISK_OK;
+    if (defer) return ISK_OK;
+    return finish_epoch(e, loss, status_word);
 }
 
 extern "C" int isk_train_batch(isk_engine* e, const float* target, int32_t minibatch, const int32_t* perm, double* loss) {
@@ -1956,6 +1968,8 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
         for (int ep = 0; ep < epochs; ++ep) {
             double l = 0;
             const int32_t* p = perms ? perms + k * e->N : nullptr;
+            // (collecting an iteration's loss only after the NEXT iteration's forward has been launched -- so that the host's
+            // turn-around runs under that kernel -- was built and measured: +-0 at minibatch 1000, 5 % SLOWER at minibatch 100)
             int st = 0;
             int r = train_epoch(e, -1, p, &l, &st, ep == 0, ep == epochs - 1);
             if (st) {   // the target's DomainError (constant chi / singular simplex) outranks the loss check
@@ -2324,7 +2338,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
                 for (int b = 0; b < nbatches; ++b) {
                     launch_grads(e, e->d_perm + (long long)b * local_batch, local_batch, 1.0f / (float)global_batch, nslab);
                     if (coll) RCCLCHK(g_rccl.AllReduce(e->d_grad, e->d_grad, red_count, ncclFloat, ncclSum, e->comm, e->stream));
-                    launch_opt(e, 1.0f);
+                    launch_opt(e, 1.0f, true, false, b == nbatches - 1);
                 }
             }
             double* acc = e->h_res;          // published by the last opt_step (mapped pinned memory)

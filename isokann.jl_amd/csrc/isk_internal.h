@@ -227,18 +227,19 @@ void isk_launch_train_grad1n(const TrainShape& s, const TrainBuffers& b, const i
 int  isk_train_tail_nblocks(int B);
 long long isk_train_part_floats(const TrainShape& s, int maxB);
 
-struct OptArgs {
+struct OptArgs {            // <= 128 bytes: a third 64-byte kernarg line cost 2.7 us per optimizer step (measured at minibatch = 100)
     float* theta; const float* grad; float* m; float* v;
-    long long n;
-    int kind; float lr, reg, beta1, beta2, eps, rho;
-    float bc1, bc2;         // 1 - beta1^t, 1 - beta2^t for this step
     const double* bt;       // optional: device [beta1^t, beta2^t] of THIS step (then bc1/bc2 are derived from it, so the launch
                             // arguments do not change from step to step and the epoch can be replayed as a hipGraph)
-    int nslab; long long slab_prefix;   // gradient slabs to sum for parameter indices < slab_prefix
-    float gscale;           // gradient multiplier (1, or 1/global_batch in data-parallel mode)
-    const double* loss_acc; // collapsed flag at [1]: skip the update when set (src/iso.jl:186-189 throws before update!)
+    double* loss_acc;       // [0] epoch loss sum, [1] collapsed flag (set: skip the update, src/iso.jl:186-189 throws before update!),
+                            // [2] (as int) the target's status word
     double* host_pub;       // optional device pointer to MAPPED pinned host memory: [loss sum, collapsed flag, status word]
-    const int* status;      //          the target's status word published with them
+    long long n;
+    long long slab_prefix;  // gradient slabs are summed for parameter indices < slab_prefix
+    int kind, nslab;
+    float lr, reg, beta1, beta2, eps, rho;
+    float bc1, bc2;         // 1 - beta1^t, 1 - beta2^t for this step (host copy, used when bt == nullptr)
+    float gscale;           // gradient multiplier (1, or 1/global_batch in data-parallel mode)
 };
 void isk_launch_opt_step(const OptArgs& a, hipStream_t st);
 

@@ -889,7 +889,9 @@ void isk_launch_train_grad1n(const TrainShape& s, const TrainBuffers& b, const i
 // Optimisers.jl 0.4.7: OptimiserChain(WeightDecay(reg), Adam | Nesterov), one thread per parameter.
 // The batch loss sits in grad[n]; a non-finite loss (or an earlier one in this epoch) skips the
 // update, as the reference throws before update! (src/iso.jl:186-189).
-__global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a, double* loss_acc) {
+static_assert(sizeof(OptArgs) <= 128, "OptArgs: two kernarg cache lines");
+__global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
+    double* const loss_acc = a.loss_acc;
     ISK_LATENCY_CHAIN_PRIO();
     const float bc1 = a.bt ? (float)(1.0 - a.bt[0]) : a.bc1, bc2 = a.bt ? (float)(1.0 - a.bt[1]) : a.bc2;
     const float lstep = a.grad[a.n];
@@ -903,7 +905,7 @@ __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a, double* loss_a
             // one counts): no copy kernels behind the epoch, the host only waits for an event
             a.host_pub[0] = acc0;
             a.host_pub[1] = bad ? 1.0 : 0.0;
-            ((int*)(a.host_pub + 2))[0] = a.status ? a.status[0] : 0;
+            ((int*)(a.host_pub + 2))[0] = ((const int*)(loss_acc + 2))[0];
         }
     }
     if (bad) return;
@@ -933,7 +935,7 @@ void isk_launch_opt_step(const OptArgs& a, hipStream_t st) {
     long long b = (a.n + 255) / 256;
     if (b > 2048) b = 2048;
     if (b < 1) b = 1;
-    hipLaunchKernelGGL(opt_step_kernel, dim3((unsigned)b), dim3(256), 0, st, a, (double*)a.loss_acc);
+    hipLaunchKernelGGL(opt_step_kernel, dim3((unsigned)b), dim3(256), 0, st, a);
 }
 
 // ------------------------------------------------------------------ coordinate pullback ---
