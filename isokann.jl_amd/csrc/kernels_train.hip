@@ -152,9 +152,7 @@ __global__ __launch_bounds__(FW1N_WAVES * 64, 4) void train_fwd1n_kernel(Fwd1nAr
     int r0 = rb * 32 + li, r1 = r0 + 16;
     if (r0 > a.B - 1) r0 = a.B - 1;
     if (r1 > a.B - 1) r1 = a.B - 1;
-    const long long x0r = a.perm ? a.perm[r0] : r0, x1r = a.perm ? a.perm[r1] : r1;
-    const float* x0 = a.X + x0r * (long long)a.Fp + lq * 4;
-    const float* x1 = a.X + x1r * (long long)a.Fp + lq * 4;
+    const int x0r = a.perm ? a.perm[r0] : r0, x1r = a.perm ? a.perm[r1] : r1;      // consumed after the first weight loads are out
     const f32x4* Wp = (const f32x4*)a.W1n + lane;
     const int cbeg = ks * a.cpb;
     int cend = cbeg + a.cpb;
@@ -163,15 +161,21 @@ __global__ __launch_bounds__(FW1N_WAVES * 64, 4) void train_fwd1n_kernel(Fwd1nAr
 #pragma unroll
     for (int t = 0; t < NTB; ++t) { acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     struct Frag { f32x4 xa, xb, g, b, w[NTB]; };
+    const float* x0 = a.X + lq * 4;
+    const float* x1 = a.X + lq * 4;
+    bool xset = false;
     auto load = [&](Frag& f, int c) {
-        f.xa = *(const f32x4*)(x0 + c * 16);
-        f.xb = *(const f32x4*)(x1 + c * 16);
-        if (LN) { f.g = *(const f32x4*)(a.g + c * 16 + lq * 4); f.b = *(const f32x4*)(a.beta + c * 16 + lq * 4); }
+        // the weight / LayerNorm loads first: the sample addresses depend on the batch's row indices (a load of their own),
+        // and a wave issues in order -- whatever stands behind the first sample load waits for that index with it
 #pragma unroll
         for (int t = 0; t < NTB; ++t) {
             const int tt = t0 + t < a.nt ? t0 + t : a.nt - 1;             // a short last group re-reads its last tile (discarded)
             f.w[t] = Wp[(long long)(c * a.nt + tt) * 64];
         }
+        if (LN) { f.g = *(const f32x4*)(a.g + c * 16 + lq * 4); f.b = *(const f32x4*)(a.beta + c * 16 + lq * 4); }
+        if (!xset) { x0 += (long long)x0r * a.Fp; x1 += (long long)x1r * a.Fp; xset = true; }
+        f.xa = *(const f32x4*)(x0 + c * 16);
+        f.xb = *(const f32x4*)(x1 + c * 16);
     };
     auto mma = [&](const Frag& f) {
 #pragma unroll
@@ -770,15 +774,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(
                 float av[4];
                 f32x4 bq[4][NB4 > 0 ? NB4 : 1];
                 float br[4][NR > 0 ? NR : 1];
+                // the delta rows first: the sample addresses depend on the row indices fetched above (in-order issue)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    av[j] = Xc[(long long)rr[cb][j] * b.Fp];
                     const float* drow = b.delta1 + (long long)(r0 + j) * H1p;
 #pragma unroll
                     for (int q = 0; q < NB4; ++q) bq[j][q] = *(const f32x4*)(drow + 64 * q + 4 * li);
 #pragma unroll
                     for (int u = 0; u < NR; ++u) br[j][u] = drow[64 * NB4 + 16 * u + li];
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] = Xc[(long long)rr[cb][j] * b.Fp];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
