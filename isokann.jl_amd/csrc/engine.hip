@@ -757,7 +757,8 @@ static void featurize_ys_ahead(isk_engine* e) {
 static void featurize_ys_beside_training(isk_engine* e, long long train_launch_steps) {
     // only worth it when the training phase is a long chain of small launches: with a handful of big steps the
     // throttled featurizer would outlast them and become the critical path (measured at minibatch = 0)
-    if (train_launch_steps < 4) return;
+    static const long long min_steps = [] { const char* v = getenv("ISK_SIDE_MIN_STEPS"); return v ? atoll(v) : 4LL; }();
+    if (train_launch_steps < min_steps) return;
     if (overlap_mode() != 2 || !e->cfg.featurize_every_iteration || !e->d_xhat_alt || e->ys_ahead) return;
     (void)hipEventRecord(e->ev_fwd_done, e->stream);
     (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
