@@ -227,7 +227,7 @@ void isk_launch_train_grad1n(const TrainShape& s, const TrainBuffers& b, const i
 int  isk_train_tail_nblocks(int B);
 long long isk_train_part_floats(const TrainShape& s, int maxB);
 
-struct OptArgs {            // <= 128 bytes: a third 64-byte kernarg line cost 2.7 us per optimizer step (measured at minibatch = 100)
+struct OptArgs {            // kept within two 64-byte kernarg lines
     float* theta; const float* grad; float* m; float* v;
     const double* bt;       // optional: device [beta1^t, beta2^t] of THIS step (then bc1/bc2 are derived from it, so the launch
                             // arguments do not change from step to step and the epoch can be replayed as a hipGraph)
