@@ -707,9 +707,12 @@ static void featurize_resident(isk_engine* e) {
         // the (un-throttled) xs launch runs under the tail of the throttled ys featurization instead of after it
         // the side-stream launch covered the ys AND the xs rows (one launch over the contiguous input slab), the f32 xs
         // copy for the training kernels included: swap the three buffer pairs
-        std::swap(e->d_xhat, e->d_xhat_alt);
-        std::swap(e->d_xscale, e->d_xscale_alt);
-        std::swap(e->d_xs32, e->d_xs32_alt);
+        static const bool dbg_copy = [] { const char* v = getenv("ISK_DEBUG_FEAT_COPY"); return v && atoi(v) != 0; }();
+        if (!dbg_copy) {                 // (diagnostic stream instead of the featurizer: the other buffers hold no features)
+            std::swap(e->d_xhat, e->d_xhat_alt);
+            std::swap(e->d_xscale, e->d_xscale_alt);
+            std::swap(e->d_xs32, e->d_xs32_alt);
+        }
         e->ys_ahead = false;
         fold_ahead(e);                  // the weight planes of the coming forward (normally already built behind the last epoch)
         (void)hipStreamWaitEvent(e->stream, e->ev_ys_ready, 0);

@@ -354,8 +354,23 @@ bool isk_featurize_reg_ok(const FeatArgs& a) {
     return need <= 32 && (!pd || (a.packed_pairs != nullptr && a.D <= 2048 && (size_t)4 * (a.D / 3) * 16 <= 150 * 1024));
 }
 
+// diagnostic (ISK_DEBUG_FEAT_COPY=1): the background launch replaced by a plain stream of the same bytes (coordinates in,
+// rows out, no LDS, no arithmetic): separates what the training kernels lose to the featurizer's MEMORY traffic from what
+// they lose to its LDS / issue-slot use
+__global__ __launch_bounds__(256) void debug_stream_kernel(const f32x4* __restrict__ in, long long nin, f32x4* __restrict__ out, long long nout) {
+    const long long stride = (long long)gridDim.x * 256;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nin; i += stride) acc += __builtin_nontemporal_load(in + i);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nout; i += stride) __builtin_nontemporal_store(acc, out + i);
+}
+
 void isk_launch_featurize(const FeatArgs& a, hipStream_t st) {
     if (a.S <= 0) return;
+    static const int dbg_copy = [] { const char* v = getenv("ISK_DEBUG_FEAT_COPY"); return v ? atoi(v) : 0; }();
+    if (dbg_copy && a.background) {
+        hipLaunchKernelGGL(debug_stream_kernel, dim3(256 * dbg_copy), dim3(256), 0, st, (const f32x4*)a.in, a.S * a.D / 4, (f32x4*)a.xhat, a.S * a.Fp / 4);
+        return;
+    }
     const bool pd = a.pairs != nullptr;
     const int need = (a.Fp + 63) / 64;
     if (isk_featurize_reg_ok(a)) {
