@@ -1,7 +1,9 @@
 // Host side of the MI355X ISOKANN engine: owns device memory, sequences the kernels of
-// kernels_fwd.hip / kernels_train.hip on one HIP stream, implements the C ABI of
-// include/isokann_hip.h.  The Float64 inner-simplex (ISA) solve runs on the host, as it does
-// in the reference (src/isotarget.jl:81-107 pulls chi and ks to the CPU).
+// kernels_fwd.hip / kernels_fwd_bf16.hip / kernels_train.hip / kernels_isa.hip / kernels_layered.hip on the engine's
+// streams (main, side: the next iteration's featurizer, copy: shuffle orders), implements the C ABI of
+// include/isokann_hip.h.  Nothing of an isk_run iteration runs on the host: the Float64 inner-simplex (ISA) target is
+// a device kernel chain (the reference pulls chi and ks to the CPU, src/isotarget.jl:81-107; the host twin
+// isa_solve_host below serves the host-driven data-parallel hooks and isk_isa_solve).
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
