@@ -2179,7 +2179,11 @@ RcclApi g_rccl;
 
 int rccl_load() {
     if (g_rccl.lib) return ISK_OK;
-    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // the copy the host process already uses first (PyTorch ships its own librccl: two different RCCL builds in one
+    // process would each keep their own view of the devices and of the IPC state)
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return fail(ISK_EUNSUPPORTED, std::string("cannot load librccl.so: ") + dlerror());
