@@ -2181,7 +2181,12 @@ int rccl_load() {
     if (g_rccl.lib) return ISK_OK;
     // the copy the host process already uses first (PyTorch ships its own librccl: two different RCCL builds in one
     // process would each keep their own view of the devices and of the IPC state)
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    void* h = nullptr;
+    if (const char* over = getenv("ISK_RCCL_LIB")) {     // another collective library with the same six entry points (tests/mock_rccl)
+        h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return fail(ISK_EUNSUPPORTED, std::string("cannot load ISK_RCCL_LIB: ") + dlerror());
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);

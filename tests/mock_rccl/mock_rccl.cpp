@@ -1,0 +1,165 @@
+// TEST DOUBLE, not a product path.  A stand-in for librccl.so that lets TWO (or more) processes sharing ONE GPU run the
+// engine's native data-parallel driver (isk_dp_run): real RCCL rejects two ranks on one device ("Duplicate GPU
+// detected"), and the build loop has single-GPU boxes only.  It implements exactly the six entry points the engine
+// binds (engine.hip rccl_load) with host staging through a POSIX shared-memory segment: every collective drains the
+// stream, copies the operand to the rank's slot, meets the other ranks at a barrier, reduces / concatenates in RANK ORDER
+// (so every rank computes the same bits) and copies the result back.  Slow and synchronous by design -- what it checks
+// is the engine's collective SEQUENCE, counts, offsets and shard arithmetic at world > 1, and that no rank leaves the
+// others waiting (the barrier gives up after ISK_MOCK_RCCL_TIMEOUT_S (60) seconds and the collective returns an error instead of hanging).
+// Selected with ISK_RCCL_LIB=<path> (tests/test_gpu_dp_native2.py).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace {
+constexpr size_t SLOT_BYTES = 16u << 20;
+int mock_timeout_s() {
+    static const int t = [] { const char* v = getenv("ISK_MOCK_RCCL_TIMEOUT_S"); return v && atoi(v) > 0 ? atoi(v) : 60; }();
+    return t;
+}
+
+struct Header {
+    std::atomic<int> arrived;
+    std::atomic<int> generation;
+    std::atomic<long long> ncalls;      // collectives completed (rank 0 counts): the test reads it back
+};
+
+struct MockComm {
+    int rank, world;
+    char name[64];
+    uint8_t* base;
+    size_t bytes;
+    Header* hdr() const { return reinterpret_cast<Header*>(base); }
+    uint8_t* slot(int r) const { return base + 4096 + (size_t)r * SLOT_BYTES; }
+};
+
+bool barrier(MockComm* c) {
+    Header* h = c->hdr();
+    const int gen = h->generation.load(std::memory_order_acquire);
+    if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == c->world) {
+        h->arrived.store(0, std::memory_order_relaxed);
+        h->generation.fetch_add(1, std::memory_order_release);
+        return true;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (h->generation.load(std::memory_order_acquire) == gen) {
+        std::this_thread::yield();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(mock_timeout_s())) return false;
+    }
+    return true;
+}
+
+size_t type_size(ncclDataType_t t) {
+    switch (t) {
+        case ncclFloat: return 4;
+        case ncclInt64: return 8;
+        case ncclDouble: return 8;
+        default: return 0;
+    }
+}
+
+template <typename T>
+void reduce_into(T* acc, const T* x, size_t n, ncclRedOp_t op) {
+    if (op == ncclSum) for (size_t i = 0; i < n; ++i) acc[i] += x[i];
+    else for (size_t i = 0; i < n; ++i) acc[i] = x[i] > acc[i] ? x[i] : acc[i];
+}
+}  // namespace
+
+extern "C" {
+
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
+    std::memset(id, 0, sizeof(*id));
+    std::snprintf(id->internal, sizeof(id->internal), "/iskmock_%d_%lld", (int)getpid(),
+                  (long long)std::chrono::steady_clock::now().time_since_epoch().count());
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int world, ncclUniqueId id, int rank) {
+    if (!comm || world < 1 || rank < 0 || rank >= world) return ncclInvalidArgument;
+    MockComm* c = new MockComm();
+    c->rank = rank; c->world = world;
+    std::snprintf(c->name, sizeof(c->name), "%s", id.internal);
+    c->bytes = 4096 + (size_t)world * SLOT_BYTES;
+    const int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)c->bytes) != 0) { if (fd >= 0) close(fd); delete c; return ncclSystemError; }
+    c->base = (uint8_t*)mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (c->base == MAP_FAILED) { delete c; return ncclSystemError; }
+    if (!barrier(c)) { munmap(c->base, c->bytes); delete c; return ncclInternalError; }
+    *comm = reinterpret_cast<ncclComm_t>(c);
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommDestroy(ncclComm_t comm) {
+    MockComm* c = reinterpret_cast<MockComm*>(comm);
+    if (!c) return ncclSuccess;
+    if (const char* out = getenv("ISK_MOCK_RCCL_COUNT_FILE")) {
+        if (c->rank == 0) {
+            if (FILE* f = std::fopen(out, "w")) { std::fprintf(f, "%lld\n", c->hdr()->ncalls.load()); std::fclose(f); }
+        }
+    }
+    munmap(c->base, c->bytes);
+    if (c->rank == 0) shm_unlink(c->name);
+    delete c;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm,
+                           hipStream_t stream) {
+    MockComm* c = reinterpret_cast<MockComm*>(comm);
+    const size_t ts = type_size(dt);
+    if (!c || !ts || (op != ncclSum && op != ncclMax) || count * ts > SLOT_BYTES) return ncclInvalidArgument;
+    if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipMemcpy(c->slot(c->rank), send, count * ts, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    if (!barrier(c)) return ncclInternalError;
+    std::vector<uint8_t> acc(c->slot(0), c->slot(0) + count * ts);
+    for (int r = 1; r < c->world; ++r) {
+        if (dt == ncclFloat) reduce_into((float*)acc.data(), (const float*)c->slot(r), count, op);
+        else if (dt == ncclDouble) reduce_into((double*)acc.data(), (const double*)c->slot(r), count, op);
+        else reduce_into((long long*)acc.data(), (const long long*)c->slot(r), count, op);
+    }
+    if (!barrier(c)) return ncclInternalError;           // nobody overwrites a slot before every rank has read it
+    if (c->rank == 0) c->hdr()->ncalls.fetch_add(1);
+    if (hipMemcpy(recv, acc.data(), count * ts, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclAllGather(const void* send, void* recv, size_t sendcount, ncclDataType_t dt, ncclComm_t comm, hipStream_t stream) {
+    MockComm* c = reinterpret_cast<MockComm*>(comm);
+    const size_t ts = type_size(dt);
+    if (!c || !ts || sendcount * ts > SLOT_BYTES) return ncclInvalidArgument;
+    if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipMemcpy(c->slot(c->rank), send, sendcount * ts, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    if (!barrier(c)) return ncclInternalError;
+    for (int r = 0; r < c->world; ++r)
+        if (hipMemcpy((uint8_t*)recv + (size_t)r * sendcount * ts, c->slot(r), sendcount * ts, hipMemcpyHostToDevice) != hipSuccess)
+            return ncclUnhandledCudaError;
+    if (!barrier(c)) return ncclInternalError;
+    if (c->rank == 0) c->hdr()->ncalls.fetch_add(1);
+    return ncclSuccess;
+}
+
+const char* ncclGetErrorString(ncclResult_t r) {
+    switch (r) {
+        case ncclSuccess: return "success";
+        case ncclInternalError: return "mock rccl: a rank did not reach the collective (barrier timeout)";
+        case ncclInvalidArgument: return "mock rccl: invalid argument";
+        case ncclSystemError: return "mock rccl: shared memory";
+        default: return "mock rccl: hip error";
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+"""The engine's NATIVE data-parallel driver (isk_dp_run: collectives issued by the engine on its own stream) at
+world_size 2 on ONE GPU.  Real RCCL refuses two ranks on one device, so the engine is pointed (ISK_RCCL_LIB) at
+tests/mock_rccl -- a test double with RCCL's six entry points that stages through shared memory and reduces in rank
+order.  What this covers that the one-rank RCCL test (test_gpu_parity.py) cannot: the collective sequence, counts, shard
+offsets (`first = N * rank` of the gathered ISA arrays, the one-slab gradient buffer) and that both ranks issue the
+same collectives in the same order (a mismatch ends in the mock's barrier timeout, not a hang).  The result must equal
+the single-process isk_run on the full data with the equivalent global shuffle, and the replicas must be bit-identical."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from tests.test_gpu_dp2 import _free_port, _mk_iso, _problem  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+MOCK_SRC = os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp")
+
+
+@pytest.fixture(scope="module")
+def mock_lib():
+    out = os.path.join(tempfile.gettempdir(), "librccl_mock_%d.so" % os.getuid())
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc, "-O2", "-fPIC", "-shared", MOCK_SRC, "-o", out, "-lrt"], check=True)
+    return out
+
+
+def _worker(rank, world, port, nout, minibatch, niter, epochs, outdir, mock):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ISK_RCCL_LIB=mock)
+    if rank == 0:
+        os.environ["ISK_MOCK_RCCL_COUNT_FILE"] = os.path.join(outdir, "ncalls.txt")
+    import ctypes as C
+    import importlib
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import __graft_entry__ as ge
+        pkg = ge.load_package()
+        dp = importlib.import_module("isokann_jl_amd.dp")
+        capi = importlib.import_module("isokann_jl_amd.capi")
+        xs, ys, pairs, widths, theta = _problem(nout)
+        lo, hi = dp.shard_bounds(xs.shape[1], world, rank)
+        torch.cuda.set_device(0)
+        iso = _mk_iso(pkg, xs[:, lo:hi], ys[:, :, lo:hi], pairs, widths, theta, nout, minibatch)
+        local = dp.HipLocal(iso, use_torch_stream=False)
+        # the communicator hand-shake of HipLocal.comm_init_native, with gloo carrying the 128 bytes
+        ident = np.zeros(128, np.uint8)
+        if rank == 0:
+            capi.check(local.lib.isk_dp_comm_id(ident.ctypes.data_as(C.POINTER(C.c_uint8))))
+        t = torch.from_numpy(ident)
+        dist.broadcast(t, src=0)
+        ident = np.ascontiguousarray(t.numpy())
+        capi.check(local.lib.isk_dp_comm_init(local.h, ident.ctypes.data_as(C.POINTER(C.c_uint8)), rank, world))
+        counts = [hi - lo] * world
+        bl, nb, gb = dp.batch_plan(minibatch, counts, world, hi - lo)
+        perms = np.stack([np.random.default_rng(1000 * rank + i).permutation(hi - lo) for i in range(niter * epochs)]).astype(np.int32)
+        losses = local.run_native(niter, epochs, bl, nb, gb, perms) / sum(counts)
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), losses=losses, params=iso.model.get_params(), perms=perms, lo=lo, hi=hi,
+                 plan=np.array([bl, nb, gb]))
+        iso.close()                     # destroys the communicator (rank 0 writes the collective count)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nout,minibatch,epochs", [(1, 64, 1), (3, 64, 1), (3, 0, 1), (3, 48, 2)])
+def test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, nout, minibatch, epochs):
+    import torch.multiprocessing as mp
+    pkg = gpu_pkg
+    world, niter = 2, 3
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), nout, minibatch, niter, epochs, d, mock_lib), nprocs=world, join=True)
+        r = [np.load(os.path.join(d, f"r{k}.npz")) for k in range(world)]
+        ncalls = int(open(os.path.join(d, "ncalls.txt")).read())
+    np.testing.assert_array_equal(r[0]["losses"], r[1]["losses"])      # rank-ordered reduction: the same bits everywhere
+    np.testing.assert_array_equal(r[0]["params"], r[1]["params"])
+    bl, nb, gb = (int(v) for v in r[0]["plan"])
+    # collectives per run: the equal-shard check once, per iteration 1 (shift-scale range) or 2 (ks, chi gathers),
+    # per optimizer step one gradient all-reduce
+    assert ncalls == 1 + niter * ((1 if nout == 1 else 2) + epochs * nb)
+    xs, ys, pairs, widths, theta = _problem(nout)
+    N = xs.shape[1]
+    gperms = []
+    for k in range(niter * epochs):
+        head = np.concatenate([np.concatenate([int(x["lo"]) + x["perms"][k][b * bl:(b + 1) * bl] for x in r]) for b in range(nb)])
+        gperms.append(np.concatenate([head, np.setdiff1d(np.arange(N), head)]))
+    ref = _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, gb if minibatch else 0)
+    pkg.run(ref, niter, epochs, perms=np.stack(gperms))
+    np.testing.assert_allclose(r[0]["losses"], ref.losses, rtol=2e-4)
+    got, want = r[0]["params"], ref.model.get_params()
+    off = np.abs(got - want) > 5e-6 + 5e-4 * np.abs(want)               # Adam sign flips of rounding-level gradients: see test_gpu_dp2
+    assert off.mean() <= 2e-3, f"{off.sum()} of {off.size} parameters differ"
+    assert np.abs(got - want).max() <= 2 * niter * epochs * 1e-2 + 1e-6
+    ref.close()
+
+
+def _absent_worker(rank, world, port, outdir, mock):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ISK_RCCL_LIB=mock, ISK_MOCK_RCCL_TIMEOUT_S="5")
+    import ctypes as C
+    import importlib
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import __graft_entry__ as ge
+        pkg = ge.load_package()
+        dp = importlib.import_module("isokann_jl_amd.dp")
+        capi = importlib.import_module("isokann_jl_amd.capi")
+        xs, ys, pairs, widths, theta = _problem(1)
+        lo, hi = dp.shard_bounds(xs.shape[1], world, rank)
+        torch.cuda.set_device(0)
+        iso = _mk_iso(pkg, xs[:, lo:hi], ys[:, :, lo:hi], pairs, widths, theta, 1, 64)
+        local = dp.HipLocal(iso, use_torch_stream=False)
+        ident = np.zeros(128, np.uint8)
+        if rank == 0:
+            capi.check(local.lib.isk_dp_comm_id(ident.ctypes.data_as(C.POINTER(C.c_uint8))))
+        t = torch.from_numpy(ident)
+        dist.broadcast(t, src=0)
+        ident = np.ascontiguousarray(t.numpy())
+        capi.check(local.lib.isk_dp_comm_init(local.h, ident.ctypes.data_as(C.POINTER(C.c_uint8)), rank, world))
+        msg = ""
+        try:
+            # rank 1: a batch decomposition that fails validation -> returns before its first collective
+            local.run_native(1, 1, 32 if rank == 0 else 0, 1, 64, None)
+        except Exception as ex:           # noqa: BLE001
+            msg = f"{type(ex).__name__}: {ex}"
+        open(os.path.join(outdir, f"r{rank}.txt"), "w").write(msg)
+        dist.barrier()
+        iso.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_driver_reports_a_rank_that_stays_away(gpu_pkg, mock_lib):
+    """a collective one rank never joins comes back as an error code on the others (the mock's barrier times out the
+    way RCCL's watchdog would), and the rank with the bad argument returns BEFORE its first collective"""
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_absent_worker, args=(2, _free_port(), d, mock_lib), nprocs=2, join=True)
+        m0, m1 = (open(os.path.join(d, f"r{k}.txt")).read() for k in range(2))
+    assert "bad batch decomposition" in m1, m1
+    assert "rccl" in m0 and "did not reach" in m0, m0
