@@ -117,6 +117,7 @@ struct isk_engine {
     hipStream_t copy = nullptr;       // small H2D staging (the epoch's shuffle order): never queued behind the side-stream featurizer
     hipEvent_t ev_fwd_done = nullptr, ev_ys_ready = nullptr;
     long long side_after_forward = 0;   // isk_run / isk_dp_run: launch the side-stream ys featurization right behind the forward
+    long long early_rows = 0;           // rows of the next iteration already featurized beside THIS iteration's forward (ISK_FEAT_EARLY_PCT)
                                         // kernel (value = optimizer steps of the coming training phase), not after the target kernels
     bool ys_ahead = false;       // a side-stream featurization of ys is in flight / complete
     // parameters
@@ -687,17 +688,21 @@ extern "C" int isk_reset_opt_state(isk_engine* e) {
 // ---------------------------------------------------------------------------------------
 // data
 // ---------------------------------------------------------------------------------------
-// xscale != nullptr: split-f16 planes (forward_mode 3) with the inverse row scales there; xs32: the same rows in f32 as well
-static void featurize_rows(isk_engine* e, const float* in, long long S, float* xhat, hipStream_t st = nullptr, float* xscale = nullptr,
-                           float* xs32 = nullptr, long long x32_first = 0) {
+// Featurizes S rows into rows [row0, row0 + S) of the feature buffer `xhat` (its BASE).  xscale != nullptr: split-f16 planes
+// (forward_mode 3; unit-blocked rows, isk_plane_off) with the inverse row scales at xscale[row0 ..]; xs32: the rows from
+// local row x32_first on in f32 as well
+static void featurize_rows(isk_engine* e, const float* in, long long S, float* xhat, long long row0, hipStream_t st = nullptr,
+                           float* xscale = nullptr, float* xs32 = nullptr, long long x32_first = 0, int bg_wgs = 1) {
     FeatArgs a = {};
-    a.in = in; a.pairs = e->d_pairs; a.packed_pairs = e->d_packed; a.xhat = xhat; a.S = S; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
+    a.in = in; a.pairs = e->d_pairs; a.packed_pairs = e->d_packed; a.S = S; a.D = e->Din; a.F = e->F; a.Fp = e->Fp;
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
-    a.background = (st != nullptr);
-    a.planes = xscale != nullptr; a.xscale = xscale; a.xhat32 = xs32; a.x32_first = x32_first;
+    a.background = (st != nullptr) ? bg_wgs : 0;       // 1: the default throttle; > 1: that many workgroups in total
+    a.planes = xscale != nullptr;
+    if (a.planes) { a.xhat = xhat; a.row0 = row0; a.xscale = xscale + row0; }
+    else a.xhat = xhat + row0 * e->Fp;
+    a.xhat32 = xs32; a.x32_first = x32_first;
     isk_launch_featurize(a, st ? st : e->stream);
 }
-static float* xs_scale_of(const isk_engine* e, float* xscale) { return xscale ? xscale + e->N * e->K : nullptr; }
 
 // per-iteration featurization.  ys (the 95 % share) may already have been produced on the side
 // stream, into the other buffer of the pair, while the previous iteration's MFMA-bound forward was
@@ -721,10 +726,10 @@ static void featurize_resident(isk_engine* e) {
         return;
     } else {
         ScopedTimer t(e, ISK_T_FEATURIZE);
-        featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat, nullptr, e->d_xscale);
+        featurize_rows(e, e->d_in_ys, e->N * e->K, e->d_xhat, 0, nullptr, e->d_xscale);
     }
     ScopedTimer t(e, ISK_T_FEATURIZE);
-    featurize_rows(e, e->d_in_xs, e->N, e->d_xhat + (long long)e->N * e->K * e->Fp, nullptr, xs_scale_of(e, e->d_xscale), e->d_xs32);
+    featurize_rows(e, e->d_in_xs, e->N, e->d_xhat, e->N * e->K, nullptr, e->d_xscale, e->d_xs32);
 }
 
 // Where the next iteration's ys featurization runs (ISK_OVERLAP_FEATURIZE):
@@ -751,7 +756,7 @@ static void featurize_ys_ahead(isk_engine* e) {
     (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
     {
         ScopedTimer t(e, ISK_T_FEATURIZE, e->side);
-        featurize_rows(e, e->d_in_ys, e->N * e->K + e->N, e->d_xhat_alt, e->side, e->d_xscale_alt, e->d_xs32_alt, e->N * e->K);
+        featurize_rows(e, e->d_in_ys, e->N * e->K + e->N, e->d_xhat_alt, 0, e->side, e->d_xscale_alt, e->d_xs32_alt, e->N * e->K);
     }
     (void)hipEventRecord(e->ev_ys_ready, e->side);
     e->ys_ahead = true;
@@ -769,10 +774,36 @@ static void featurize_ys_beside_training(isk_engine* e, long long train_launch_s
     (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
     {
         ScopedTimer t(e, ISK_T_FEATURIZE, e->side);
-        featurize_rows(e, e->d_in_ys, e->N * e->K + e->N, e->d_xhat_alt, e->side, e->d_xscale_alt, e->d_xs32_alt, e->N * e->K);
+        const long long r0 = e->early_rows;              // already done beside the forward (featurize_early_share)
+        featurize_rows(e, e->d_in_ys + r0 * e->Din, e->N * e->K + e->N - r0, e->d_xhat_alt, r0, e->side, e->d_xscale_alt, e->d_xs32_alt,
+                       e->N * e->K - r0);
+        e->early_rows = 0;
     }
     (void)hipEventRecord(e->ev_ys_ready, e->side);
     e->ys_ahead = true;
+}
+
+// Experiment knob ISK_FEAT_EARLY_PCT (default 0 = off): that share of the next iteration's ys rows is featurized on the side
+// stream BESIDE THIS ITERATION'S FORWARD (ISK_FEAT_EARLY_WGS workgroups, default 128), the rest beside the training
+// kernels as usual: a lighter stream beside the latency-bound training chain at the price of a slower forward.
+// Called right before the forward is enqueued (every earlier reader of the other buffers precedes this point).
+static void featurize_early_share(isk_engine* e, long long train_launch_steps) {
+    static const int pct = [] { const char* v = getenv("ISK_FEAT_EARLY_PCT"); return v ? atoi(v) : 0; }();
+    static const int wgs = [] { const char* v = getenv("ISK_FEAT_EARLY_WGS"); return v && atoi(v) > 1 ? atoi(v) : 128; }();
+    static const long long min_steps = [] { const char* v = getenv("ISK_SIDE_MIN_STEPS"); return v ? atoll(v) : 4LL; }();
+    e->early_rows = 0;
+    if (pct <= 0 || train_launch_steps < min_steps) return;
+    if (overlap_mode() != 2 || !e->cfg.featurize_every_iteration || !e->d_xhat_alt || e->ys_ahead) return;
+    long long r = (e->N * e->K) * (long long)(pct > 100 ? 100 : pct) / 100;
+    r -= r % 16;
+    if (r <= 0) return;
+    (void)hipEventRecord(e->ev_fwd_done, e->stream);
+    (void)hipStreamWaitEvent(e->side, e->ev_fwd_done, 0);
+    {
+        ScopedTimer t(e, ISK_T_FEATURIZE, e->side);
+        featurize_rows(e, e->d_in_ys, r, e->d_xhat_alt, 0, e->side, e->d_xscale_alt, nullptr, 0, wgs);
+    }
+    e->early_rows = r;
 }
 
 // The throttled featurizer is the longer branch of [training || featurizer]: start it right behind the forward kernel,
@@ -798,8 +829,9 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
     const int H1p = isk_pad16(e->cfg.widths[1]);
     HIPCHK(hipMalloc((void**)&e->d_in_ys, (size_t)(N * K + N) * D * sizeof(float)));
     e->d_in_xs = e->d_in_ys + (size_t)N * K * D;
-    HIPCHK(hipMalloc((void**)&e->d_xhat, (size_t)S * e->Fp * sizeof(float)));
-    if (e->cfg.featurize_every_iteration) HIPCHK(hipMalloc((void**)&e->d_xhat_alt, (size_t)S * e->Fp * sizeof(float)));
+    const long long Srows = isk_plane_rows(S);           // the unit-blocked plane image (forward_mode 3) holds whole 16-row units
+    HIPCHK(hipMalloc((void**)&e->d_xhat, (size_t)Srows * e->Fp * sizeof(float)));
+    if (e->cfg.featurize_every_iteration) HIPCHK(hipMalloc((void**)&e->d_xhat_alt, (size_t)Srows * e->Fp * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_xs32, (size_t)N * e->Fp * sizeof(float)));
     if (e->cfg.featurize_every_iteration) HIPCHK(hipMalloc((void**)&e->d_xs32_alt, (size_t)N * e->Fp * sizeof(float)));
     if (e->planes) {
@@ -913,7 +945,7 @@ extern "C" int isk_features(isk_engine* e, const float* coords, int64_t D, int64
 static int forward_cols(isk_engine* e, const float* host_in, int64_t rowlen, int64_t ncols, bool is_coords, float* out) {
     TmpBuf in, xh, o, xsc;
     HIPCHK(hipMalloc(&in.p, (size_t)ncols * rowlen * sizeof(float)));
-    HIPCHK(hipMalloc(&xh.p, (size_t)ncols * e->Fp * sizeof(float)));
+    HIPCHK(hipMalloc(&xh.p, (size_t)isk_plane_rows(ncols) * e->Fp * sizeof(float)));
     HIPCHK(hipMalloc(&o.p, (size_t)ncols * e->nout * sizeof(float)));
     if (e->planes) HIPCHK(hipMalloc(&xsc.p, (size_t)ncols * sizeof(float)));
     HIPCHK(hipMemcpyAsync(in.p, host_in, (size_t)ncols * rowlen * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -1072,12 +1104,12 @@ static int forward_resident(isk_engine* e, int which, bool ahead = false) {
     long long S = nys + e->N;
     int tid = ISK_T_FWD_YS;
     if (which == 1) S = nys;
-    if (which == 2) { X += nys * e->Fp; out += nys * e->nout; S = e->N; tid = ISK_T_FWD_XS; }
+    if (which == 2) { if (!e->planes) X += nys * e->Fp; out += nys * e->nout; S = e->N; tid = ISK_T_FWD_XS; }
     if (ahead) (void)hipEventRecord(e->ev_fwd_done, e->stream);
     {
         ScopedTimer t(e, tid);
         MlpFwdArgs f = fwd_args(e, X, S, out);
-        if (e->planes) f.xscale = e->d_xscale + (which == 2 ? nys : 0);
+        if (e->planes) { f.xscale = e->d_xscale + (which == 2 ? nys : 0); f.x_row0 = which == 2 ? nys : 0; }   // unit-blocked rows: base + row index
         // diagnostic only (ISK_DEBUG_STAMPS=1 with a -DISK_STAMP build of the bf16x3 kernel): phase cycle sums
         static const bool stamps = getenv("ISK_DEBUG_STAMPS") != nullptr;
         static unsigned long long* dbg_st = nullptr;
@@ -1392,7 +1424,7 @@ static int koopman_cols(isk_engine* e, const float* ys, int64_t D, int64_t K, in
     const long long S = K * ncols;
     TmpBuf in, xh, o, ks, xsc;
     HIPCHK(hipMalloc(&in.p, (size_t)S * D * sizeof(float)));
-    HIPCHK(hipMalloc(&xh.p, (size_t)S * e->Fp * sizeof(float)));
+    HIPCHK(hipMalloc(&xh.p, (size_t)isk_plane_rows(S) * e->Fp * sizeof(float)));
     if (e->planes) HIPCHK(hipMalloc(&xsc.p, (size_t)S * sizeof(float)));
     HIPCHK(hipMalloc(&o.p, (size_t)S * e->nout * sizeof(float)));
     HIPCHK(hipMalloc(&ks.p, (size_t)ncols * e->nout * sizeof(float)));
@@ -1960,6 +1992,7 @@ extern "C" int isk_run(isk_engine* e, int32_t n, int32_t epochs, const int32_t* 
             const long long bs = (mb == 0 || e->N < mb) ? e->N : mb;
             static const int early = [] { const char* v = getenv("ISK_SIDE_EARLY"); return v ? atoi(v) : 1; }();
             e->side_after_forward = early ? (e->N / bs) * epochs : 0;
+            if (early) featurize_early_share(e, e->side_after_forward);
         }
         // the constant-chi check needs the device status word; it is read together with the loss
         const int tr = compute_target(e, false, e->cfg.featurize_every_iteration != 0);
@@ -2329,6 +2362,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
     for (int it = 0; it < n; ++it) {
         if (e->cfg.featurize_every_iteration) featurize_resident(e);      // first: see isk_run
         e->side_after_forward = (long long)nbatches * epochs;
+        featurize_early_share(e, e->side_after_forward);
         const int tr = dp_target_native(e);
         e->side_after_forward = 0;
         CHK(tr);

@@ -122,13 +122,8 @@ __device__ __forceinline__ void static_for_tiles(std::integer_sequence<int, Ts..
     (f(std::integral_constant<int, Ts>{}), ...);
 }
 
-#if ISK_ABLATE == 15
-#define PX_CH 512
-#define PX_H 256
-#else
 #define PX_CH 32
 #define PX_H 4
-#endif
 // the sample stream is read once per launch (1.45 GB): non-temporal loads keep it from evicting the weight planes and
 // the training working set (measured: step 1.647 -> 1.628 ms, cached-features mode 1.191 -> 1.163 ms)
 #ifndef ISK_X_NT
@@ -150,7 +145,10 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
     constexpr int STAGE16 = G::STAGE16, PER_T = G::PER_T, NX = G::NX, SLOTS = G::SLOTS;
     constexpr int TBAR = G::tile_dw(PER_T - 1);          // the stage's barrier follows the tile with the last LDS write
     constexpr bool XPF = TBAR < NT - 1;                  // next stage's first fragments can be fetched before this stage ends
-    constexpr int PXH = PRE ? 16 : PX_H;                 // float offset of a lane's second 16-byte load: the lo plane / the second half
+    // float offsets of a lane's second 16-byte load (the lo plane / the second half) and of the next chunk.  Pre-split
+    // samples live unit-blocked (isk_plane_off): chunk = 2 KiB, lo plane 1 KiB behind hi
+    constexpr int PXH = PRE ? 256 : PX_H;
+    constexpr int XCH = PRE ? 512 : PX_CH;
     static_assert(!PRE || NPL == 2, "pre-split samples come as two f16 planes");
     const int tid = threadIdx.x;
     const int last = nch - 1;
@@ -178,7 +176,7 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             xr[0][u][h] = *(const f32x4v*)(xp[u] + PXH * h);
-            xr[1][u][h] = *(const f32x4v*)(xp[u] + (last > 0 ? PX_CH : 0) + PXH * h);
+            xr[1][u][h] = *(const f32x4v*)(xp[u] + (last > 0 ? XCH : 0) + PXH * h);
         }
     __syncthreads();                                     // the previous pass's epilogue scratch aliases the buffers
 #pragma unroll
@@ -241,7 +239,15 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
                 if (PRE) {
                     const f16x8 wh = __builtin_bit_cast(f16x8, wf[fb][0]), wl = __builtin_bit_cast(f16x8, wf[fb][NPL > 1 ? 1 : 0]);
 #define F_(P_, W_) _Pragma("unroll") for (int u = 0; u < U; ++u) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, cur[u].P_), W_, acc[u][t], 0, 0, 0);
+#if ISK_ABLATE == 16          /* diagnostic: two of the three MFMAs, every operand still loaded (wrong results; what does the matrix work cost?) */
+                    F_(p1, wl) F_(p0, wh)
+#elif ISK_ABLATE == 17        /* diagnostic: one of the three, every operand still loaded */
+                    F_(p0, wh)
+                    _Pragma("unroll") for (int u = 0; u < U; ++u) asm volatile("" :: "v"(cur[u].p1));
+                    asm volatile("" :: "v"(wl));
+#else
                     F_(p1, wh) F_(p0, wl) F_(p0, wh)
+#endif
 #undef F_
                 } else if (NPL == 1) {
 #pragma unroll
@@ -256,7 +262,7 @@ __device__ __forceinline__ void pipe_pass(const MlpFwdArgs& a, const u32x4* __re
                 // ---- this tile's share of the stage's side work
 #pragma unroll
                 for (int i = 0; i < NX; ++i)
-                    if (G::tile_x(i) == t && ISK_ABLATE != 12) xr[s][i >> 1][i & 1] = X_LD((const f32x4v*)(xp[i >> 1] + cx * PX_CH + PXH * (i & 1)));
+                    if (G::tile_x(i) == t && ISK_ABLATE != 12) xr[s][i >> 1][i & 1] = X_LD((const f32x4v*)(xp[i >> 1] + cx * XCH + PXH * (i & 1)));
 #pragma unroll
                 for (int i = 0; i < PER_T; ++i)
                     if (G::tile_dw(i) == t && ISK_ABLATE != 14) wr[i * NTHR + tid] = wreg[i];
@@ -312,17 +318,9 @@ __device__ __forceinline__ void pipe_run(const MlpFwdArgs& a, const uint4* __res
         if (r > a.S - 1) r = a.S - 1;
         if (r < 0) r = 0;
         if (a.rows) r = a.rows[r];
-#if ISK_ABLATE == 15
-        {   // ablation: pretend the samples are stored fragment-linear (1 KiB per unit, chunk and half)
-            long long ub = u0 + u;
-            const long long umax = (a.S + 15) / 16 - 1;
-            if (ub > umax) ub = umax;
-            if (ub < 0) ub = 0;
-            xp[u] = a.X + ub * 16 * (long long)a.Fp + lane * 4;
-        }
-#else
-        xp[u] = a.X + r * (long long)a.Fp + lq * (PRE ? 4 : 8);
-#endif
+        // pre-split planes: the lane's 16 bytes of row r inside the unit's KiB (16 rows x 64 B) -- the 64 lanes of a load
+        // cover that KiB exactly: 8 whole lines
+        xp[u] = PRE ? a.X + isk_plane_off(a.x_row0 + r, a.Fp) + lq * 4 : a.X + r * (long long)a.Fp + lq * 8;
     }
     // pre-split operands: the inverse scales of this lane's four accumulator rows (row = 4 lq + r), fetched before the
     // pass so the epilogue does not wait on them

@@ -30,10 +30,18 @@ struct FeatArgs {
     // split-f16 output (forward_mode 3; register featurizer only, see isk_featurize_reg_ok): xhat rows are written as
     // [Fp/32 chunks][32 x f16 hi | 32 x f16 lo] of xhat * 2^s (same 4*Fp bytes per row), 2^-s goes to xscale[row]
     int planes;
+    long long row0;         // planes only: `xhat` is the BASE of the plane buffer and local row s is global row row0 + s of its
+                            // unit-blocked layout (isk_plane_off): a unit = 16 consecutive rows, per 32-feature chunk one 2 KiB
+                            // block [hi: 16 rows x 64 B | lo: 16 rows x 64 B], so that one MFMA operand load of the forward
+                            // (16 rows x 64 B) is ONE contiguous KiB = 8 whole 128-byte lines instead of half of 16 lines
     float* xscale;          // [S] inverse row scales (planes only)
     float* xhat32;          // optional: a second copy, always f32, of rows >= x32_first at xhat32[(row - x32_first)][Fp] (the xs rows the
     long long x32_first;    //           training kernels read)
 };
+// float offset of global row g inside the unit-blocked plane buffer (chunk 0, hi plane, first feature pair); chunk c adds
+// 512 floats (2 KiB), the lo plane 256 floats (1 KiB).  Rows are padded to whole units: isk_plane_rows(S).
+__host__ __device__ static inline long long isk_plane_off(long long g, int Fp) { return (g >> 4) * 16 * (long long)Fp + (g & 15) * 16; }
+static inline long long isk_plane_rows(long long S) { return (S + 15) / 16 * 16; }
 void isk_launch_featurize(const FeatArgs& a, hipStream_t st);
 bool isk_featurize_reg_ok(const FeatArgs& a);
 
@@ -75,6 +83,7 @@ struct MlpFwdArgs {
     // wscale[0] the inverse scale of the weight planes (isk_launch_fold_f16); z = acc * xscale[row] * wscale[0]
     const float* xscale;
     const float* wscale;
+    long long x_row0;          // split-f16 only: X is the base of the unit-blocked plane buffer, logical row r is its row x_row0 + r
     unsigned long long* dbg;   // diagnostic builds only (-DISK_STAMP): per-wave phase cycle sums, else nullptr
 };
 // append the bias block to the LDS image (call once nt1 / ntail / tail[] / tailw_floats are final)

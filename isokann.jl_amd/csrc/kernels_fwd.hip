@@ -136,10 +136,19 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 // out as 8-byte stores (512 contiguous bytes per wave instruction) and, in PLANES mode, an f16 pair is one dword.
 //
 // PLANES (forward_mode 3): the standardised row is written pre-split for the split-f16 forward GEMM
-// (fwd_f16 path in fwd_bf16_kernel.hpp): per 32-feature chunk 128 bytes = [32 x f16 hi | 32 x f16 lo] with
+// (fwd_f16 path in fwd_bf16_kernel.hpp): per 32-feature chunk 64 B of hi and 64 B of lo with
 //     xs = xhat * 2^s (row scale, maximum in [2^14, 2^15)),  hi = f16(xs),  lo = f16(xs - hi)      (22 mantissa bits)
 // and 2^-s goes to xscale[row].  Same bytes per row as the f32 image (4*Fp); the forward kernel then loads MFMA A
-// operands straight from HBM with no conversion work.
+// operands straight from HBM with no conversion work.  The rows are stored UNIT-BLOCKED (FeatArgs.row0, isk_plane_off):
+// 16 consecutive rows share, per chunk, one 2 KiB block [hi: 16 x 64 B | lo: 16 x 64 B], because what the forward kernel
+// pays for is the number of 128-byte lines one load instruction touches (measured with address-only ablation builds of
+// the forward: 16 rows x 64 B of a row-major image = half of 16 lines per instruction 0.39 ms, the same bytes as one
+// contiguous KiB = 8 whole lines 0.29 ms; quad-contiguous or same-DRAM-page variants that still touch 16 lines gain
+// little).  A line of that image holds 64 B of TWO neighbouring rows: a wave therefore takes the rows in pairs
+// (2j, 2j+1 in consecutive trips), parks the first row's plane dwords in a wave-private LDS stash and stores both rows
+// together behind the second one -- the two halves of every line leave in consecutive store instructions of one wave,
+// as the hi / lo halves of a row-major line did (stored a row apart -- 3.5 us under the throttle -- the half lines were
+// written back separately: featurizer 0.73 -> 0.82 ms, training beside it 0.69 -> 0.78).
 template <int NFL, int NDL, bool PDIST, int PF = 1, bool PLANES = false>
 __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const unsigned* __restrict__ packed_pairs) {
     static_assert(NFL % 2 == 0, "a lane holds adjacent feature pairs");
@@ -148,6 +157,9 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int natoms = a.D / 3;
     f32x4* cw = (f32x4*)smem + (size_t)wave * natoms;        // wave-private xyzw coordinates
+    // PLANES: behind the coordinates, per wave NPB x 64 (hi, lo) dword pairs of the pair's first row
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2* stash = (u32x2*)((f32x4*)smem + (PDIST ? 4 * (size_t)natoms : 0)) + (size_t)wave * (NPB * 64);
     unsigned pr[NFL];
     if (PDIST) {
 #pragma unroll
@@ -158,7 +170,9 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
     }
     const float invF = 1.0f / (float)a.F;
     const long long nw = (long long)gridDim.x * 4;
-    long long s = (long long)blockIdx.x * 4 + wave;
+    const long long w0 = (long long)blockIdx.x * 4 + wave;
+    // trip t of this wave -> row.  PLANES: rows in pairs (see above); else row w0 + t nw
+    auto row_of = [&](long long t) { return PLANES ? 2 * (w0 + (t >> 1) * nw) + (t & 1) : w0 + t * nw; };
     // software pipeline: the next PF samples' rows (NDL or NFL dwords per lane each) are in flight in registers while
     // the current one is featurized, so a wave keeps HBM busy on its own (needed when the kernel runs
     // throttled beside the training kernels)
@@ -201,7 +215,19 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
                 buf[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (128 * (u >> 1) + 2 * lane + (u & 1)) * 4, 0, FEAT_AUX));
         }
     };
-    auto one = [&](float (&buf)[NIN], long long srow) {
+    auto plane_rv = [&](long long srow) {
+        // descriptor over the rest of the row's unit block, starting at the row's 64-byte slot of chunk 0: chunks at or
+        // past Fp/32 (the lanes' padding features) fall outside it and are dropped
+        const long long g = a.row0 + srow;
+        const unsigned long long p = (unsigned long long)(a.xhat + isk_plane_off(g, a.Fp));
+        isk_i32x4 rv;
+        rv[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+        rv[1] = __builtin_amdgcn_readfirstlane((int)((p >> 32) & 0xffffu));
+        rv[2] = __builtin_amdgcn_readfirstlane(srow < a.S ? 64 * a.Fp - (int)(g & 15) * 64 : 0);
+        rv[3] = 0x00020000;
+        return rv;
+    };
+    auto one = [&](float (&buf)[NIN], long long srow, long long srow_refill, const int second) {
         float d[NFL];
         if (PDIST) {
 #pragma unroll
@@ -213,7 +239,7 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
 #pragma unroll
             for (int i = 0; i < NFL; ++i) d[i] = buf[i];
         }
-        fetch(buf, srow + PF * nw);                          // refill this slot: the sample PF trips ahead
+        fetch(buf, srow_refill);                             // refill this slot: the sample PF trips ahead
         if (PDIST) {
             __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes have landed
             __builtin_amdgcn_wave_barrier();
@@ -262,15 +288,30 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
             for (int i = 0; i < NFL; ++i) m = fmaxf(m, fabsf(xh[i]));
             float sc, inv;
             isk_f16_scale(wave_max_dpp(m), sc, inv);
-            const isk_i32x4 ro = row_rv(a.xhat, srow, a.Fp, a.Fp);
+            // no arrays of converted values here: the kernel sits at the register limit that lets two 128-register training
+            // waves share a SIMD with it (248 of 512), and 16 more registers cost the training chain 40 % beside it
+            if (!second) {                                   // wave-uniform: first row of the pair -> stash
 #pragma unroll
-            for (int pb = 0; pb < NPB; ++pb) {
-                const isk_f32x2 sv = {xh[2 * pb] * sc, xh[2 * pb + 1] * sc};
-                const isk_f16x2 hi = __builtin_convertvector(sv, isk_f16x2);
-                const isk_f16x2 lo = __builtin_convertvector(sv - __builtin_convertvector(hi, isk_f32x2), isk_f16x2);
-                const int off = 512 * pb + (lane >> 4) * 128 + (lane & 15) * 4;   // chunk 4 pb + lane/16, pair lane%16
-                isk_raw_buffer_store_u32(__builtin_bit_cast(unsigned, hi), ro, off, 0, FEAT_AUX);
-                isk_raw_buffer_store_u32(__builtin_bit_cast(unsigned, lo), ro, off + 64, 0, FEAT_AUX);
+                for (int pb = 0; pb < NPB; ++pb) {
+                    const isk_f32x2 sv = {xh[2 * pb] * sc, xh[2 * pb + 1] * sc};
+                    const isk_f16x2 hi = __builtin_convertvector(sv, isk_f16x2);
+                    const isk_f16x2 lo = __builtin_convertvector(sv - __builtin_convertvector(hi, isk_f32x2), isk_f16x2);
+                    stash[pb * 64 + lane] = (u32x2){__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo)};
+                }
+            } else {
+                const isk_i32x4 ra = plane_rv(srow - 1), rb = plane_rv(srow);
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb) {
+                    const u32x2 fa = stash[pb * 64 + lane];                            // same lane wrote it: no barrier needed
+                    const isk_f32x2 sv = {xh[2 * pb] * sc, xh[2 * pb + 1] * sc};
+                    const isk_f16x2 hi = __builtin_convertvector(sv, isk_f16x2);
+                    const isk_f16x2 lo = __builtin_convertvector(sv - __builtin_convertvector(hi, isk_f32x2), isk_f16x2);
+                    const int off = (4 * pb + (lane >> 4)) * 2048 + (lane & 15) * 4;  // chunk 4 pb + lane/16, pair lane%16
+                    isk_raw_buffer_store_u32(fa[0], ra, off, 0, FEAT_AUX);
+                    isk_raw_buffer_store_u32(__builtin_bit_cast(unsigned, hi), rb, off, 0, FEAT_AUX);
+                    isk_raw_buffer_store_u32(fa[1], ra, off + 1024, 0, FEAT_AUX);
+                    isk_raw_buffer_store_u32(__builtin_bit_cast(unsigned, lo), rb, off + 1024, 0, FEAT_AUX);
+                }
             }
             if (lane == 0 && srow < a.S) a.xscale[srow] = inv;
         } else {
@@ -296,17 +337,19 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
         if (a.stats && lane == 0 && srow < a.S) { a.stats[2 * srow] = mu; a.stats[2 * srow + 1] = rstd; }
     };
 #pragma unroll
-    for (int p = 0; p < PF; ++p) fetch(nxt[p], s + p * nw);
-    for (; s < a.S; s += PF * nw) {              // rows past the end (last trip) run on empty descriptors
+    for (int p = 0; p < PF; ++p) fetch(nxt[p], row_of(p));
+    // rows past the end (the last trips) run on empty descriptors; PLANES: a pair is entered when its even row exists
+    for (long long t = 0; row_of(PLANES ? (t & ~1LL) : t) < a.S; t += PF) {
 #pragma unroll
-        for (int p = 0; p < PF; ++p) one(nxt[p], s + p * nw);
+        for (int p = 0; p < PF; ++p) one(nxt[p], row_of(t + p), row_of(t + p + PF), (int)((t + p) & 1));
     }
 }
 
 template <int NFL, int NDL>
 static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream_t st) {
     const bool pd = a.pairs != nullptr;
-    const size_t lds = pd ? (size_t)4 * (a.D / 3) * 16 : 0;
+    // wave-private coordinate cells + (planes) the stash of a row pair's first row
+    const size_t lds = (pd ? (size_t)4 * (a.D / 3) * 16 : 0) + (a.planes ? (size_t)4 * (NFL / 2) * 64 * 8 : 0);
     // waves per CU bounded by the wave-private LDS image (160 KiB) and by 16 (4 per SIMD)
     static const int cap_env = [] { const char* v = getenv("ISK_FEAT_WG_PER_CU"); return v ? atoi(v) : 1; }();
     // background launches (beside the training kernels) run ONE self-pipelined workgroup per CU: measured
@@ -320,6 +363,7 @@ static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream
     long long cap = (long long)ISK_NUM_CU * wg_per_cu;
     static const int bg_total = [] { const char* v = getenv("ISK_FEAT_BG_WGS"); return v ? atoi(v) : 0; }();
     if (a.background && bg_total > 0) cap = bg_total;          // tuning knob: background workgroups in total
+    if (a.background > 1) cap = a.background;                  // the caller names the workgroup count (early share beside the forward)
     if (blocks > cap) blocks = cap;
     void* args[] = {(void*)&a, (void*)&packed};
     if (pd) {
@@ -333,7 +377,7 @@ static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream
         (void)hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), args, lds, st);
     } else {
         const void* fn = a.planes ? (const void*)featurize_reg_kernel<NFL, 1, false, 1, true> : (const void*)featurize_reg_kernel<NFL, 1, false, 1, false>;
-        (void)hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), args, 0, st);
+        (void)hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), args, lds, st);
     }
 }
 

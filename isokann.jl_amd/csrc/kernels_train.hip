@@ -54,6 +54,22 @@ __device__ __attribute__((noinline)) float t_dact(int act, float z, float a) {
     }
 }
 
+// diagnostic build -DISK_KSTAMP: every training kernel's first workgroup appends (kernel id, s_memrealtime) to a ring --
+// the start times of consecutive launches WITHOUT a profiler attached (scripts/kstamps.py)
+#ifdef ISK_KSTAMP
+__device__ unsigned long long g_kstamps[2048];
+__device__ unsigned g_kstamp_n;
+extern "C" void isk_debug_kstamps(unsigned long long* out, unsigned* n) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kstamps), sizeof(unsigned long long) * 2048);
+    (void)hipMemcpyFromSymbol(n, HIP_SYMBOL(g_kstamp_n), sizeof(unsigned));
+}
+#define KSTAMP(id) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { \
+        const unsigned k_ = atomicAdd(&g_kstamp_n, 1u); \
+        g_kstamps[k_ & 2047] = ((unsigned long long)(id) << 56) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffffffffull); } } while (0)
+#else
+#define KSTAMP(id) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------ train_fwd1 -------
 // grid (units, nt1); workgroup = FW1_WAVES waves splitting the feature (K) axis of one 16x16
 // output tile; every wave issues the loads of up to FW1_GROUP chunks before its MFMAs (the step
@@ -143,6 +159,7 @@ void isk_launch_gemm_rows(const float* X, int ldx, const float* Wt, const float*
 template <int NTB, bool LN>
 __global__ __launch_bounds__(FW1N_WAVES * 64, 4) void train_fwd1n_kernel(Fwd1nArgs a) {
     ISK_LATENCY_CHAIN_PRIO();
+    KSTAMP(1);
     extern __shared__ __attribute__((aligned(16))) float red[];          // [4 wave pairs][2 units][NTB][256]: 40 KB at NTB = 5
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -371,6 +388,7 @@ struct TailDesc {
 __global__ __launch_bounds__(TAIL_THREADS, 4) void train_tail_kernel(TailDesc d, TrainBuffers b, const int* __restrict__ perm,
                                                                   int B, float inv_div) {
     ISK_LATENCY_CHAIN_PRIO();
+    KSTAMP(2);
     TSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float lred[TAIL_THREADS / 64];
@@ -706,6 +724,7 @@ template <int NT, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm,
                                                               int B, int nparts) {
     ISK_LATENCY_CHAIN_PRIO();
+    KSTAMP(3);
     GSTAMP(0);
     constexpr int NB4 = NT / 4, NR = NT % 4;
     constexpr int CB = 4;                          // chunks per batch: their row indices are fetched together
@@ -899,6 +918,7 @@ static_assert(sizeof(OptArgs) <= 128, "OptArgs: two kernarg cache lines");
 __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
     double* const loss_acc = a.loss_acc;
     ISK_LATENCY_CHAIN_PRIO();
+    KSTAMP(4);
     const float bc1 = a.bt ? (float)(1.0 - a.bt[0]) : a.bc1, bc2 = a.bt ? (float)(1.0 - a.bt[1]) : a.bc2;
     const float lstep = a.grad[a.n];
     const bool bad = (loss_acc[1] != 0.0) || !isfinite(lstep);
