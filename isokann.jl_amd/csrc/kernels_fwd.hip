@@ -149,17 +149,23 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 // together behind the second one -- the two halves of every line leave in consecutive store instructions of one wave,
 // as the hi / lo halves of a row-major line did (stored a row apart -- 3.5 us under the throttle -- the half lines were
 // written back separately: featurizer 0.73 -> 0.82 ms, training beside it 0.69 -> 0.78).
-template <int NFL, int NDL, bool PDIST, int PF = 1, bool PLANES = false>
+// TIGHT: F > 64 (NFL - 2), i.e. only a lane's LAST feature pair can lie past the end of the row -- the validity select
+// (one per feature and use otherwise) is compiled for those two registers only.  The kernel runs throttled to one wave
+// per SIMD beside the training kernels, where its time is its instruction count (~930 per row before this, the selects
+// and the predicated coordinate writes ~150 of them).
+template <int NFL, int NDL, bool PDIST, int PF = 1, bool PLANES = false, bool TIGHT = false>
 __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const unsigned* __restrict__ packed_pairs) {
     static_assert(NFL % 2 == 0, "a lane holds adjacent feature pairs");
     constexpr int NPB = NFL / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int natoms = a.D / 3;
-    f32x4* cw = (f32x4*)smem + (size_t)wave * natoms;        // wave-private xyzw coordinates
+    f32x4* cw = (f32x4*)smem + (size_t)wave * (natoms + 1);  // wave-private xyzw coordinates (+ one cell that takes the lanes past the last atom)
     // PLANES: behind the coordinates, per wave NPB x 64 (hi, lo) dword pairs of the pair's first row
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    u32x2* stash = (u32x2*)((f32x4*)smem + (PDIST ? 4 * (size_t)natoms : 0)) + (size_t)wave * (NPB * 64);
+    u32x2* stash = (u32x2*)((f32x4*)smem + (PDIST ? 4 * (size_t)(natoms + 1) : 0)) + (size_t)wave * (NPB * 64);
+    // feature i of this lane exists (padding features: pair (0, 0) / a load past the row's end, i.e. d == 0)
+    auto ok = [&](int i) { return (TIGHT && i < NFL - 2) ? true : 128 * (i >> 1) + 2 * lane + (i & 1) < a.F; };
     unsigned pr[NFL];
     if (PDIST) {
 #pragma unroll
@@ -231,9 +237,9 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
         float d[NFL];
         if (PDIST) {
 #pragma unroll
-            for (int u = 0; u < NAL; ++u) {
+            for (int u = 0; u < NAL; ++u) {                 // unpredicated: lanes past the last atom (they loaded zeros) share a spare cell
                 const int at = 64 * u + lane;
-                if (at < natoms) ((f32x3*)cw)[at] = (f32x3){buf[3 * u], buf[3 * u + 1], buf[3 * u + 2]};
+                ((f32x3*)cw)[at < natoms ? at : natoms] = (f32x3){buf[3 * u], buf[3 * u + 1], buf[3 * u + 2]};
             }
         } else {
 #pragma unroll
@@ -263,37 +269,41 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
             __builtin_amdgcn_wave_barrier();             // all reads issued before the next trip's writes
         }
         float mu = 0.f, rstd = 1.f;
+        float tt[NFL];                                       // d - mu, 0 for padding features
         if (a.normalize) {
             float sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < NFL; ++i) sum += (128 * (i >> 1) + 2 * lane + (i & 1) < a.F) ? d[i] : 0.f;
+            for (int i = 0; i < NFL; ++i) sum += d[i];       // padding features are exactly 0
             mu = wave_sum_dpp(sum) * invF;
             float ss = 0.f;
 #pragma unroll
             for (int i = 0; i < NFL; ++i) {
-                const float t = d[i] - mu;
-                ss += (128 * (i >> 1) + 2 * lane + (i & 1) < a.F) ? t * t : 0.f;
+                tt[i] = ok(i) ? d[i] - mu : 0.f;
+                ss = fmaf(tt[i], tt[i], ss);
             }
             const float var = wave_sum_dpp(ss) * invF;
             if (a.ln_mode == ISK_LN_VAR_EPS2) rstd = 1.0f / sqrtf(var + a.eps * a.eps);
             else if (a.ln_mode == ISK_LN_STD_EPS) rstd = 1.0f / (sqrtf(var) + a.eps);
             else rstd = 1.0f / sqrtf(var + a.eps);
-        }
-        float xh[NFL];
+        } else {
 #pragma unroll
-        for (int i = 0; i < NFL; ++i) xh[i] = (128 * (i >> 1) + 2 * lane + (i & 1) < a.F) ? (d[i] - mu) * rstd : 0.f;
+            for (int i = 0; i < NFL; ++i) tt[i] = d[i];
+        }
         if (PLANES) {
+            // xhat = tt * rstd; its row maximum is rstd * max|tt| (rounding is monotone), and the plane scale 2^s folds into
+            // one factor with rstd (a power of two: the same bits as scaling xhat afterwards)
             float m = 0.f;
 #pragma unroll
-            for (int i = 0; i < NFL; ++i) m = fmaxf(m, fabsf(xh[i]));
+            for (int i = 0; i < NFL; ++i) m = fmaxf(m, fabsf(tt[i]));
             float sc, inv;
-            isk_f16_scale(wave_max_dpp(m), sc, inv);
+            isk_f16_scale(wave_max_dpp(m) * rstd, sc, inv);
+            const float s2 = rstd * sc;
             // no arrays of converted values here: the kernel sits at the register limit that lets two 128-register training
             // waves share a SIMD with it (248 of 512), and 16 more registers cost the training chain 40 % beside it
             if (!second) {                                   // wave-uniform: first row of the pair -> stash
 #pragma unroll
                 for (int pb = 0; pb < NPB; ++pb) {
-                    const isk_f32x2 sv = {xh[2 * pb] * sc, xh[2 * pb + 1] * sc};
+                    const isk_f32x2 sv = {tt[2 * pb] * s2, tt[2 * pb + 1] * s2};
                     const isk_f16x2 hi = __builtin_convertvector(sv, isk_f16x2);
                     const isk_f16x2 lo = __builtin_convertvector(sv - __builtin_convertvector(hi, isk_f32x2), isk_f16x2);
                     stash[pb * 64 + lane] = (u32x2){__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo)};
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
 #pragma unroll
                 for (int pb = 0; pb < NPB; ++pb) {
                     const u32x2 fa = stash[pb * 64 + lane];                            // same lane wrote it: no barrier needed
-                    const isk_f32x2 sv = {xh[2 * pb] * sc, xh[2 * pb + 1] * sc};
+                    const isk_f32x2 sv = {tt[2 * pb] * s2, tt[2 * pb + 1] * s2};
                     const isk_f16x2 hi = __builtin_convertvector(sv, isk_f16x2);
                     const isk_f16x2 lo = __builtin_convertvector(sv - __builtin_convertvector(hi, isk_f32x2), isk_f16x2);
                     const int off = (4 * pb + (lane >> 4)) * 2048 + (lane & 15) * 4;  // chunk 4 pb + lane/16, pair lane%16
@@ -318,20 +328,20 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
             const isk_i32x4 ro = row_rv(a.xhat, srow, a.Fp, a.Fp);
 #pragma unroll
             for (int pb = 0; pb < NPB; ++pb)
-                isk_raw_buffer_store_f32x2((isk_f32x2){xh[2 * pb], xh[2 * pb + 1]}, ro, (128 * pb + 2 * lane) * 4, 0, FEAT_AUX);
+                isk_raw_buffer_store_f32x2((isk_f32x2){tt[2 * pb] * rstd, tt[2 * pb + 1] * rstd}, ro, (128 * pb + 2 * lane) * 4, 0, FEAT_AUX);
         }
         if (a.xhat32 && srow >= a.x32_first) {               // wave-uniform: a second, f32 copy (the xs rows the training kernels read)
             const isk_i32x4 r32 = row_rv(a.xhat32, srow - a.x32_first, a.Fp, srow < a.S ? a.Fp : 0);
 #pragma unroll
             for (int pb = 0; pb < NPB; ++pb)
-                isk_raw_buffer_store_f32x2((isk_f32x2){xh[2 * pb], xh[2 * pb + 1]}, r32, (128 * pb + 2 * lane) * 4, 0, 0);
+                isk_raw_buffer_store_f32x2((isk_f32x2){tt[2 * pb] * rstd, tt[2 * pb + 1] * rstd}, r32, (128 * pb + 2 * lane) * 4, 0, 0);
         }
         if (a.raw) {                                         // wave-uniform: kept for the coordinate pullback
             const isk_i32x4 rr = row_rv(a.raw, srow, a.Fp, a.Fp);
 #pragma unroll
             for (int pb = 0; pb < NPB; ++pb) {
                 const int f = 128 * pb + 2 * lane;
-                isk_raw_buffer_store_f32x2((isk_f32x2){(f < a.F) ? d[2 * pb] : 0.f, (f + 1 < a.F) ? d[2 * pb + 1] : 0.f}, rr, f * 4, 0, 0);
+                isk_raw_buffer_store_f32x2((isk_f32x2){d[2 * pb], d[2 * pb + 1]}, rr, f * 4, 0, 0);     // padding features are exactly 0
             }
         }
         if (a.stats && lane == 0 && srow < a.S) { a.stats[2 * srow] = mu; a.stats[2 * srow + 1] = rstd; }
@@ -349,7 +359,8 @@ template <int NFL, int NDL>
 static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream_t st) {
     const bool pd = a.pairs != nullptr;
     // wave-private coordinate cells + (planes) the stash of a row pair's first row
-    const size_t lds = (pd ? (size_t)4 * (a.D / 3) * 16 : 0) + (a.planes ? (size_t)4 * (NFL / 2) * 64 * 8 : 0);
+    const size_t lds = (pd ? (size_t)4 * (a.D / 3 + 1) * 16 : 0) + (a.planes ? (size_t)4 * (NFL / 2) * 64 * 8 : 0);
+    const bool tight = a.F > 64 * (NFL - 2);     // only the last feature pair of a lane can be padding
     // waves per CU bounded by the wave-private LDS image (160 KiB) and by 16 (4 per SIMD)
     static const int cap_env = [] { const char* v = getenv("ISK_FEAT_WG_PER_CU"); return v ? atoi(v) : 1; }();
     // background launches (beside the training kernels) run ONE self-pipelined workgroup per CU: measured
@@ -370,7 +381,8 @@ static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream
         // background launches keep two samples in flight per wave (ISK_FEAT_PF=1: one).  Measured on C3, same box:
         // 1.554 -> 1.533 ms/step; three in flight: 1.558
         static const int pf = [] { const char* v = getenv("ISK_FEAT_PF"); return v ? atoi(v) : 1; }();
-        const void* fn = a.planes ? (const void*)featurize_reg_kernel<NFL, NDL, true, 1, true> : (const void*)featurize_reg_kernel<NFL, NDL, true, 1, false>;
+        const void* fn = a.planes ? (tight ? (const void*)featurize_reg_kernel<NFL, NDL, true, 1, true, true> : (const void*)featurize_reg_kernel<NFL, NDL, true, 1, true>)
+                                  : (const void*)featurize_reg_kernel<NFL, NDL, true, 1, false>;
         if (a.background && pf == 2)
             fn = a.planes ? (const void*)featurize_reg_kernel<NFL, NDL, true, 2, true> : (const void*)featurize_reg_kernel<NFL, NDL, true, 2, false>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
