@@ -261,9 +261,12 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
             for (int i = 0; i < NFL; ++i) {
                 __builtin_amdgcn_sched_barrier(0);
                 const f32x3 pa = qa[i % GW], pb = qb[i % GW];
-                const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+                // (x, y) as one packed subtract and one packed multiply: 5 VALU operations per distance instead of 6
+                const isk_f32x2 dxy = (isk_f32x2){pa[0], pa[1]} - (isk_f32x2){pb[0], pb[1]};
+                const float dz = pa[2] - pb[2];
                 if (i + GW < NFL) { qa[i % GW] = cw3[pr[i + GW] & 0xffffu]; qb[i % GW] = cw3[pr[i + GW] >> 16]; }
-                d[i] = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
+                const isk_f32x2 sq = dxy * dxy;
+                d[i] = __builtin_amdgcn_sqrtf(fmaf(dz, dz, sq[0]) + sq[1]);
             }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_wave_barrier();             // all reads issued before the next trip's writes
@@ -271,17 +274,21 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
         float mu = 0.f, rstd = 1.f;
         float tt[NFL];                                       // d - mu, 0 for padding features
         if (a.normalize) {
-            float sum = 0.f;
+            // a lane's feature pairs as packed operands: half the adds / fmas
+            isk_f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < NFL; ++i) sum += d[i];       // padding features are exactly 0
-            mu = wave_sum_dpp(sum) * invF;
-            float ss = 0.f;
+            for (int pb = 0; pb < NPB; ++pb) sum2 += (isk_f32x2){d[2 * pb], d[2 * pb + 1]};      // padding features are exactly 0
+            mu = wave_sum_dpp(sum2[0] + sum2[1]) * invF;
+            isk_f32x2 ss2 = {0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < NFL; ++i) {
-                tt[i] = ok(i) ? d[i] - mu : 0.f;
-                ss = fmaf(tt[i], tt[i], ss);
+            for (int pb = 0; pb < NPB; ++pb) {
+                isk_f32x2 t2 = (isk_f32x2){d[2 * pb], d[2 * pb + 1]} - (isk_f32x2){mu, mu};
+                if (!ok(2 * pb)) t2[0] = 0.f;
+                if (!ok(2 * pb + 1)) t2[1] = 0.f;
+                tt[2 * pb] = t2[0]; tt[2 * pb + 1] = t2[1];
+                ss2 += t2 * t2;
             }
-            const float var = wave_sum_dpp(ss) * invF;
+            const float var = wave_sum_dpp(ss2[0] + ss2[1]) * invF;
             if (a.ln_mode == ISK_LN_VAR_EPS2) rstd = 1.0f / sqrtf(var + a.eps * a.eps);
             else if (a.ln_mode == ISK_LN_STD_EPS) rstd = 1.0f / (sqrtf(var) + a.eps);
             else rstd = 1.0f / sqrtf(var + a.eps);
