@@ -341,6 +341,29 @@ def test_run_full_batch_chi_within_1e5(gpu_pkg):
 
 
 @pytest.mark.parametrize("every_iter", [False, True])
+@pytest.mark.parametrize("N,K,nout", [(37, 3, 1), (21, 5, 3), (17, 1, 1), (33, 7, 3)])
+def test_run_when_ys_and_xs_rows_share_a_plane_unit(gpu_pkg, N, K, nout, every_iter):
+    """the split-f16 operand planes are stored in units of 16 rows over the [ys; xs] slab (isk_plane_off): N*K odd or not a
+    multiple of 16 puts the xs rows in the middle of a unit and the featurizer's row pairs across the ys / xs boundary;
+    the side-stream launch of the per-iteration mode covers both parts in one go, the resident one in two"""
+    pkg = gpu_pkg
+    data, odata, om = _coords_case(pkg, 13, 45, N, K, nout, seed=300 + N)
+    tgt, otgt = (pkg.TransformShiftscale(), O.TransformShiftscale()) if nout == 1 else (pkg.TransformISA(), O.TransformISA())
+    iso = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(1e-2, 1e-3), target=tgt, minibatch=8,
+                  featurize_every_iteration=every_iter)
+    oiso = O.Iso(odata, om, O.setup(O.AdamRegularized(1e-2, 1e-3), om), target=otgt, minibatch=8)
+    np.testing.assert_allclose(pkg.chis(iso), O.chis(oiso), atol=2e-5)
+    np.testing.assert_allclose(pkg.koopman(iso), O.expectation(om, odata.features[1]), atol=2e-5)
+    rng = np.random.default_rng(N)
+    perms = np.stack([rng.permutation(N) for _ in range(6)])
+    pkg.run(iso, 6, 1, perms=perms)                     # >= 4 optimizer steps per iteration: the side-stream featurizer is used
+    O.run(oiso, 6, 1, perms=list(perms))
+    np.testing.assert_allclose(iso.losses, oiso.losses, rtol=2e-3)
+    np.testing.assert_allclose(pkg.chis(iso), O.chis(oiso), atol=2e-4)
+    iso.close()
+
+
+@pytest.mark.parametrize("every_iter", [False, True])
 @pytest.mark.parametrize("name", ["c1_shiftscale_nesterov", "c2small_shiftscale_adam", "c3small_isa_adam"])
 def test_run_matches_golden(gpu_pkg, name, every_iter):
     pkg = gpu_pkg
