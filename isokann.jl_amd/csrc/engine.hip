@@ -117,8 +117,8 @@ struct isk_engine {
     hipStream_t copy = nullptr;       // small H2D staging (the epoch's shuffle order): never queued behind the side-stream featurizer
     hipEvent_t ev_fwd_done = nullptr, ev_ys_ready = nullptr;
     long long side_after_forward = 0;   // isk_run / isk_dp_run: launch the side-stream ys featurization right behind the forward
-    long long early_rows = 0;           // rows of the next iteration already featurized beside THIS iteration's forward (ISK_FEAT_EARLY_PCT)
                                         // kernel (value = optimizer steps of the coming training phase), not after the target kernels
+    long long early_rows = 0;           // rows of the next iteration already featurized beside THIS iteration's forward (ISK_FEAT_EARLY_PCT)
     bool ys_ahead = false;       // a side-stream featurization of ys is in flight / complete
     // parameters
     float *d_theta = nullptr, *d_grad = nullptr, *d_m = nullptr, *d_v = nullptr;
