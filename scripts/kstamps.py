@@ -10,7 +10,7 @@ c = synth.WORKLOADS["c3"]
 xs, ys = synth.synthetic_coords(c["atoms"], c["N"], c["K"], seed=0)
 feat = pkg.FeaturesPairs(synth.random_pairs(c["atoms"], c["feat"], seed=0))
 iso = pkg.Iso(pkg.SimulationData(xs, ys, feat), model=pkg.densenet(pkg.pairnet_widths(c["feat"], nout=3), layernorm=True),
-              opt=pkg.AdamRegularized(), minibatch=1000, forward_mode=3, featurize_every_iteration="--cached" not in sys.argv)
+              opt=pkg.AdamRegularized(), minibatch=int(os.environ.get("KS_MB", "1000")), forward_mode=3, featurize_every_iteration="--cached" not in sys.argv)
 pkg.run(iso, 12, 1)
 lib = iso._lib
 buf = (ctypes.c_ulonglong * 2048)()
