@@ -1,7 +1,8 @@
 """Two ranks of the data-parallel driver on ONE GPU (each process owns an engine on cuda:0 and half of the start
 points; collectives through a gloo group, staged via the host): the host-driven isk_dp_* hooks at P = 2 must reproduce
-the single-process isk_run on the full data with the equivalent global shuffle.  (The native RCCL driver cannot be run
-with two ranks on one device -- RCCL rejects duplicate GPUs -- and is covered at P = 1 in test_gpu_parity.py.)"""
+the single-process isk_run on the full data with the equivalent global shuffle.  (The native driver -- collectives issued by
+the engine -- runs with two ranks on one device through a mock collective library: test_gpu_dp_native2.py; real RCCL rejects
+duplicate GPUs and is covered at P = 1 in test_gpu_parity.py.)"""
 import os
 import socket
 import sys
@@ -38,12 +39,12 @@ def _problem(nout):
     return xs, ys, pairs, widths, om.get_flat().astype(np.float32)
 
 
-def _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, minibatch):
+def _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, minibatch, every_iter=False):
     model = pkg.densenet(widths, layernorm=True)
     model.params = theta
     tr = pkg.TransformShiftscale() if nout == 1 else pkg.TransformISA()
     return pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=model, opt=pkg.AdamRegularized(1e-2, 1e-3),
-                   target=tr, minibatch=minibatch)
+                   target=tr, minibatch=minibatch, featurize_every_iteration=every_iter)
 
 
 def _worker(rank, world, port, nout, minibatch, niter, outdir):

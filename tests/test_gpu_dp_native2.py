@@ -32,7 +32,7 @@ def mock_lib():
     return out
 
 
-def _worker(rank, world, port, nout, minibatch, niter, epochs, outdir, mock):
+def _worker(rank, world, port, nout, minibatch, niter, epochs, outdir, mock, every_iter):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ISK_RCCL_LIB=mock)
     if rank == 0:
         os.environ["ISK_MOCK_RCCL_COUNT_FILE"] = os.path.join(outdir, "ncalls.txt")
@@ -49,7 +49,7 @@ def _worker(rank, world, port, nout, minibatch, niter, epochs, outdir, mock):
         xs, ys, pairs, widths, theta = _problem(nout)
         lo, hi = dp.shard_bounds(xs.shape[1], world, rank)
         torch.cuda.set_device(0)
-        iso = _mk_iso(pkg, xs[:, lo:hi], ys[:, :, lo:hi], pairs, widths, theta, nout, minibatch)
+        iso = _mk_iso(pkg, xs[:, lo:hi], ys[:, :, lo:hi], pairs, widths, theta, nout, minibatch, every_iter)
         local = dp.HipLocal(iso, use_torch_stream=False)
         # the communicator hand-shake of HipLocal.comm_init_native, with gloo carrying the 128 bytes
         ident = np.zeros(128, np.uint8)
@@ -70,13 +70,23 @@ def _worker(rank, world, port, nout, minibatch, niter, epochs, outdir, mock):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nout,minibatch,epochs", [(1, 64, 1), (3, 64, 1), (3, 0, 1), (3, 48, 2)])
-def test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, nout, minibatch, epochs):
+def test_native_driver_two_ranks_every_forward_mode(gpu_pkg, mock_lib, fwd_mode):
+    """what bench.py runs on a multi-GPU node -- ISA target, featurization inside every iteration, the side-stream featurizer
+    beside the training steps and the collectives -- in the f32, split-bf16 and split-f16 (unit-blocked operand planes)
+    forward modes (ISK_FWD_MODE is inherited by the ranks)"""
+    test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, 3, 16, 1, True)
+
+
+@pytest.mark.parametrize("nout,minibatch,epochs,every_iter", [(1, 64, 1, False), (3, 64, 1, False), (3, 0, 1, False), (3, 48, 2, False),
+                                                             (1, 16, 2, True)])
+def test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, nout, minibatch, epochs, every_iter):
+    """every_iter: featurization inside every iteration, i.e. the side-stream featurizer beside the training steps and the
+    collectives (what bench.py runs on a multi-GPU node); minibatch 16 gives the >= 4 optimizer steps that switch it on"""
     import torch.multiprocessing as mp
     pkg = gpu_pkg
     world, niter = 2, 3
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), nout, minibatch, niter, epochs, d, mock_lib), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), nout, minibatch, niter, epochs, d, mock_lib, every_iter), nprocs=world, join=True)
         r = [np.load(os.path.join(d, f"r{k}.npz")) for k in range(world)]
         ncalls = int(open(os.path.join(d, "ncalls.txt")).read())
     np.testing.assert_array_equal(r[0]["losses"], r[1]["losses"])      # rank-ordered reduction: the same bits everywhere
@@ -91,7 +101,7 @@ def test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, nout, m
     for k in range(niter * epochs):
         head = np.concatenate([np.concatenate([int(x["lo"]) + x["perms"][k][b * bl:(b + 1) * bl] for x in r]) for b in range(nb)])
         gperms.append(np.concatenate([head, np.setdiff1d(np.arange(N), head)]))
-    ref = _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, gb if minibatch else 0)
+    ref = _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, gb if minibatch else 0, every_iter)
     pkg.run(ref, niter, epochs, perms=np.stack(gperms))
     np.testing.assert_allclose(r[0]["losses"], ref.losses, rtol=2e-4)
     got, want = r[0]["params"], ref.model.get_params()
