@@ -182,6 +182,19 @@ def main():
         def barrier():
             dist.barrier()
 
+    watchdog = None
+    if use_dp and world > 1:
+        # a collective that a peer never joins blocks inside the engine for good (there is nothing to catch): leave with a
+        # diagnostic instead of hanging until the launcher's own limit kills the job
+        import threading
+
+        def _bail():
+            print(f"[bench] rank {rank}: no progress for {int(os.environ.get('ISK_BENCH_WATCHDOG_S', '420'))} s in the data-parallel run "
+                  "(a collective is waiting for a peer?) -- aborting", file=sys.stderr, flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(float(os.environ.get("ISK_BENCH_WATCHDOG_S", "420")), _bail)
+        watchdog.daemon = True
+        watchdog.start()
     if use_dp and world > 1:
         # safety valve for the first step on a real multi-GPU node: if the engine-driven RCCL run raises (on every rank alike:
         # e.g. a communicator that cannot be used), agree on it and continue on the host-driven torch.distributed hooks
@@ -203,6 +216,8 @@ def main():
     step(args.steps)
     sync(); barrier(); sync()
     dt = time.perf_counter() - t0
+    if watchdog is not None:
+        watchdog.cancel()
     if use_dp:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
