@@ -2206,6 +2206,8 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;          // optional: the two gathers of the ISA target go out as one group
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi g_rccl;
@@ -2233,6 +2235,9 @@ int rccl_load() {
     a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
     a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
+    if (!a.GroupStart || !a.GroupEnd) a.GroupStart = a.GroupEnd = nullptr;
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.AllGather || !a.GetErrorString)
         return fail(ISK_EUNSUPPORTED, "librccl.so lacks a required symbol");
     g_rccl = a;
@@ -2319,8 +2324,12 @@ static int dp_target_native(isk_engine* e) {            // the caller has run fe
             HIPCHK(hipMalloc((void**)&e->d_gchi, (size_t)n_global * d * sizeof(float)));
             e->gather_rows = n_global;
         }
-        RCCLCHK(g_rccl.AllGather(ks, e->d_gks, (size_t)e->N * d, ncclFloat, e->comm, e->stream));
-        RCCLCHK(g_rccl.AllGather(chi, e->d_gchi, (size_t)e->N * d, ncclFloat, e->comm, e->stream));
+        // one group: RCCL aggregates the two small gathers into a single launch (each is latency, not bytes)
+        if (g_rccl.GroupStart) RCCLCHK(g_rccl.GroupStart());
+        const ncclResult_t r1 = g_rccl.AllGather(ks, e->d_gks, (size_t)e->N * d, ncclFloat, e->comm, e->stream);
+        const ncclResult_t r2 = g_rccl.AllGather(chi, e->d_gchi, (size_t)e->N * d, ncclFloat, e->comm, e->stream);
+        const ncclResult_t r3 = g_rccl.GroupEnd ? g_rccl.GroupEnd() : ncclSuccess;      // always closed, whatever r1 / r2 say
+        RCCLCHK(r1); RCCLCHK(r2); RCCLCHK(r3);
         ks = e->d_gks; chi = e->d_gchi;
     }
     return isk_dp_isa_dev(e, ks, chi, n_global, first);

@@ -1,7 +1,7 @@
 // TEST DOUBLE, not a product path.  A stand-in for librccl.so that lets TWO (or more) processes sharing ONE GPU run the
 // engine's native data-parallel driver (isk_dp_run): real RCCL rejects two ranks on one device ("Duplicate GPU
-// detected"), and the build loop has single-GPU boxes only.  It implements exactly the six entry points the engine
-// binds (engine.hip rccl_load) with host staging through a POSIX shared-memory segment: every collective drains the
+// detected"), and the build loop has single-GPU boxes only.  It implements exactly the entry points the engine
+// binds (engine.hip rccl_load: six, plus the optional group pair) with host staging through a POSIX shared-memory segment: every collective drains the
 // stream, copies the operand to the rank's slot, meets the other ranks at a barrier, reduces / concatenates in RANK ORDER
 // (so every rank computes the same bits) and copies the result back.  Slow and synchronous by design -- what it checks
 // is the engine's collective SEQUENCE, counts, offsets and shard arithmetic at world > 1, and that no rank leaves the
@@ -151,6 +151,10 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t sendcount, ncclD
     if (c->rank == 0) c->hdr()->ncalls.fetch_add(1);
     return ncclSuccess;
 }
+
+// groups: the mock's collectives are synchronous, a group is just its members in order
+ncclResult_t ncclGroupStart() { return ncclSuccess; }
+ncclResult_t ncclGroupEnd() { return ncclSuccess; }
 
 const char* ncclGetErrorString(ncclResult_t r) {
     switch (r) {
