@@ -748,24 +748,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(
     const int rr_ = tid & 3, lanep = (tid >> 2) & 63, lqp = lanep >> 4, lip = lanep & 15;
     const int k = ft * 16 + 4 * lqp + rr_;
     const float* W1n = b.theta + s.off_W[0] + (long long)ft * NT * 256;
-    // small-gradient partial vectors: one element per 16-lane group, lanes split the partials (slab 0 only)
-    if (slab == 0) {
-        const long long ngroups = (long long)gridDim.x * (NW * 4);
-        const long long grp = (long long)blockIdx.x * (NW * 4) + (tid >> 4);
-        for (long long e = grp; e < PS; e += ngroups) {
-            if (e >= 1 && e < 1 + H1) continue;     // D is rebuilt below
-            float acc = 0.f;
-            for (int w0 = li; w0 < nparts; w0 += 64) {       // 4 independent loads per lane in flight
-                float pv[4];
+    // small-gradient partial vectors: one element per 16-lane group, lanes split the partials (slab 0 only).  The loads of a
+    // group's (first) element go out HERE, ahead of the main loop's own loads, and are summed behind it: done in front of the
+    // loop the reduction was a memory round trip of its own for the first PS / 32 workgroups (2.2 us of the kernel's 15).
+    const long long red_groups = (long long)gridDim.x * (NW * 4);
+    const long long red_grp = (long long)blockIdx.x * (NW * 4) + (tid >> 4);
+    const bool red_pre = slab == 0 && red_grp < PS && !(red_grp >= 1 && red_grp < 1 + H1);
+    float red_pv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (red_pre) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int w = w0 + 16 * u; pv[u] = (w < nparts) ? b.part[(long long)w * PS + e] : 0.f; }
-                acc += (pv[0] + pv[1]) + (pv[2] + pv[3]);
-            }
-#pragma unroll
-            for (int sft = 8; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft, WAVE);
-            const long long gi = part_to_grad(s, e);
-            if (li == 0 && gi >= 0) gout[gi] = acc;
-        }
+        for (int u = 0; u < 4; ++u) { const int w = li + 16 * u; red_pv[u] = (w < nparts) ? b.part[(long long)w * PS + red_grp] : 0.f; }
     }
     GSTAMP(1);
     f32x4 acc[NT];
@@ -820,6 +812,24 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(
                     }
                 }
             }
+        }
+    }
+    if (slab == 0) {
+        for (long long e = red_grp; e < PS; e += red_groups) {
+            if (e >= 1 && e < 1 + H1) continue;     // D is rebuilt below
+            float racc = 0.f;
+            int w0 = li;
+            if (e == red_grp && red_pre) { racc = (red_pv[0] + red_pv[1]) + (red_pv[2] + red_pv[3]); w0 += 64; }
+            for (; w0 < nparts; w0 += 64) {          // 4 independent loads per lane in flight
+                float pv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int w = w0 + 16 * u; pv[u] = (w < nparts) ? b.part[(long long)w * PS + e] : 0.f; }
+                racc += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+            }
+#pragma unroll
+            for (int sft = 8; sft > 0; sft >>= 1) racc += __shfl_xor(racc, sft, WAVE);
+            const long long gi = part_to_grad(s, e);
+            if (li == 0 && gi >= 0) gout[gi] = racc;
         }
     }
     GSTAMP(2);
