@@ -931,7 +931,19 @@ __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
     KSTAMP(4);
     const float bc1 = a.bt ? (float)(1.0 - a.bt[0]) : a.bc1, bc2 = a.bt ? (float)(1.0 - a.bt[1]) : a.bc2;
     const float lstep = a.grad[a.n];
-    const bool bad = (loss_acc[1] != 0.0) || !isfinite(lstep);
+    const double collapsed = loss_acc[1];
+    // this thread's (first) parameter: its operands are requested before the batch loss is looked at -- waiting for the loss
+    // first put a second memory round trip in front of every update
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool in0 = i0 < a.n;
+    const long long ic = in0 ? i0 : 0;
+    const float th0 = a.theta[ic];
+    float gs0 = a.grad[ic];
+    if (ic < a.slab_prefix)                              // [LN | W1 | b1] gradients arrive split over row slabs
+        for (int sl = 1; sl < a.nslab; ++sl) gs0 += a.grad[(long long)sl * (a.n + 2) + ic];
+    const float m0 = a.m[ic];
+    const float v0 = a.kind == ISK_OPT_ADAM ? a.v[ic] : 0.f;
+    const bool bad = (collapsed != 0.0) || !isfinite(lstep);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         double acc0 = loss_acc[0];
         if (bad) loss_acc[1] = 1.0;
@@ -945,25 +957,27 @@ __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
         }
     }
     if (bad) return;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
-        const float th = a.theta[i];
-        float gs = a.grad[i];
-        if (i < a.slab_prefix)                           // [LN | W1 | b1] gradients arrive split over row slabs
-            for (int sl = 1; sl < a.nslab; ++sl) gs += a.grad[(long long)sl * (a.n + 2) + i];
+    auto update = [&](long long i, float th, float gs, float mi, float vi) {
         const float g = gs * a.gscale + a.reg * th;
         float d;
         if (a.kind == ISK_OPT_ADAM) {
-            const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
-            const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+            const float m = a.beta1 * mi + (1.f - a.beta1) * g;
+            const float v = a.beta2 * vi + (1.f - a.beta2) * g * g;
             a.m[i] = m;
             a.v[i] = v;
             d = m / bc1 / (sqrtf(v / bc2) + a.eps) * a.lr;
         } else {
-            const float vel = a.m[i];
-            d = -a.rho * a.rho * vel + (1.f + a.rho) * a.lr * g;
-            a.m[i] = a.rho * vel - a.lr * g;
+            d = -a.rho * a.rho * mi + (1.f + a.rho) * a.lr * g;
+            a.m[i] = a.rho * mi - a.lr * g;
         }
         a.theta[i] = th - d;
+    };
+    if (in0) update(i0, th0, gs0, m0, v0);
+    for (long long i = i0 + (long long)gridDim.x * 256; i < a.n; i += (long long)gridDim.x * 256) {
+        float gs = a.grad[i];
+        if (i < a.slab_prefix)                           // [LN | W1 | b1] gradients arrive split over row slabs
+            for (int sl = 1; sl < a.nslab; ++sl) gs += a.grad[(long long)sl * (a.n + 2) + i];
+        update(i, a.theta[i], gs, a.m[i], a.kind == ISK_OPT_ADAM ? a.v[i] : 0.f);
     }
 }
 
