@@ -273,6 +273,16 @@ __global__ __launch_bounds__(ISA_T) void isa_step_kernel(IsaArgs a, int j, const
     __shared__ double vrow[D];
     const long long N = a.N;
     double* X = a.work;
+    // this thread's rows do not depend on the argmax: requested before it is finalized (two dependent round trips and
+    // three barriers), not behind it
+    const long long base = (long long)blockIdx.x * ISA_ROWS + threadIdx.x;
+    double xv[ISA_R][D];
+#pragma unroll
+    for (int r = 0; r < ISA_R; ++r) {
+        const long long n = base + (long long)r * ISA_T;
+#pragma unroll
+        for (int k = 0; k < D; ++k) xv[r][k] = (n < N) ? X[n * D + k] : 0.0;
+    }
     finalize_argmax<D>(Pin, G, shd, shi, vrow, a.status, N);
     const double rn = shd[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) ind[j] = (int)shi[0];
@@ -282,14 +292,6 @@ __global__ __launch_bounds__(ISA_T) void isa_step_kernel(IsaArgs a, int j, const
     for (int k = 0; k < D; ++k) vr[k] = vrow[k] * inv;
     double bv = -1.0;
     long long bi = 0x7fffffffffffffffLL;
-    const long long base = (long long)blockIdx.x * ISA_ROWS + threadIdx.x;
-    double xv[ISA_R][D];
-#pragma unroll
-    for (int r = 0; r < ISA_R; ++r) {
-        const long long n = base + (long long)r * ISA_T;
-#pragma unroll
-        for (int k = 0; k < D; ++k) xv[r][k] = (n < N) ? X[n * D + k] : 0.0;
-    }
     __syncthreads();          // every thread holds its (old) rows before any row of this slab is overwritten
 #pragma unroll
     for (int r = 0; r < ISA_R; ++r) {
@@ -328,6 +330,15 @@ __global__ __launch_bounds__(ISA_T) void isa_target_kernel(IsaArgs a, const doub
     __shared__ int bad;
     const long long N = a.N;
     double* T = a.work + N * D;
+    // this thread's ks / chi rows: requested before the argmax is finalized and thread 0 inverts the simplex
+    const long long base = (long long)blockIdx.x * ISA_ROWS + threadIdx.x;
+    float kv[ISA_R][D], cv[ISA_R][D];
+#pragma unroll
+    for (int r = 0; r < ISA_R; ++r) {
+        const long long n = base + (long long)r * ISA_T;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { kv[r][k] = (n < N) ? a.ks[n * D + k] : 0.f; cv[r][k] = (n < N) ? a.chi[n * D + k] : 0.f; }
+    }
     finalize_argmax<D>(Pin, G, shd, shi, vrow, a.status, N);
     if (threadIdx.x == 0) {
         bad = 0;
@@ -390,14 +401,6 @@ __global__ __launch_bounds__(ISA_T) void isa_target_kernel(IsaArgs a, const doub
     double cst[D * D];
 #pragma unroll
     for (int i = 0; i < D * D; ++i) cst[i] = 0;
-    const long long base = (long long)blockIdx.x * ISA_ROWS + threadIdx.x;
-    float kv[ISA_R][D], cv[ISA_R][D];
-#pragma unroll
-    for (int r = 0; r < ISA_R; ++r) {
-        const long long n = base + (long long)r * ISA_T;
-#pragma unroll
-        for (int k = 0; k < D; ++k) { kv[r][k] = (n < N) ? a.ks[n * D + k] : 0.f; cv[r][k] = (n < N) ? a.chi[n * D + k] : 0.f; }
-    }
 #pragma unroll
     for (int r = 0; r < ISA_R; ++r) {
         const long long n = base + (long long)r * ISA_T;
@@ -441,6 +444,15 @@ __global__ __launch_bounds__(ISA_T) void isa_perm_kernel(IsaArgs a, const double
     __shared__ int psh[2 * D];
     const long long N = a.N;
     const double* T = a.work + N * D;
+    // this thread's target rows: requested before the cost sums and the permutation search
+    const long long base = (long long)blockIdx.x * ISA_ROWS + threadIdx.x;
+    double tv[ISA_R][D];
+#pragma unroll
+    for (int r = 0; r < ISA_R; ++r) {
+        const long long n = base + (long long)r * ISA_T;
+#pragma unroll
+        for (int k = 0; k < D; ++k) tv[r][k] = (n < N) ? T[n * D + k] : 0.0;
+    }
     if (threadIdx.x < D) rperm[threadIdx.x] = threadIdx.x;
     if (a.permute) {
         if (threadIdx.x < D * D) {
@@ -481,14 +493,6 @@ __global__ __launch_bounds__(ISA_T) void isa_perm_kernel(IsaArgs a, const double
     double mom[2 * D];
 #pragma unroll
     for (int i = 0; i < 2 * D; ++i) mom[i] = 0;
-    const long long base = (long long)blockIdx.x * ISA_ROWS + threadIdx.x;
-    double tv[ISA_R][D];
-#pragma unroll
-    for (int r = 0; r < ISA_R; ++r) {
-        const long long n = base + (long long)r * ISA_T;
-#pragma unroll
-        for (int k = 0; k < D; ++k) tv[r][k] = (n < N) ? T[n * D + k] : 0.0;
-    }
 #pragma unroll
     for (int r = 0; r < ISA_R; ++r) {
         const long long n = base + (long long)r * ISA_T;
