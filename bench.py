@@ -11,9 +11,12 @@ WeightDecay+Adam) on xs.   value = Koopman samples (N*K, summed over ranks) per 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W          (one rank per GPU, RCCL)
 
-Multi-GPU is WEAK scaling: every rank holds its own C3-sized shard (N=10000 starts, K=20) and a
-fixed per-rank minibatch, so the global batch is minibatch*N_gpus and the number of optimizer
-steps per epoch stays constant; one flat [gradient|loss] all-reduce per step.
+Multi-GPU (default) is STRONG scaling = BASELINE.json configs[3] (C4): the SAME villin problem -- global N = 10 000 start
+points, global minibatch 1000 -- sharded over the ranks in contiguous N-slabs (N/P starts and a 1000/P-row local batch per
+GPU), one flat [gradient | loss | flag] all-reduce per optimizer step; value = global N*K / step time.  `--scaling weak` gives
+every rank its own C3-sized shard and a fixed per-rank minibatch instead (global batch = minibatch * P).
+`--shard-of P` (one GPU): ONE rank's share of the P-way strong-scaled run -- N/P starts, local batch minibatch/P, every
+collective issued on a one-rank communicator -- to record its step time before a P-GPU node measures the real thing.
 """
 import argparse
 import json
@@ -30,9 +33,11 @@ if ROOT not in sys.path:
 import __graft_entry__ as ge  # noqa: E402
 
 
-def build_iso(pkg, wl, seed, device, args):
+def build_iso(pkg, wl, seed, device, args, n_local=None):
     from isokann_jl_amd import synth
-    c = synth.WORKLOADS[wl]
+    c = dict(synth.WORKLOADS[wl])
+    if n_local is not None:
+        c["N"] = n_local                 # this rank's N-slab (its own seed: the union over ranks is the global synthetic data set)
     xs, ys = synth.synthetic_coords(c["atoms"], c["N"], c["K"], seed=seed)
     if c["feat"] == "all":
         feat, F = pkg.FeaturesAll(), c["atoms"] * (c["atoms"] - 1) // 2
@@ -43,7 +48,8 @@ def build_iso(pkg, wl, seed, device, args):
     opt = pkg.AdamRegularized() if args.opt == "adam" else pkg.NesterovRegularized()
     data = pkg.SimulationData(xs, ys, feat)
     iso = pkg.Iso(data, opt=opt, model=model, minibatch=args.minibatch, device=device,
-                  featurize_every_iteration=not args.cached_features, seed=seed, forward_mode=args.forward_mode)
+                  featurize_every_iteration=not args.cached_features, seed=seed, forward_mode=args.forward_mode,
+                  options={"train_bf16": 1} if args.train_bf16 else None)
     del xs, ys
     return iso, c, widths
 
@@ -116,6 +122,13 @@ def main():
                     help="0 = f32 MFMA forward, 1 = split-bf16 (bf16x3, f32-equivalent), 2 = plain bf16 operands (reduced precision), "
                          "3 = split-f16 (f16x2, f32-equivalent; planes written by the featurizer)")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel driver even with one rank (rehearsal)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="multi-GPU: strong = the workload's global N and global minibatch sharded over the ranks (C4); weak = a full "
+                         "workload and a fixed minibatch per rank")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="P",
+                    help="one GPU: run ONE rank's share of the P-way strong-scaled run (N/P starts, local batch minibatch/P, collectives "
+                         "on a one-rank communicator)")
+    ap.add_argument("--train-bf16", action="store_true", help="wide networks (c5shard): training GEMMs on bf16 operands, f32 accumulate")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,7 +143,9 @@ def main():
         sys.exit("no HIP device for this rank: the product path has no CPU fallback")
 
     dist = None
-    use_dp = world > 1 or args.force_dp
+    if args.shard_of and world > 1:
+        sys.exit("--shard-of rehearses one rank's share on ONE GPU")
+    use_dp = world > 1 or args.force_dp or args.shard_of > 0
     real_stdout = None
     if use_dp:
         # RCCL prints a version banner on stdout; the driver wants exactly one JSON line there
@@ -146,10 +161,21 @@ def main():
 
     if args.forward_mode == 3 and args.workload == "c5shard":
         args.forward_mode = 1      # 512-wide layers run on the layered path, where a split-f16 request means the split-bf16 kernels
-    iso, c, widths = build_iso(pkg, args.workload, seed=rank, device=local_rank, args=args)
-    N, K = c["N"], c["K"]
-    bs = N if (args.minibatch == 0 or N < args.minibatch) else args.minibatch
-    nb_rows = (N // bs) * bs
+    from isokann_jl_amd import synth
+    n_global_wl = synth.WORKLOADS[args.workload]["N"]
+    parts = args.shard_of if args.shard_of else world                  # ranks the global problem is (or would be) sharded over
+    strong = parts > 1 and args.scaling == "strong"
+    if strong and n_global_wl % parts:
+        sys.exit(f"strong scaling needs equal shards: N = {n_global_wl} is not a multiple of {parts}")
+    if strong and args.minibatch and (args.minibatch % parts or args.minibatch < parts):
+        sys.exit(f"strong scaling splits the global minibatch over the ranks: {args.minibatch} is not a multiple of {parts}")
+    iso, c, widths = build_iso(pkg, args.workload, seed=rank, device=local_rank, args=args, n_local=n_global_wl // parts if strong else None)
+    N, K = c["N"], c["K"]                                             # per rank
+    n_global = n_global_wl if strong else N * world
+    gmb = args.minibatch if strong else args.minibatch * world        # global minibatch (0 = full batch)
+    bs_g = n_global if (gmb == 0 or n_global < gmb) else gmb
+    bl = N if bs_g == n_global else bs_g // parts                     # rows of a batch on this rank
+    nb_rows = (N // bl) * bl
 
     if not use_dp:
         def step(k=1):
@@ -167,14 +193,20 @@ def main():
         from isokann_jl_amd import dp
         comm = dp.Comm(device=torch.device("cuda", local_rank))
         local = dp.HipLocal(iso)
-        rng = np.random.default_rng(1000 + rank)
-        gmb = 0 if args.minibatch == 0 else args.minibatch * world       # fixed per-rank batch
         counts = dp.shard_counts(local, comm)
+        if args.shard_of:
+            # one rank of a P-way run on its own: the engine's collectives on the one-rank communicator, the batch plan of P ranks
+            iso.set_option("dp_force_coll", 1)
+            if not local.comm_init_native(comm):
+                sys.exit("--shard-of needs the native (RCCL) data-parallel run")
 
-        def step(k=1):
-            # rng=None: the engine draws the shuffle orders itself (seeded), hidden behind the forward, instead of ~0.15 ms of
-            # host work between two iterations
-            iso.losses.extend(dp.dp_run(local, comm, k, 1, gmb, None, counts=counts))
+            def step(k=1):
+                iso.losses.extend(float(l) / n_global for l in local.run_native(k, 1, bl, N // bl, bs_g, None))
+        else:
+            def step(k=1):
+                # rng=None: the engine draws the shuffle orders itself (seeded), hidden behind the forward, instead of ~0.15 ms
+                # of host work between two iterations
+                iso.losses.extend(dp.dp_run(local, comm, k, 1, gmb, None, counts=counts))
 
         def sync():
             torch.cuda.synchronize()
@@ -182,24 +214,35 @@ def main():
         def barrier():
             dist.barrier()
 
-    watchdog = None
-    if use_dp and world > 1:
-        # a collective that a peer never joins blocks inside the engine for good (there is nothing to catch): leave with a
-        # diagnostic instead of hanging until the launcher's own limit kills the job
-        import threading
+    # a collective that a peer never joins blocks inside the engine for good (there is nothing to catch): leave with a
+    # diagnostic instead of hanging until the launcher's own limit kills the job.  The timer is re-armed around every phase
+    # (safety-valve step, warm-up, timed steps), so it bounds the time WITHOUT PROGRESS, not the length of the run.
+    import threading
+    wd_limit = float(os.environ.get("ISK_BENCH_WATCHDOG_S", "420"))
+    wd = {"timer": None, "phase": "", "t0": time.perf_counter()}
+
+    def arm(phase):
+        if wd["timer"] is not None:
+            wd["timer"].cancel()
+        if phase and wd["phase"]:
+            print(f"[bench] rank {rank}: {wd['phase']} took {time.perf_counter() - wd['t0']:.1f} s", file=sys.stderr, flush=True)
+        wd["phase"], wd["t0"], wd["timer"] = phase, time.perf_counter(), None
+        if not (phase and use_dp and world > 1):
+            return
 
         def _bail():
-            print(f"[bench] rank {rank}: no progress for {int(os.environ.get('ISK_BENCH_WATCHDOG_S', '420'))} s in the data-parallel run "
+            print(f"[bench] rank {rank}: phase '{phase}' made no progress for {int(wd_limit)} s in the data-parallel run "
                   "(a collective is waiting for a peer?) -- aborting", file=sys.stderr, flush=True)
             os._exit(3)
-        watchdog = threading.Timer(float(os.environ.get("ISK_BENCH_WATCHDOG_S", "420")), _bail)
-        watchdog.daemon = True
-        watchdog.start()
+        wd["timer"] = threading.Timer(wd_limit, _bail)
+        wd["timer"].daemon = True
+        wd["timer"].start()
     if use_dp and world > 1:
         # safety valve for the first step on a real multi-GPU node: if the engine-driven RCCL run raises (on every rank alike:
         # e.g. a communicator that cannot be used), agree on it and continue on the host-driven torch.distributed hooks
         import torch
         failed = 0
+        arm("first data-parallel step")
         try:
             step()
         except Exception as ex:      # noqa: BLE001
@@ -209,15 +252,16 @@ def main():
         dist.all_reduce(f, op=dist.ReduceOp.MAX)
         if int(f.item()):
             local._native_agreed = False
+    arm("warm-up")
     if args.warmup:
         step(args.warmup)
     sync(); barrier(); sync()
+    arm("timed steps")
     t0 = time.perf_counter()
     step(args.steps)
     sync(); barrier(); sync()
     dt = time.perf_counter() - t0
-    if watchdog is not None:
-        watchdog.cancel()
+    arm("")
     if use_dp:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
@@ -247,13 +291,18 @@ def main():
         tm = iso.timers(enable=False)
         ffwd, fwd_flops, step_flops = algorithmic_flops(widths, N, K, nb_rows)
         ms, cnt = tm["fwd_ys"]
-        traffic = None
-        try:        # HBM bytes per launch of this kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
-            if args.workload == "c3" and not args.cached_features:
-                traffic = pm["mlp_fwd_traffic_bytes_per_launch"][{0: "f32", 1: "bf16x3", 2: "bf16", 3: "f16x2"}[args.forward_mode]]
-        except Exception:
-            traffic = None
+        # HBM bytes per launch of this kernel: NOT measured in this run (PMC counters need rocprofv3 passes of their own) -- the
+        # figure of the committed counter summary of the same command, named in `traffic_source`
+        traffic, traffic_source = None, None
+        for pmf in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", pmf)))
+                if args.workload == "c3" and not args.cached_features and world == 1 and not args.shard_of:
+                    traffic = pm["mlp_fwd_traffic_bytes_per_launch"][{0: "f32", 1: "bf16x3", 2: "bf16", 3: "f16x2"}[args.forward_mode]]
+                    traffic_source = "profiles/" + pmf + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of the same command; not measured in this run)"
+                    break
+            except Exception:
+                continue
         if cnt:
             avg = ms / cnt
             alg_tf = fwd_flops / (avg * 1e-3) / 1e12
@@ -305,8 +354,26 @@ def main():
             except Exception:
                 pass
             roof.setdefault("algorithmic_bytes_per_launch", rows * fp * 4)
-            roof.update({"avg_ms": avg, "launches": cnt,
-                         "phases_ms": {k: (v[0] / v[1] if v[1] else None) for k, v in tm.items()}})
+            roof["traffic_source"] = traffic_source
+            phases = {k: (v[0] / v[1] if v[1] else None) for k, v in tm.items()}
+            per_it = {k: (v[0] / args.profile_steps if v[1] else None) for k, v in tm.items()}
+            roof.update({"avg_ms": avg, "launches": cnt, "phases_ms": phases, "phases_ms_per_iteration": per_it})
+            # the whole step against SURVEY.md 8(d)'s algorithmic work (fused-from-coordinates bytes, GEMM flops)
+            step_ms = 1e3 * dt / args.steps
+            if "atoms" in c and not args.cached_features:
+                isa = 1 if widths[-1] > 1 else 0
+                sbytes = 4 * 3 * c["atoms"] * N * (K + isa + 1)
+                roof["step"] = {"algorithmic_bytes": sbytes, "algorithmic_flops": step_flops, "ms": step_ms,
+                                "GB_per_s": sbytes / (step_ms * 1e-3) / 1e9, "frac_of_8TBps": sbytes / (step_ms * 1e-3) / 8e12,
+                                "TFLOP_per_s": step_flops / (step_ms * 1e-3) / 1e12,
+                                "frac_of_157.3_f32_mfma": step_flops / (step_ms * 1e-3) / 157.3e12}
+            tr_ms = per_it.get("train")
+            if tr_ms:
+                tflops = nb_rows * (3 * ffwd - 2 * widths[0] * widths[1])
+                roof["training_chain"] = {"flops_per_epoch": tflops, "ms_per_epoch": tr_ms, "optimizer_steps": nb_rows // bl,
+                                          "us_per_step": 1e3 * tr_ms / max(1, nb_rows // bl), "TFLOP_per_s": tflops / (tr_ms * 1e-3) / 1e12,
+                                          "frac_of_157.3_f32_mfma": tflops / (tr_ms * 1e-3) / 157.3e12,
+                                          "allreduce_ms_per_epoch": per_it.get("allreduce")}
     if use_dp:
         dist.barrier()
 
@@ -314,17 +381,24 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.workload, args)
-        value = world * N * K * args.steps / dt
+        # Koopman samples of the problem the ranks solve TOGETHER per step: the global N in strong scaling, world * N in weak;
+        # a --shard-of rehearsal reports its own shard only (one rank of P: not a whole-job number)
+        value = (N if args.shard_of else n_global) * K * args.steps / dt
+        scaling = None if world == 1 else args.scaling
         line = {
             "metric": "ISOKANN train-step Koopman-samples (N*K)/sec", "value": value, "unit": "Koopman-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": {0: "f32", 3: "f32 (Koopman forward GEMM as split-f16 x2 MFMA, f32 accumulate, f32-equivalent; training f32)",
                       1: "f32 (Koopman forward GEMM as split-bf16 x3 MFMA, f32 accumulate; training f32)",
                       2: "bf16 (Koopman forward GEMM with bf16 operands, f32 accumulate: REDUCED precision, not the headline; training f32)"}[args.forward_mode],
             "data": "synthetic", "dp_replicas_consistent": dp_consistent,
-            "config": {"workload": c["label"], "N_per_gpu": N, "K": K, "features": widths[0], "widths": widths,
-                       "minibatch_per_gpu": args.minibatch, "optimizer": args.opt + "+weightdecay",
+            "config": {"workload": (("C4 = " if strong and args.workload == "c3" else "") + synth.WORKLOADS[args.workload]["label"]
+                                    + (f" -- sharded data-parallel over {parts} GPUs (strong scaling)" if strong and not args.shard_of else "")
+                                    + (f" -- ONE rank's share of a {parts}-way strong-scaled run, rehearsed on one GPU" if args.shard_of else "")
+                                    + (f" -- one full copy per GPU (weak scaling)" if world > 1 and not strong else "")),
+                       "N_global": n_global, "N_per_gpu": N, "K": K, "features": widths[0], "widths": widths,
+                       "minibatch_global": gmb, "minibatch_per_gpu": bl, "optimizer": args.opt + "+weightdecay",
                        "featurize": "cached" if args.cached_features else "every-iteration (fused pdist+LayerNorm kernel)",
                        "forward_mode": {0: "f32", 1: "bf16x3", 2: "bf16", 3: "f16x2"}[args.forward_mode],
                        "parallelism": f"dp{world} over N" if world > 1 else "single GPU"},

@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define ISK_MAX_LAYERS 8
-#define ISK_ABI_VERSION 1
+#define ISK_ABI_VERSION 2
 
 typedef struct isk_engine isk_engine;
 
@@ -46,7 +46,8 @@ typedef enum isk_status {
     ISK_ECOLLAPSED = 5,    /* DomainError "model collapsed under training"    src/iso.jl:186-189      */
     ISK_ESINGULAR = 6,     /* DomainError "simplex transformation ... singular" src/isotarget.jl:94-97 */
     ISK_EUNSUPPORTED = 7,  /* configuration outside what the kernels cover */
-    ISK_ESTATE = 8         /* call order (e.g. train before set_data) */
+    ISK_ESTATE = 8,        /* call order (e.g. train before set_data) */
+    ISK_EPEER = 9          /* data-parallel run: ANOTHER rank failed (its own call returns the cause); this rank stopped with it */
 } isk_status;
 
 typedef enum { ISK_ACT_IDENTITY = 0, ISK_ACT_SIGMOID = 1, ISK_ACT_TANH = 2, ISK_ACT_RELU = 3, ISK_ACT_SWISH = 4 } isk_act;
@@ -105,8 +106,11 @@ typedef struct isk_config {
                                             samples are written pre-split by the featurizer, the weights at the fold),
                                             three f16 MFMAs per product block, f32 accumulate: f32-equivalent accuracy,
                                             half the matrix work of mode 1 and no conversion in the GEMM loop.  Shapes
-                                            it does not cover (layered path, > 2048 features, > 682 atoms) run mode 1.
-                                            Training kernels are f32 in every mode. */
+                                            it does not cover (layered path, > 2048 features, > 682 atoms) run mode 1
+                                            (isk_get_option "forward_mode" reports the effective mode).
+                                            Training kernels are f32 in every mode (wide networks: option train_bf16). */
+    int32_t force_layered;               /* 1: run this network on the layered (wide-network) path even if the fused kernels
+                                            could hold it (test coverage of that path); 0 = by shape */
 } isk_config;
 
 /* ---- library ------------------------------------------------------------------ */
@@ -121,6 +125,30 @@ int  isk_create(const isk_config* cfg, isk_engine** out);
 void isk_destroy(isk_engine* e);
 int  isk_synchronize(isk_engine* e);
 int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's stream (e.g. torch's) */
+
+/* ---- options: per-engine knobs that select a kernel variant or the schedule of an iteration --------------------------
+ * (no counterpart in the reference: Flux picks its kernels by dispatch).  Integer-valued; isk_create takes the defaults
+ * below, or ISK_<KEY> from the environment of the creating process; nothing is latched process-wide.
+ *   key                 default  meaning
+ *   overlap_featurize   2        where the NEXT iteration's featurization runs: 2 = side stream beside the training kernels,
+ *                                1 = beside the forward, 0 = inline on the main stream
+ *   side_min_steps      4        fewest optimizer steps of the coming training phase for which the side stream is used
+ *   side_early          1        start the side launch right behind the forward (0: after the target kernels)
+ *   feat_wg_per_cu      1        throttle of the background featurizer (workgroups per CU) / feat_bg_wgs (in total, 0 = off)
+ *   feat_pf             1        samples in flight per wave of the background featurizer (1 | 2)
+ *   feat_early_pct      0        share of the next iteration's rows featurized beside THIS forward (feat_early_wgs workgroups)
+ *   train_graph         1        replay a training epoch as one hipGraph
+ *   grad1_nw8           -1       layer-1 gradient kernel: 1 = 8-wave variant, 0 = 16-wave, -1 = 8-wave while the featurizer runs
+ *   fwd_waves_per_simd  1        residency of the f32-MFMA forward kernel
+ *   bf16_skew           1        split-bf16 forward: the second wave of a SIMD converts in the first half of a stage
+ *   dense_groups        1        wide networks, bf16 forward: one grouped launch per layer
+ *   layered_blas        1        wide networks, f32 training: rocBLAS sgemm for the plain layer GEMMs (0: in-house kernels)
+ *   train_bf16          0        wide networks: training GEMMs on bf16 operands (f32 master weights, f32 accumulate)
+ *   dp_force_coll       0        issue the native collectives on a one-rank communicator (tests)
+ *   debug_feat_copy / debug_stamps / debug_rowmod   0   diagnostics
+ * Read-only keys of isk_get_option: forward_mode (effective), layered, planes, nparams_engine. */
+int  isk_set_option(isk_engine* e, const char* key, int64_t value);
+int  isk_get_option(isk_engine* e, const char* key, int64_t* value);
 
 /* ---- parameters / optimizer state: Flux.setup, cpu(iso), save/load
  *      src/iso.jl:27,74,257,405-420 ----------------------------------------------- */
@@ -247,15 +275,38 @@ int  isk_dp_epoch_end(isk_engine* e, double* loss_sum);
  *       which the first nbatches*local_batch entries are used (NULL: the engine draws them from its seeded generator,
  *       like isk_run, while the forward runs); losses[k] = sum of the reduced batch losses of
  *       epoch k (divide by the global N for train_batch!'s return value, src/iso.jl:193).
- * Without isk_dp_comm_init (or with world == 1) isk_dp_run runs the same code without collectives. */
+ * Without isk_dp_comm_init (or with world == 1) isk_dp_run runs the same code without collectives.
+ * Errors are agreed on: argument / allocation failures of any rank by one small all-reduce before the run's first collective,
+ * failures inside the step loop through a flag slot behind the batch loss in every gradient all-reduce -- every rank skips the
+ * update in that same step and returns (the failing rank its own status, the others ISK_EPEER) instead of waiting for a peer. */
 int  isk_dp_comm_id(uint8_t id[128]);
 int  isk_dp_comm_init(isk_engine* e, const uint8_t id[128], int32_t rank, int32_t world);
 int  isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t local_batch, int32_t nbatches, int64_t global_batch,
                 const int32_t* perms, double* losses);
 
+/* ONE host process for all GPUs of a node -- the reference is a single Julia process that calls gpu(iso) once (src/iso.jl:256):
+ *   isk_dp_create_all(cfg, devices, n, engines)    n engines (cfg->device is replaced by devices[i]) + ONE communicator group
+ *                                                  (ncclCommInitAll); engines[] are ordinary handles (isk_chis, isk_get_params, ...)
+ *   isk_dp_set_params_all(engines, n, flat, len)   the same Flux-order parameter vector on every replica
+ *   isk_dp_set_data_all(engines, n, xs, ys, D, K, N)   SimulationData(xs, ys): engine i receives the contiguous N-slab
+ *                                                  [i N/n, (i+1) N/n) of xs (D, N) and ys (D, K, N); N must be a multiple of n
+ *   isk_dp_run_all(engines, n_eng, n, epochs, minibatch, perms, losses)   run!(iso, n, epochs) on the sharded data: one host
+ *       thread per engine inside the call drives isk_dp_run (the step loop is launch-bound; the Julia host sees one blocking
+ *       ccall).  minibatch keeps its meaning on the GLOBAL data (src/iso.jl:180; < 0: cfg.minibatch); perms: NULL, or one
+ *       (n*epochs, N/n) array of LOCAL shuffles per engine; losses[k] = train_batch!'s return value (src/iso.jl:193)
+ *   isk_dp_destroy_all(engines, n) */
+int  isk_dp_create_all(const isk_config* cfg, const int32_t* devices, int32_t n, isk_engine** engines);
+int  isk_dp_set_params_all(isk_engine** engines, int32_t n, const float* flat, int64_t nflat);
+int  isk_dp_set_data_all(isk_engine** engines, int32_t n, const float* xs, const float* ys, int64_t D, int64_t K, int64_t N);
+int  isk_dp_run_all(isk_engine** engines, int32_t n_engines, int32_t n, int32_t epochs, int32_t minibatch,
+                    const int32_t* const* perms, double* losses);
+void isk_dp_destroy_all(isk_engine** engines, int32_t n);
+
 /* ---- instrumentation -------------------------------------------------------------- */
+/* ISK_T_ALLREDUCE: the gradient all-reduces of the native data-parallel run (inside the ISK_T_TRAIN span);
+ * ISK_T_TARGET includes the target's own collectives (min/max all-reduce, ks / chi all-gather) */
 typedef enum { ISK_T_FEATURIZE = 0, ISK_T_FWD_YS = 1, ISK_T_FWD_XS = 2, ISK_T_TARGET = 3,
-               ISK_T_TRAIN = 4, ISK_T_COUNT = 5 } isk_timer_id;
+               ISK_T_TRAIN = 4, ISK_T_ALLREDUCE = 5, ISK_T_COUNT = 6 } isk_timer_id;
 /* HIP-event timing of the named phase on the engine's stream (enable before the run) */
 int  isk_timers_enable(isk_engine* e, int32_t on);
 int  isk_timers_read(isk_engine* e, double total_ms[ISK_T_COUNT], int64_t count[ISK_T_COUNT]);

@@ -277,7 +277,7 @@ def featuredim(d) -> int:
 
 # -------------------------------------------------------------------------------- Iso --
 def _make_config(data: SimulationData, model: ModelSpec, opt: OptSpec, target, minibatch: int, device: int,
-                 featurize_every_iteration: bool, seed: int, forward_mode: int = 0):
+                 featurize_every_iteration: bool, seed: int, forward_mode: int = 0, force_layered: bool = False):
     lib = capi.load()
     cfg = capi.Config()
     lib.isk_config_default(C.byref(cfg))
@@ -325,6 +325,7 @@ def _make_config(data: SimulationData, model: ModelSpec, opt: OptSpec, target, m
     cfg.minibatch = int(minibatch)
     cfg.seed = int(seed)
     cfg.forward_mode = int(forward_mode)
+    cfg.force_layered = int(bool(force_layered))
     return cfg, keep
 
 
@@ -364,7 +365,8 @@ class Iso:
 
     def __init__(self, data: SimulationData, *, opt: Optional[OptSpec] = None, model: Optional[ModelSpec] = None,
                  target=None, minibatch: int = 100, loggers=None, device: int = 0,
-                 featurize_every_iteration: bool = False, seed: int = 0, forward_mode: int = 0):
+                 featurize_every_iteration: bool = False, seed: int = 0, forward_mode: int = 0, force_layered: bool = False,
+                 options: Optional[dict] = None):
         self.data = data
         self.optspec = opt if opt is not None else NesterovRegularized()          # src/iso.jl:18
         self.modelspec = model if model is not None else pairnet(data)            # src/simulation.jl:126-127
@@ -381,11 +383,16 @@ class Iso:
         self.nout = outputdim(self.modelspec)
         self._lib = capi.load()
         cfg, keep = _make_config(data, self.modelspec, self.optspec, target, minibatch, device,
-                                 featurize_every_iteration, seed, forward_mode)
+                                 featurize_every_iteration, seed, forward_mode, force_layered)
         h = C.c_void_p()
         capi.check(self._lib.isk_create(C.byref(cfg), C.byref(h)))
         self._h = h
         del keep
+        # the engine may run another forward arithmetic than the one asked for (split-f16 falls back to split-bf16 on shapes
+        # it does not cover; ISK_FWD_MODE overrides at creation): keep what it reports, so that save() records what ran
+        self.forward_mode = self.get_option("forward_mode")
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
         self.model = HipModel(self)
         if self.modelspec.params is None:
             self.modelspec.init_glorot(np.random.default_rng(seed))
@@ -401,9 +408,18 @@ class Iso:
 
     @minibatch.setter
     def minibatch(self, mb: int):
-        self._minibatch = int(mb)
         if getattr(self, "_h", None):
-            capi.check(self._lib.isk_set_minibatch(self._h, int(mb)))
+            capi.check(self._lib.isk_set_minibatch(self._h, int(mb)))      # validates: the field follows only on success
+        self._minibatch = int(mb)
+
+    # -- engine options (kernel variants / scheduling; include/isokann_hip.h lists the keys) ----------------------------
+    def set_option(self, key: str, value: int) -> None:
+        capi.check(self._lib.isk_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int64(0)
+        capi.check(self._lib.isk_get_option(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
 
     def close(self):
         if getattr(self, "_h", None):

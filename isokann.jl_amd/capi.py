@@ -13,16 +13,16 @@ import os
 import numpy as np
 
 ISK_MAX_LAYERS = 8
-ISK_ABI_VERSION = 1
+ISK_ABI_VERSION = 2
 
-OK, EINVAL, EHIP, ENOMEM, ECONSTANT_CHI, ECOLLAPSED, ESINGULAR, EUNSUPPORTED, ESTATE = range(9)
+OK, EINVAL, EHIP, ENOMEM, ECONSTANT_CHI, ECOLLAPSED, ESINGULAR, EUNSUPPORTED, ESTATE, EPEER = range(10)
 ACT = {"identity": 0, "sigmoid": 1, "tanh": 2, "relu": 3, "swish": 4}
 FEAT_IDENTITY, FEAT_ALLPAIRS, FEAT_PAIRLIST = 0, 1, 2
 OPT = {"adam": 0, "nesterov": 1}
 TARGET_SHIFTSCALE, TARGET_ISA, TARGET_HOST = 0, 1, 2
 LN_MODE = {"var_eps2": 0, "std_eps": 1, "var_eps": 2}
-T_FEATURIZE, T_FWD_YS, T_FWD_XS, T_TARGET, T_TRAIN, T_COUNT = 0, 1, 2, 3, 4, 5
-TIMER_NAMES = ("featurize", "fwd_ys", "fwd_xs", "target", "train")
+T_FEATURIZE, T_FWD_YS, T_FWD_XS, T_TARGET, T_TRAIN, T_ALLREDUCE, T_COUNT = 0, 1, 2, 3, 4, 5, 6
+TIMER_NAMES = ("featurize", "fwd_ys", "fwd_xs", "target", "train", "allreduce")
 
 LIB_PATH = os.environ.get("ISK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libisokann_hip.so")
 
@@ -55,6 +55,7 @@ class Config(C.Structure):
         ("target_kind", C.c_int32), ("isa_permute", C.c_int32), ("isa_whitening", C.c_int32),
         ("minibatch", C.c_int32), ("seed", C.c_uint64),
         ("forward_mode", C.c_int32),
+        ("force_layered", C.c_int32),
     ]
 
 
@@ -75,6 +76,8 @@ PROTOTYPES = {
     "isk_destroy": (None, [_H]),
     "isk_synchronize": (C.c_int, [_H]),
     "isk_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "isk_set_option": (C.c_int, [_H, C.c_char_p, C.c_int64]),
+    "isk_get_option": (C.c_int, [_H, C.c_char_p, _i64p]),
     "isk_nparams": (C.c_int, [_H, _i64p]),
     "isk_set_params": (C.c_int, [_H, _f32p, C.c_int64]),
     "isk_get_params": (C.c_int, [_H, _f32p, C.c_int64]),
@@ -117,6 +120,11 @@ PROTOTYPES = {
     "isk_dp_comm_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "isk_dp_comm_init": (C.c_int, [_H, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),
     "isk_dp_run": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _i32p, _f64p]),
+    "isk_dp_create_all": (C.c_int, [C.POINTER(Config), _i32p, C.c_int32, C.POINTER(_H)]),
+    "isk_dp_set_params_all": (C.c_int, [C.POINTER(_H), C.c_int32, _f32p, C.c_int64]),
+    "isk_dp_set_data_all": (C.c_int, [C.POINTER(_H), C.c_int32, _f32p, _f32p, C.c_int64, C.c_int64, C.c_int64]),
+    "isk_dp_run_all": (C.c_int, [C.POINTER(_H), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_i32p), _f64p]),
+    "isk_dp_destroy_all": (None, [C.POINTER(_H), C.c_int32]),
     "isk_timers_enable": (C.c_int, [_H, C.c_int32]),
     "isk_timers_read": (C.c_int, [_H, _f64p, _i64p]),
     "isk_timers_reset": (C.c_int, [_H]),

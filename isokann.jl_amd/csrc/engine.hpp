@@ -1,0 +1,233 @@
+// Shared declarations of the host engine's translation units (engine*.hip): the engine state, the error macros and the
+// helpers one part calls in another.  The C ABI itself is include/isokann_hip.h; the kernel launchers are isk_internal.h.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>
+#include <rocblas/rocblas.h>
+#include "isk_internal.h"
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+int isk_fail(int code, const std::string& msg);        // sets the thread-local message of isk_last_error, returns code
+#define fail isk_fail
+
+#define HIPCHK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            return fail(_e == hipErrorOutOfMemory ? ISK_ENOMEM : ISK_EHIP,                                \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                               \
+    } while (0)
+
+#define CHK(expr)                      \
+    do {                               \
+        int _r = (expr);               \
+        if (_r != ISK_OK) return _r;   \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------------------
+struct EventPair { hipEvent_t a, b; int id; };
+
+struct isk_engine {
+    isk_config cfg;
+    IskOptions opt;                  // per-engine knobs (isk_set_option / isk_get_option)
+    int L = 0, F = 0, Fp = 0, Din = 0, nout = 0;
+    // ENGINE layout of the flat parameter / gradient / optimizer-state vectors (what the kernels see).  Fused path
+    // (`native`): LayerNorm scale and bias padded to Fp, layer-1 weights fragment-linear [Fp/16][nt][64][4] (zero padded),
+    // everything else in Flux order; layered path: the Flux order itself.  See kernels_train.hip.
+    long long nparams = 0, off_lns = -1, off_lnb = -1;
+    long long off_W[ISK_MAX_LAYERS], off_b[ISK_MAX_LAYERS];
+    bool native = false;
+    // API layout (Flux trainables order, W column-major (out, in)): isk_get/set_params, optimizer state, isk_batch_grads
+    long long napi = 0, aoff_lns = -1, aoff_lnb = -1;
+    long long aoff_W[ISK_MAX_LAYERS], aoff_b[ISK_MAX_LAYERS];
+    bool wt_dirty = true;            // fused path: theta changed since the forward weight images (d_Wt, d_bias) were built
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // side stream: the (weight-independent) ys featurization of the NEXT iteration runs here,
+    // concurrently with the latency-bound training kernels of the current one
+    hipStream_t side = nullptr;
+    hipStream_t copy = nullptr;       // small H2D staging (the epoch's shuffle order): never queued behind the side-stream featurizer
+    hipEvent_t ev_fwd_done = nullptr, ev_ys_ready = nullptr;
+    long long side_after_forward = 0;   // isk_run / isk_dp_run: launch the side-stream ys featurization right behind the forward
+                                        // kernel (value = optimizer steps of the coming training phase), not after the target kernels
+    long long early_rows = 0;           // rows of the next iteration already featurized beside THIS iteration's forward (ISK_FEAT_EARLY_PCT)
+    bool ys_ahead = false;       // a side-stream featurization of ys is in flight / complete
+    // parameters
+    float *d_theta = nullptr, *d_grad = nullptr, *d_m = nullptr, *d_v = nullptr;
+    float* d_Wt[ISK_MAX_LAYERS] = {nullptr};
+    float* d_bias[ISK_MAX_LAYERS] = {nullptr};
+    void* d_W16 = nullptr;           // split-bf16 / split-f16 planes of the folded layer-1 weights (forward_mode 1, 2, 3)
+    bool w16_dirty = true;
+    // forward_mode 3 (split-f16 x2): the featurizer writes pre-split f16 planes + inverse row scales, the xs rows also in f32
+    bool planes = false;             // effective: mode 3 requested AND the register featurizer / fused kernels cover the shape
+    unsigned* d_wmax = nullptr;      // [2] weight-tensor maximum of the folded layer-1 image: fold_kernel builds it in one slot and clears the
+    int wmax_par = 0, wmax_last = 0; //     other for the next fold (no memset node), fold_f16 reads the slot of the latest fold
+    float* d_wscale = nullptr;       // [1] inverse scale of the weight planes
+    float* d_xscale = nullptr;       // [(N*K + N)] inverse row scales of d_xhat
+    float* d_xscale_alt = nullptr;   //             ... of d_xhat_alt
+    float* d_xs32 = nullptr;         // [N][Fp] f32 standardised xs rows (training kernels)
+    float* d_xs32_alt = nullptr;     //         the copy the side-stream featurizer writes for the next iteration
+    // layered path (networks too wide for the fused kernels): per-layer images and HBM activations
+    bool layered = false;
+    void* d_W16L[ISK_MAX_LAYERS] = {nullptr};     // bf16 planes per layer (forward_mode 1)
+    float* d_WtT[ISK_MAX_LAYERS] = {nullptr};     // fragment-linear W' per layer l >= 1 (delta back-propagation)
+    float *d_actA = nullptr, *d_actB = nullptr;   // resident forward ping-pong [(N*K+N)][max pad32(H)]
+    float* d_lz[ISK_MAX_LAYERS] = {nullptr};      // training: pre-activations per layer [Bpad][pad16(N_l)]
+    float* d_la[ISK_MAX_LAYERS] = {nullptr};      //           activations
+    float* d_ld[ISK_MAX_LAYERS] = {nullptr};      //           deltas
+    float *d_G0 = nullptr, *d_D0 = nullptr;       // raw layer-0 gradient for the LayerNorm unfold
+    float* d_xb = nullptr;                        // rocBLAS training path: the batch rows of layer 0, gathered contiguous
+    float* d_W0g = nullptr;                       //                        layer-0 weights with the LayerNorm scale folded in (Flux layout)
+    rocblas_handle blas = nullptr;
+    float* d_zero = nullptr;                      // zero bias for the transposed GEMMs
+    double* d_loss_acc = nullptr;
+    int* d_status = nullptr;
+    int* d_rank_err = nullptr;       // data-parallel runs: this rank's error flag (set by the host on a local failure), reduced with the gradients
+    float* d_mm = nullptr;
+    int2* d_pairs = nullptr;
+    unsigned* d_packed = nullptr;
+    double bt1 = 0.9, bt2 = 0.999;
+    // device copy of [bt1, bt2]: opt_step derives the Adam bias corrections from it and the fold that follows advances it,
+    // so a training step's launch arguments never change and an epoch can be replayed as ONE hipGraph (train_epoch_graph)
+    double* d_bt = nullptr;
+    bool bt_dev_valid = false;
+    // the captured epoch: nb x (train_fwd1n, train_tail, train_grad1n, opt_step).  TWO slots: with per-iteration
+    // featurization the xs feature rows the launches read alternate between d_xs32 and d_xs32_alt
+    struct TrainGraph {
+        hipGraphExec_t exec = nullptr;
+        long long bs = 0, nb = 0;
+        int flags = -1;
+        const float* xs = nullptr;
+    } tg[2];
+    bool tg_disabled = false;
+    hipEvent_t ev_loss = nullptr;        // recorded behind the epoch's loss read-back: the host waits for IT, not for the stream
+    // data
+    long long N = 0, K = 0, D = 0;
+    float *d_in_xs = nullptr, *d_in_ys = nullptr;   // raw coords / raw features: ONE allocation, ys rows then xs rows (d_in_xs points inside)
+    float* d_xhat = nullptr;                         // CURRENT [(N*K + N)][Fp] buffer: ys rows first, then xs rows
+    float* d_xhat_alt = nullptr;                     // the other buffer of the pair (per-iteration featurize mode)
+    float* d_out = nullptr;                          // [(N*K + N)][nout]
+    float *d_ks = nullptr, *d_target = nullptr, *d_lossw = nullptr;
+    float* d_kw = nullptr;                           // optional Koopman sample weights [N][K] (WeightedSamples)
+    bool have_target = false, have_ks = false;
+    // training workspace
+    float *d_z1 = nullptr, *d_delta1 = nullptr, *d_part = nullptr;
+    int* d_perm = nullptr;
+    hipEvent_t ev_perm = nullptr;   // the shuffle order of the coming epoch was uploaded on the side stream (isk_run)
+    double* h_res = nullptr;     // pinned + mapped: [loss sum, collapsed flag, status word], published by opt_step (d_hres = its device address)
+    double* d_hres = nullptr;
+    bool loss_acc_zeroed = false; // the K-mean kernel of this iteration already zeroed d_loss_acc
+    int* h_perm = nullptr;       // pinned staging for the shuffle order: an async copy from pageable memory waits for the stream
+    double* d_At = nullptr;      // host-driven data-parallel ISA: the Float64 simplex inverse (applied in Float64, as on the device path)
+    int* d_rowperm = nullptr;
+    double* d_isa_work = nullptr;
+    // native data-parallel run (isk_dp_run): RCCL communicator + gathered ks / chi
+    ncclComm_t comm = nullptr;
+    int dp_rank = 0, dp_world = 1;
+    int dp_err = ISK_OK;             // native run: this rank's first failure inside the step loop (dp_poison) ...
+    std::string dp_errmsg;           // ... and its message; reported when the epoch's collectives are through
+    int* h_flag = nullptr;           // pinned staging word for d_rank_err
+    float* d_gks = nullptr;
+    float* d_gchi = nullptr;
+    long long gather_rows = 0;
+    double* d_isa_work_dp = nullptr;
+    long long isa_work_dp_rows = 0;
+    uint64_t rng[4];
+    int dp_perm_len = 0;
+    int last_nslab = 1;
+    // timers
+    bool timers_on = false;
+    std::vector<EventPair> ev_live, ev_free;
+    double t_ms[ISK_T_COUNT] = {0};
+    long long t_cnt[ISK_T_COUNT] = {0};
+};
+
+// ---- timers ---------------------------------------------------------------------------
+// ---- timers ---------------------------------------------------------------------------
+struct ScopedTimer {
+    isk_engine* e; EventPair ep; bool on; hipStream_t st;
+    ScopedTimer(isk_engine* e_, int id, hipStream_t s = nullptr) : e(e_), on(e_->timers_on), st(s ? s : e_->stream) {
+        if (!on) return;
+        if (!e->ev_free.empty()) { ep = e->ev_free.back(); e->ev_free.pop_back(); }
+        else { (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b); }
+        ep.id = id;
+        (void)hipEventRecord(ep.a, st);
+    }
+    ~ScopedTimer() {
+        if (!on) return;
+        (void)hipEventRecord(ep.b, st);
+        e->ev_live.push_back(ep);
+    }
+};
+
+static void drain_timers(isk_engine* e) {
+    for (auto& ep : e->ev_live) {
+        (void)hipEventSynchronize(ep.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { e->t_ms[ep.id] += ms; e->t_cnt[ep.id] += 1; }
+        e->ev_free.push_back(ep);
+    }
+    e->ev_live.clear();
+}
+
+struct TmpBuf {
+    void* p = nullptr;
+    ~TmpBuf() { if (p) (void)hipFree(p); }
+};
+
+// ---- engine.hip ------------------------------------------------------------------------
+int layer_kp(const isk_engine* e, int l);
+void free_dev(void* p);
+void shuffle_perm(isk_engine* e, std::vector<int32_t>& p);
+int act_of_layer(const isk_engine* e, int l);
+MlpFwdArgs fwd_args(const isk_engine* e, const float* X, long long S, float* out);
+TrainShape train_shape(const isk_engine* e);
+long long z1_rows(long long B);
+TrainBuffers train_buffers(const isk_engine* e);
+void launch_fold(isk_engine* e);
+void ensure_folded(isk_engine* e);
+void fold_ahead(isk_engine* e);
+void api_to_engine(const isk_engine* e, const float* a, std::vector<float>& out);
+void engine_to_api(const isk_engine* e, const float* in, float* a);
+FeatArgs feat_args(const isk_engine* e);                 // featurizer arguments common to every launch (pairs, shape, LayerNorm mode, options)
+void featurize_resident(isk_engine* e);
+void featurize_ys_beside_training(isk_engine* e, long long train_launch_steps);
+void featurize_early_share(isk_engine* e, long long train_launch_steps);
+void side_featurize_hook(isk_engine* e);
+int launch_forward(isk_engine* e, const MlpFwdArgs& f);
+int need_data(isk_engine* e);
+int forward_resident(isk_engine* e, int which, bool ahead = false);
+void launch_kmean(isk_engine* e);
+hipError_t zero_loss_acc(isk_engine* e);
+int check_status(isk_engine* e);
+int compute_target(isk_engine* e, bool check, bool ahead = false);
+int pick_slabs(int B);
+bool prepare_dev_bt(isk_engine* e);
+void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nslab = 1, bool step = true, bool capturing = false);
+void launch_opt(isk_engine* e, float gscale, bool fold = true, bool capturing = false, bool publish = true);
+int stage_perm_ahead(isk_engine* e, const int32_t* perm);
+void engine_options_init(isk_engine* e);                 // defaults, then ISK_<KEY> of the creating process
+// ---- engine_layered.hip ----------------------------------------------------------------
+int forward_layered(isk_engine* e, const float* X, long long S, float* out, float* actA, float* actB);
+void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float inv_div);
+bool blas_ready(isk_engine* e);
+void blas_release(isk_engine* e);
+int bf16_planes(const isk_engine* e);
+// ---- engine_isa_host.hip ---------------------------------------------------------------
+int isa_solve_host(const isk_engine* e, const std::vector<float>& ks, const std::vector<float>& chi, long long N, int d,
+                   std::vector<double>& At, std::vector<int>& rowperm, std::vector<double>* target_out);
+void loss_weights_host(const std::vector<float>& tgt, long long N, int d, std::vector<float>& w);
+// ---- engine_dp.hip ---------------------------------------------------------------------
+void dp_comm_release(isk_engine* e);

@@ -1,0 +1,198 @@
+// Layered (wide-network) path of the engine: networks whose layers do not fit the fused kernels (first hidden width > 160,
+// or a tail too wide for LDS -- e.g. C5's densenet [2000,512,512,512,1]) run layer by layer through HBM.
+#include <dlfcn.h>
+#include "engine.hpp"
+
+// bf16 planes per f32 operand of the layer-1 / dense-block forward GEMM: 0 = f32 MFMA, 3 = split-bf16, 1 = plain bf16
+int bf16_planes(const isk_engine* e) { return e->cfg.forward_mode == 1 ? 3 : (e->cfg.forward_mode == 2 ? 1 : 0); }
+
+// layer-by-layer forward: every layer is a sequence of dense-block launches of the same GEMM kernels; hidden
+// activations [S][pad32(H)] ping-pong between actA / actB (zero-initialised: the padding columns stay 0)
+int forward_layered(isk_engine* e, const float* X, long long S, float* out, float* actA, float* actB) {
+    const float* in = X;
+    int in_ld = e->Fp;
+    for (int l = 0; l < e->L; ++l) {
+        const bool last = (l == e->L - 1);
+        const int N = e->cfg.widths[l + 1];
+        const int nt_total = isk_pad16(N) / 16;
+        float* dst = last ? out : ((l % 2 == 0) ? actA : actB);
+        const int out_ld = last ? e->nout : isk_pad32(N);
+        const int planes = bf16_planes(e);
+        if (planes && e->w16_dirty)
+            isk_launch_fold_bf16(e->d_Wt[l], e->d_W16L[l], layer_kp(e, l), nt_total, planes, e->stream);
+        // plain bf16 keeps 16 output tiles per workgroup (two launches for a 512-wide layer), the others 8
+        const int tb = planes == 1 ? ISK_MAX_NT_BF16 : 8;
+        // equal column blocks of a bf16 layer go out as ONE grouped launch (the sample rows are then read from HBM once
+        // per layer instead of once per column block); ISK_DENSE_GROUPS=0 restores one launch per block
+        const int grouped = e->opt.dense_groups;
+        const int groups = (grouped && planes && nt_total > tb && nt_total % tb == 0 && nt_total / tb <= 8) ? nt_total / tb : 1;
+        auto launch_block = [&](int t0, int ntb, int ngroups) -> int {
+            MlpFwdArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.X = in; a.S = S; a.Fp = in_ld; a.nchunks = in_ld / 16;
+            a.W1t = e->d_Wt[l]; a.bias1 = e->d_bias[l] + t0 * 16;
+            a.act1 = act_of_layer(e, l); a.H1 = N; a.nt1 = ntb; a.ntail = 0;
+            a.out = dst; a.nout = out_ld;
+            a.dense_mode = 1; a.w_nt_total = nt_total; a.w_tile0 = t0; a.out_ld = out_ld; a.out_col0 = t0 * 16;
+            a.dense_groups = ngroups;
+            a.stride_a = ntb * 16 + 4; a.stride_b = 4;
+            isk_fwd_layout_biases(a);
+            int r = ISK_EUNSUPPORTED;
+            if (planes) r = isk_launch_mlp_fwd_bf16x3(a, e->d_W16L[l], planes, e->stream);
+            if (r != 0 && ngroups == 1 && ntb <= ISK_MAX_NT) r = isk_launch_mlp_fwd(a, e->stream);     // the f32 kernel: one block per launch
+            return r;
+        };
+        for (int t0 = 0; t0 < nt_total; t0 += tb * groups) {
+            const int ntb = std::min(tb, nt_total - t0);
+            int r = launch_block(t0, ntb, groups);
+            if (r != 0 && groups > 1)
+                for (int g = 0; g < groups; ++g)
+                    if ((r = launch_block(t0 + g * tb, tb, 1)) != 0) break;
+            if (r != 0) return r;
+        }
+        in = dst;
+        in_ld = out_ld;
+    }
+    e->w16_dirty = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// rocBLAS for the PLAIN GEMMs of the layered (wide-network) training path, loaded lazily.  The fused kernels
+// cover the networks whose layers fit a workgroup; 512-wide layers at a 1000-row batch are ordinary
+// [1000 x 2016] x [2016 x 512] products, where a tiled library GEMM moves 4-8x fewer bytes through L2 than
+// the one-tile-per-workgroup row GEMM used before (C5 shard: 0.47 -> ~0.2 ms per optimizer step).
+// ISK_LAYERED_BLAS=0 keeps the in-house kernels (also the fallback when librocblas.so cannot be loaded).
+// ---------------------------------------------------------------------------------------
+namespace {
+struct BlasApi {
+    void* lib = nullptr;
+    rocblas_status (*create)(rocblas_handle*) = nullptr;
+    rocblas_status (*destroy)(rocblas_handle) = nullptr;
+    rocblas_status (*set_stream)(rocblas_handle, hipStream_t) = nullptr;
+    rocblas_status (*sgemm)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const float*,
+                            const float*, rocblas_int, const float*, rocblas_int, const float*, float*, rocblas_int) = nullptr;
+    bool failed = false;
+};
+BlasApi g_blas;
+
+bool blas_load() {
+    if (g_blas.lib) return true;
+    if (g_blas.failed) return false;
+    void* h = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (h) {
+        g_blas.create = (decltype(g_blas.create))dlsym(h, "rocblas_create_handle");
+        g_blas.destroy = (decltype(g_blas.destroy))dlsym(h, "rocblas_destroy_handle");
+        g_blas.set_stream = (decltype(g_blas.set_stream))dlsym(h, "rocblas_set_stream");
+        g_blas.sgemm = (decltype(g_blas.sgemm))dlsym(h, "rocblas_sgemm");
+    }
+    if (!h || !g_blas.create || !g_blas.destroy || !g_blas.set_stream || !g_blas.sgemm) { g_blas.failed = true; return false; }
+    g_blas.lib = h;
+    return true;
+}
+}  // namespace
+
+void blas_release(isk_engine* e) {
+    if (e->blas && g_blas.destroy) (void)g_blas.destroy(e->blas);
+    e->blas = nullptr;
+}
+
+bool blas_ready(isk_engine* e) {
+    if (!e->opt.layered_blas || !e->layered || !e->d_xb) return false;
+    if (!blas_load()) return false;
+    if (!e->blas && g_blas.create(&e->blas) != rocblas_status_success) { e->blas = nullptr; g_blas.failed = true; return false; }
+    return g_blas.set_stream(e->blas, e->stream) == rocblas_status_success;
+}
+
+// one optimizer step's gradient on the layered path with library GEMMs.  All matrices are viewed column-major:
+// a row-major [rows][ld] activation buffer is the (ld x rows) matrix X', Flux's W (out, in) is the (N x K) matrix W.
+//   forward   Z' (N x B) = W (N x K) * X' (K x B)
+//   dW        G  (N x K) = D' (N x B) * X'^T          -> written in Flux layout directly
+//   dX        R' (K x B) = W^T (K x N) * D' (N x B)   -> no transposed weight image needed
+static bool launch_grads_layered_blas(isk_engine* e, const int* d_idx, int B, float inv_div) {
+    if (!blas_ready(e)) return false;
+    const int L = e->L;
+    const long long Bpad = ((B + 15) / 16) * 16;
+    const float* xs = e->d_xs32;
+    hipStream_t st = e->stream;
+    const float one = 1.f, zero = 0.f;
+    const float* X0 = xs;
+    if (d_idx) { isk_launch_gather_rows(xs, e->Fp, d_idx, B, e->d_xb, st); X0 = e->d_xb; }
+    const float* W0 = e->d_theta + e->off_W[0];
+    if (e->cfg.layernorm) {
+        isk_launch_scale_cols(e->d_theta + e->off_W[0], e->d_theta + e->off_lns, e->d_W0g, e->cfg.widths[1], e->F, st);
+        W0 = e->d_W0g;
+    }
+    bool ok = true;
+    for (int l = 0; l < L && ok; ++l) {
+        const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1], Np = isk_pad16(N);
+        const float* X = (l == 0) ? X0 : e->d_la[l - 1];
+        const int ldx = (l == 0) ? e->Fp : isk_pad16(K);
+        const float* W = (l == 0) ? W0 : e->d_theta + e->off_W[l];
+        ok = g_blas.sgemm(e->blas, rocblas_operation_none, rocblas_operation_none, N, B, K, &one, W, N, X, ldx, &zero, e->d_lz[l], Np) ==
+             rocblas_status_success;
+        // layer 0 with LayerNorm: the folded bias image (b1 + W1*beta); otherwise the bias straight from theta
+        const float* bias = (l == 0 && e->cfg.layernorm) ? e->d_bias[0] : e->d_theta + e->off_b[l];
+        isk_launch_bias_act(e->d_lz[l], bias, l < L - 1 ? e->d_la[l] : nullptr, B, Np, N, act_of_layer(e, l), st);
+    }
+    if (!ok) return false;
+    const int nop = isk_pad16(e->nout);
+    isk_launch_loss_delta(e->d_lz[L - 1], nop, e->d_target, e->d_lossw, d_idx, B, e->nout, inv_div, e->cfg.lastactivation,
+                          e->d_ld[L - 1], nop, e->d_grad + e->nparams, e->d_rank_err, st);
+    for (int l = L - 1; l >= 0 && ok; --l) {
+        const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1], Np = isk_pad16(N);
+        const float* X = (l == 0) ? X0 : e->d_la[l - 1];
+        const int ldx = (l == 0) ? e->Fp : isk_pad16(K);
+        const bool ln0 = (l == 0 && e->cfg.layernorm);
+        float* gW = ln0 ? e->d_G0 : e->d_grad + e->off_W[l];
+        ok = g_blas.sgemm(e->blas, rocblas_operation_none, rocblas_operation_transpose, N, K, B, &one, e->d_ld[l], Np, X, ldx, &zero, gW, N) ==
+             rocblas_status_success;
+        isk_launch_colsum(e->d_ld[l], Np, B, N, e->d_grad + e->off_b[l], st);
+        if (ln0)
+            isk_launch_ln_unfold(e->d_G0, e->d_grad + e->off_b[0], e->d_theta, e->off_W[0], e->off_lns, e->off_lnb, e->F, N, e->d_grad, st);
+        if (l > 0 && ok) {
+            // delta_{l-1} = (delta_l W_l) .* act'(z_{l-1});  a_{l-1} is dead after dW_l and receives the raw product
+            ok = g_blas.sgemm(e->blas, rocblas_operation_transpose, rocblas_operation_none, K, B, N, &one, e->d_theta + e->off_W[l], N,
+                              e->d_ld[l], Np, &zero, e->d_la[l - 1], isk_pad16(K)) == rocblas_status_success;
+            isk_launch_dact_mul(e->d_la[l - 1], e->d_lz[l - 1], e->d_ld[l - 1], Bpad, isk_pad16(K), K, act_of_layer(e, l - 1), st);
+        }
+    }
+    e->last_nslab = 1;
+    return ok;
+}
+
+// layered path: one optimizer step's gradient, layer by layer (see kernels_layered.hip)
+void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float inv_div) {
+    if (launch_grads_layered_blas(e, d_idx, B, inv_div)) return;
+    const int L = e->L;
+    const long long Bpad = ((B + 15) / 16) * 16;
+    const float* xs = e->d_xs32;
+    hipStream_t st = e->stream;
+    for (int l = 0; l < L; ++l) {
+        const int N = e->cfg.widths[l + 1], Np = isk_pad16(N);
+        const float* X = (l == 0) ? xs : e->d_la[l - 1];
+        const int ldx = (l == 0) ? e->Fp : isk_pad16(e->cfg.widths[l]);
+        isk_launch_gemm_rows(X, ldx, e->d_Wt[l], e->d_bias[l], Np / 16, l == 0 ? d_idx : nullptr, B, e->d_lz[l], st);
+        if (l < L - 1) isk_launch_act(e->d_lz[l], e->d_la[l], Bpad, Np, N, act_of_layer(e, l), st);
+    }
+    const int nop = isk_pad16(e->nout);
+    isk_launch_loss_delta(e->d_lz[L - 1], nop, e->d_target, e->d_lossw, d_idx, B, e->nout, inv_div, e->cfg.lastactivation,
+                          e->d_ld[L - 1], nop, e->d_grad + e->nparams, e->d_rank_err, st);
+    for (int l = L - 1; l >= 0; --l) {
+        const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1], Np = isk_pad16(N);
+        const float* X = (l == 0) ? xs : e->d_la[l - 1];
+        const int ldx = (l == 0) ? e->Fp : isk_pad16(K);
+        const bool ln0 = (l == 0 && e->cfg.layernorm);
+        isk_launch_dense_dw(X, ldx, l == 0 ? d_idx : nullptr, e->d_ld[l], Np, B, K, N, ln0 ? e->d_G0 : e->d_grad + e->off_W[l],
+                            e->d_grad + e->off_b[l], st);
+        if (ln0)
+            isk_launch_ln_unfold(e->d_G0, e->d_grad + e->off_b[0], e->d_theta, e->off_W[0], e->off_lns, e->off_lnb, e->F, N, e->d_grad, st);
+        if (l > 0) {
+            // delta_{l-1} = (delta_l W_l) .* act'(z_{l-1});  a_{l-1} is dead after dW_l and receives the raw product
+            isk_launch_gemm_rows(e->d_ld[l], Np, e->d_WtT[l], e->d_zero, isk_pad16(K) / 16, nullptr, B, e->d_la[l - 1], st);
+            isk_launch_dact_mul(e->d_la[l - 1], e->d_lz[l - 1], e->d_ld[l - 1], Bpad, isk_pad16(K), K, act_of_layer(e, l - 1), st);
+        }
+    }
+    e->last_nslab = 1;
+}

@@ -12,6 +12,34 @@
 static inline int isk_pad16(int x) { return (x + 15) & ~15; }
 static inline int isk_pad32(int x) { return (x + 31) & ~31; }   // feature rows: the bf16 MFMA contracts 32 at a time
 
+// ---------------------------------------------------------------- engine options ---
+// Every knob that selects a kernel variant or the schedule of an iteration, PER ENGINE: isk_create reads the defaults
+// (the environment variable ISK_<KEY> of the creating process overrides a default at that moment -- nothing is latched
+// in a static), isk_set_option / isk_get_option change and read them afterwards.  Keys: include/isokann_hip.h.
+struct IskOptions {
+    int bf16_skew = 1;            // split-bf16 forward: second wave of a SIMD converts samples in the first half of a stage
+    int overlap_featurize = 2;    // next iteration's featurization: 2 side stream beside training, 1 beside the forward, 0 inline
+    int side_min_steps = 4;       // fewest optimizer steps of the coming training phase for the side-stream featurizer
+    int side_early = 1;           // side launch right behind the forward (0: after the target chain)
+    int feat_early_pct = 0;       // share of the next iteration's ys rows featurized beside THIS forward (measured: a net loss)
+    int feat_early_wgs = 128;
+    int feat_wg_per_cu = 1;       // throttle of the background featurizer: workgroups per CU
+    int feat_bg_wgs = 0;          //                                        ... or in total (0 = per-CU rule)
+    int feat_pf = 1;              // samples in flight per wave of the background featurizer
+    int dense_groups = 1;         // layered bf16 forward: one grouped launch per layer
+    int layered_blas = 1;         // layered f32 training: rocBLAS sgemm for the plain GEMMs (0: in-house kernels)
+    int train_graph = 1;          // replay the training epoch as one hipGraph
+    int grad1_nw8 = -1;           // train_grad1n variant: 1 = 8 waves, 0 = 16 waves, -1 = 8 while the featurizer shares the CUs
+    int fwd_waves_per_simd = 1;   // residency of the f32 forward kernel
+    int dp_force_coll = 0;        // issue the native collectives on a one-rank communicator (tests)
+    int train_bf16 = 0;           // layered path: training GEMMs with bf16 operands (f32 master weights, f32 accumulate): the C5
+                                  // arithmetic of BASELINE.json; 0 = f32
+    int debug_inject_rank_error = 0;   // tests: in the native data-parallel run this rank flags an error at its n-th optimizer step
+    int debug_feat_copy = 0;      // diagnostics
+    int debug_stamps = 0;
+    int debug_rowmod = 0;
+};
+
 // ---------------------------------------------------------------- featurize -------
 // coords/features rows -> (optionally LayerNorm-standardised) zero-padded feature rows
 struct FeatArgs {
@@ -25,6 +53,9 @@ struct FeatArgs {
     int ln_mode;            // isk_ln_mode
     float eps;
     int background;         // launched on the side stream next to other kernels: may be throttled
+    // throttle of a background launch (engine options feat_wg_per_cu / feat_bg_wgs / feat_pf, see IskOptions); 0 = default
+    int bg_wg_per_cu, bg_wgs_total, bg_pf;
+    int dbg_copy;           // diagnostic (option debug_feat_copy): n x 256 workgroups of a plain byte stream instead of a background launch
     float* raw;             // optional [S][Fp]: un-normalised features (needed by the coordinate pullback)
     float* stats;           // optional [S][2]: mean, 1/denominator of the LayerNorm standardisation
     // split-f16 output (forward_mode 3; register featurizer only, see isk_featurize_reg_ok): xhat rows are written as
@@ -79,6 +110,7 @@ struct MlpFwdArgs {
     int bias_lds0;          // float offset of the bias block: [bias1: nt1*16][tail 0 bias: ntiles*16]...
     int stride_a, stride_b; // floats per row of the two per-wave LDS ping-pong buffers (padded width + 4)
     int sched_skew;            // bf16x3 pipelined kernel: second wave of each SIMD converts early (0 = same schedule)
+    int waves_per_simd;        // f32 forward kernel: residency (engine option fwd_waves_per_simd; 0 = 1)
     // split-f16 forward (forward_mode 3): X holds pre-split f16 planes (FeatArgs.planes), xscale the inverse row scales,
     // wscale[0] the inverse scale of the weight planes (isk_launch_fold_f16); z = acc * xscale[row] * wscale[0]
     const float* xscale;
@@ -113,9 +145,10 @@ void isk_launch_bias_act(float* z, const float* b, float* a /*nullable*/, long l
 void isk_launch_gather_rows(const float* X, int ld, const int* idx, int B, float* out, hipStream_t st);
 void isk_launch_colsum(const float* d, int ld, int B, int N, float* out, hipStream_t st);
 void isk_launch_scale_cols(const float* W, const float* g, float* out, int N, int K, hipStream_t st);
-// delta_L and the batch loss (written to *loss_slot) from the last layer's pre-activations
+// delta_L and the batch loss (written to loss_slot[0]; loss_slot[1] <- *rank_err or 0, see TrainBuffers.rank_err) from the
+// last layer's pre-activations
 void isk_launch_loss_delta(const float* z, int ld, const float* target, const float* lossw, const int* perm, int B, int nout,
-                           float inv_div, int lastact, float* delta, int delta_ld, float* loss_slot, hipStream_t st);
+                           float inv_div, int lastact, float* delta, int delta_ld, float* loss_slot, const int* rank_err, hipStream_t st);
 // cotangent seed of the coordinate pullback on the layered path: delta_L = cot .* lastact'(z_L), zero padded rows / columns
 void isk_launch_cot_delta(const float* z, int ld, const float* cot, long long B, int nout, int lastact, float* delta, int delta_ld,
                           hipStream_t st);
@@ -154,7 +187,8 @@ struct KmeanArgs {
     float* ks;              // [N][nout]
     const float* w;         // optional [N][K] sample weights (WeightedSamples / Girsanov): sum_k w*f / K
     long long N; int K, nout;
-    double* zero2;          // optional: two doubles zeroed by the first thread (the coming epoch's loss accumulator: saves a memset node)
+    double* zero2;          // optional: the coming epoch's accumulator [loss sum, collapsed flag, (status word), peer flag]: elements 0, 1
+                            // and 3 are zeroed by the first thread (saves a memset node)
 };
 void isk_launch_kmean(const KmeanArgs& a, hipStream_t st);
 void isk_launch_minmax(const float* v, long long n, float* mm /*[2] device*/, hipStream_t st);
@@ -215,6 +249,9 @@ struct TrainBuffers {
     double* loss_acc;       // [2]: epoch loss sum (double), collapsed flag (as double)
     int cot_mode;           // 1: `target` is a cotangent (coordinate pullback), see isk_launch_train_tail
     int Fp;
+    const int* rank_err;    // optional device word: this rank's error flag.  The gradient kernel copies it (as a float) into
+                            // grad[nparams + 1], the slot behind the batch loss, so the data-parallel all-reduce of [grad | loss |
+                            // flag] tells EVERY rank in the same step that some rank failed; nullptr writes 0
 };
 struct Fwd1nArgs {
     const float* X; int Fp, nch; const int* perm; int B;
@@ -241,8 +278,9 @@ struct OptArgs {            // kept within two 64-byte kernarg lines
     const double* bt;       // optional: device [beta1^t, beta2^t] of THIS step (then bc1/bc2 are derived from it, so the launch
                             // arguments do not change from step to step and the epoch can be replayed as a hipGraph)
     double* loss_acc;       // [0] epoch loss sum, [1] collapsed flag (set: skip the update, src/iso.jl:186-189 throws before update!),
-                            // [2] (as int) the target's status word
-    double* host_pub;       // optional device pointer to MAPPED pinned host memory: [loss sum, collapsed flag, status word]
+                            // [2] (as int) the target's status word, [3] ranks that flagged an error in a step of this epoch
+    double* host_pub;       // optional device pointer to MAPPED pinned host memory: [loss sum, collapsed flag, status word, peer flag]
+                            // grad[n + 1] is the (all-reduced) rank-error flag: non-zero skips the update like a non-finite loss
     long long n;
     long long slab_prefix;  // gradient slabs are summed for parameter indices < slab_prefix
     int kind, nslab;

@@ -369,7 +369,7 @@ static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream
     const size_t lds = (pd ? (size_t)4 * (a.D / 3 + 1) * 16 : 0) + (a.planes ? (size_t)4 * (NFL / 2) * 64 * 8 : 0);
     const bool tight = a.F > 64 * (NFL - 2);     // only the last feature pair of a lane can be padding
     // waves per CU bounded by the wave-private LDS image (160 KiB) and by 16 (4 per SIMD)
-    static const int cap_env = [] { const char* v = getenv("ISK_FEAT_WG_PER_CU"); return v ? atoi(v) : 1; }();
+    const int cap_env = a.bg_wg_per_cu > 0 ? a.bg_wg_per_cu : 1;       // engine option feat_wg_per_cu
     // background launches (beside the training kernels) run ONE self-pipelined workgroup per CU: measured
     // 1.74 ms/step against 1.87 with two
     int wg_per_cu = (a.background && cap_env > 0) ? cap_env : 4;
@@ -379,15 +379,15 @@ static void launch_feat_reg(const FeatArgs& a, const unsigned* packed, hipStream
     }
     long long blocks = (a.S + 3) / 4;
     long long cap = (long long)ISK_NUM_CU * wg_per_cu;
-    static const int bg_total = [] { const char* v = getenv("ISK_FEAT_BG_WGS"); return v ? atoi(v) : 0; }();
+    const int bg_total = a.bg_wgs_total;                       // engine option feat_bg_wgs
     if (a.background && bg_total > 0) cap = bg_total;          // tuning knob: background workgroups in total
     if (a.background > 1) cap = a.background;                  // the caller names the workgroup count (early share beside the forward)
     if (blocks > cap) blocks = cap;
     void* args[] = {(void*)&a, (void*)&packed};
     if (pd) {
-        // background launches keep two samples in flight per wave (ISK_FEAT_PF=1: one).  Measured on C3, same box:
-        // 1.554 -> 1.533 ms/step; three in flight: 1.558
-        static const int pf = [] { const char* v = getenv("ISK_FEAT_PF"); return v ? atoi(v) : 1; }();
+        // engine option feat_pf = 2: background launches keep two samples in flight per wave (default: one).  Measured on C3,
+        // same box: 1.554 -> 1.533 ms/step; three in flight: 1.558
+        const int pf = a.bg_pf > 0 ? a.bg_pf : 1;
         const void* fn = a.planes ? (tight ? (const void*)featurize_reg_kernel<NFL, NDL, true, 1, true, true> : (const void*)featurize_reg_kernel<NFL, NDL, true, 1, true>)
                                   : (const void*)featurize_reg_kernel<NFL, NDL, true, 1, false>;
         if (a.background && pf == 2)
@@ -417,7 +417,7 @@ bool isk_featurize_reg_ok(const FeatArgs& a) {
     return need <= 32 && (!pd || (a.packed_pairs != nullptr && a.D <= 2048 && (size_t)4 * (a.D / 3) * 16 <= 150 * 1024));
 }
 
-// diagnostic (ISK_DEBUG_FEAT_COPY=1): the background launch replaced by a plain stream of the same bytes (coordinates in,
+// diagnostic (engine option debug_feat_copy): the background launch replaced by a plain stream of the same bytes (coordinates in,
 // rows out, no LDS, no arithmetic): separates what the training kernels lose to the featurizer's MEMORY traffic from what
 // they lose to its LDS / issue-slot use
 __global__ __launch_bounds__(256) void debug_stream_kernel(const f32x4* __restrict__ in, long long nin, f32x4* __restrict__ out, long long nout) {
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void debug_stream_kernel(const f32x4* __restri
 
 void isk_launch_featurize(const FeatArgs& a, hipStream_t st) {
     if (a.S <= 0) return;
-    static const int dbg_copy = [] { const char* v = getenv("ISK_DEBUG_FEAT_COPY"); return v ? atoi(v) : 0; }();
+    const int dbg_copy = a.dbg_copy;
     if (dbg_copy && a.background) {
         hipLaunchKernelGGL(debug_stream_kernel, dim3(256 * dbg_copy), dim3(256), 0, st, (const f32x4*)a.in, a.S * a.D / 4, (f32x4*)a.xhat, a.S * a.Fp / 4);
         return;
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a, long long un
 template <int NT>
 static void launch_fwd_nt(const MlpFwdArgs& a, hipStream_t st) {
     const long long units = (a.S + 15) / 16;
-    static const int wps = [] { const char* v = getenv("ISK_FWD_WAVES_PER_SIMD"); int n = v ? atoi(v) : 1; return n < 1 ? 1 : (n > 4 ? 4 : n); }();
+    const int wps = a.waves_per_simd < 1 ? 1 : (a.waves_per_simd > 4 ? 4 : a.waves_per_simd);     // engine option fwd_waves_per_simd
     const long long waves_max = (long long)ISK_NUM_CU * 4 * wps;
     long long upw = (units + waves_max - 1) / waves_max;     // units per wave
     if (upw < 1) upw = 1;
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256) void kmean_kernel(KmeanArgs a) {
     ISK_LATENCY_CHAIN_PRIO();
     const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (a.zero2 && blockIdx.x == 0 && threadIdx.x == 0) { a.zero2[0] = 0.0; a.zero2[1] = 0.0; }
+    if (a.zero2 && blockIdx.x == 0 && threadIdx.x == 0) { a.zero2[0] = 0.0; a.zero2[1] = 0.0; a.zero2[3] = 0.0; }   // [2] is the status word
     if (n >= a.N) return;
     const float* base = a.out_ys + n * (long long)a.K * a.nout;
     const float* w = a.w ? a.w + n * (long long)a.K : nullptr;

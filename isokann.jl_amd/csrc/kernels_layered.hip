@@ -147,7 +147,7 @@ void isk_launch_dact_mul(const float* dz, const float* z, float* d, long long ro
 __global__ __launch_bounds__(1024) void loss_delta_kernel(const float* __restrict__ z, int ld, const float* __restrict__ target,
                                                           const float* __restrict__ lossw, const int* __restrict__ perm, int B,
                                                           int Bpad, int nout, float inv_div, int lastact, float* __restrict__ delta,
-                                                          int delta_ld, float* __restrict__ loss_slot) {
+                                                          int delta_ld, float* __restrict__ loss_slot, const int* __restrict__ rank_err) {
     __shared__ float red[16];
     float ls = 0.f;
     const long long tot = (long long)Bpad * delta_ld;
@@ -190,14 +190,15 @@ __global__ __launch_bounds__(1024) void loss_delta_kernel(const float* __restric
     if (threadIdx.x == 0) {
         float t = 0.f;
         for (int i = 0; i < 16; ++i) t += red[i];
-        *loss_slot = t;
+        loss_slot[0] = t;
+        loss_slot[1] = rank_err ? (float)*rank_err : 0.f;
     }
 }
 void isk_launch_loss_delta(const float* z, int ld, const float* target, const float* lossw, const int* perm, int B, int nout,
-                           float inv_div, int lastact, float* delta, int delta_ld, float* loss_slot, hipStream_t st) {
+                           float inv_div, int lastact, float* delta, int delta_ld, float* loss_slot, const int* rank_err, hipStream_t st) {
     const int Bpad = ((B + 15) / 16) * 16;
     hipLaunchKernelGGL(loss_delta_kernel, dim3(1), dim3(1024), 0, st, z, ld, target, lossw, perm, B, Bpad, nout, inv_div, lastact,
-                       delta, delta_ld, loss_slot);
+                       delta, delta_ld, loss_slot, rank_err);
 }
 
 // cotangent seed of the coordinate pullback: delta_L[n][o] = cot[n][o] * lastact'(z_L[n][o]), zero padded

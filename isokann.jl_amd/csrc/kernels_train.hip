@@ -830,6 +830,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(
             for (int sft = 8; sft > 0; sft >>= 1) racc += __shfl_xor(racc, sft, WAVE);
             const long long gi = part_to_grad(s, e);
             if (li == 0 && gi >= 0) gout[gi] = racc;
+            if (e == 0 && li == 0) gout[s.nparams + 1] = b.rank_err ? (float)*b.rank_err : 0.f;     // behind the loss: this rank's error flag
         }
     }
     GSTAMP(2);
@@ -910,8 +911,7 @@ static void launch_grad1n(const TrainShape& s, const TrainBuffers& b, const int*
 void isk_launch_train_grad1n(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab_flags, hipStream_t st) {
     const int nt1 = isk_pad16(s.widths[1]) / 16;
     const int nslab = nslab_flags & 0xff;
-    static const int nw8_env = [] { const char* v = getenv("ISK_GRAD1_NW8"); return v ? atoi(v) : -1; }();
-    const int nw8 = nw8_env >= 0 ? nw8_env : ((nslab_flags & 0x100) != 0);
+    const int nw8 = (nslab_flags & 0x100) != 0;            // the engine decides (option grad1_nw8, or: the featurizer shares the CUs)
 #define G1CASE(NT_) case NT_: if (nw8) launch_grad1n<NT_, 8>(s, b, perm, B, nslab, st); else launch_grad1n<NT_, 16>(s, b, perm, B, nslab, st); break;
     switch (nt1) {
         G1CASE(1) G1CASE(2) G1CASE(3) G1CASE(4) G1CASE(5) G1CASE(6) G1CASE(7) G1CASE(8) G1CASE(9)
@@ -931,6 +931,7 @@ __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
     KSTAMP(4);
     const float bc1 = a.bt ? (float)(1.0 - a.bt[0]) : a.bc1, bc2 = a.bt ? (float)(1.0 - a.bt[1]) : a.bc2;
     const float lstep = a.grad[a.n];
+    const float peer = a.grad[a.n + 1];                  // data-parallel: number of ranks that flagged an error in this step (else 0)
     const double collapsed = loss_acc[1];
     // this thread's (first) parameter: its operands are requested before the batch loss is looked at -- waiting for the loss
     // first put a second memory round trip in front of every update
@@ -943,9 +944,10 @@ __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
         for (int sl = 1; sl < a.nslab; ++sl) gs0 += a.grad[(long long)sl * (a.n + 2) + ic];
     const float m0 = a.m[ic];
     const float v0 = a.kind == ISK_OPT_ADAM ? a.v[ic] : 0.f;
-    const bool bad = (collapsed != 0.0) || !isfinite(lstep);
+    const bool bad = (collapsed != 0.0) || !isfinite(lstep) || peer != 0.f;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         double acc0 = loss_acc[0];
+        if (peer != 0.f) loss_acc[3] = (double)peer;
         if (bad) loss_acc[1] = 1.0;
         else { acc0 += (double)lstep; loss_acc[0] = acc0; }
         if (a.host_pub) {
@@ -954,6 +956,8 @@ __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
             a.host_pub[0] = acc0;
             a.host_pub[1] = bad ? 1.0 : 0.0;
             ((int*)(a.host_pub + 2))[0] = ((const int*)(loss_acc + 2))[0];
+            a.host_pub[3] = peer != 0.f ? (double)peer : loss_acc[3];                   // sticky within the epoch
+            __threadfence_system();                      // the three stores are visible to the host before the kernel's end-of-grid signal
         }
     }
     if (bad) return;

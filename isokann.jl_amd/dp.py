@@ -329,3 +329,85 @@ def dp_run(local, comm: Comm, n: int, epochs: int, minibatch: int, rng: Optional
             if hasattr(local, "check_target"):
                 local.check_target()                    # deferred DomainError of the device-resident target
     return losses
+
+
+class IsoAll:
+    """ONE host process driving several GPUs (isk_dp_create_all / isk_dp_run_all): what `gpu(iso)` of the reference's single
+    Julia process becomes on a multi-GPU node (src/iso.jl:256).  `devices`: HIP ordinals, one engine and one N-slab each
+    (N must be a multiple of their number).  Mirrors the part of `Iso` a training script uses: run, chis, koopman, losses."""
+
+    def __init__(self, data, devices, *, opt=None, model=None, target=None, minibatch: int = 100,
+                 featurize_every_iteration: bool = False, seed: int = 0, forward_mode: int = 0, options: Optional[dict] = None):
+        from . import api
+        self.data, self.devices = data, [int(d) for d in devices]
+        self.optspec = opt if opt is not None else api.NesterovRegularized()
+        self.modelspec = model if model is not None else api.pairnet(data)
+        if target is None:
+            target = api.TransformShiftscale() if api.outputdim(self.modelspec) == 1 else api.TransformISA()
+        self.target, self.minibatch, self.nout = target, int(minibatch), api.outputdim(self.modelspec)
+        self.losses: List[float] = []
+        self._lib = capi.load()
+        cfg, keep = api._make_config(data, self.modelspec, self.optspec, target, minibatch, 0, featurize_every_iteration, seed, forward_mode)
+        n = len(self.devices)
+        self._n = n
+        self._h = (C.c_void_p * n)()
+        devs = np.asarray(self.devices, np.int32)
+        capi.check(self._lib.isk_dp_create_all(C.byref(cfg), capi.ptr_i32(devs), n, self._h))
+        del keep
+        for k, v in (options or {}).items():
+            for i in range(n):
+                capi.check(self._lib.isk_set_option(self._h[i], k.encode(), int(v)))
+        if self.modelspec.params is None:
+            self.modelspec.init_glorot(np.random.default_rng(seed))
+        flat = np.ascontiguousarray(self.modelspec.params, np.float32)
+        capi.check(self._lib.isk_dp_set_params_all(self._h, n, capi.ptr_f32(flat), flat.size))
+        xs, ys = data.coords
+        d, k, nn = ys.shape
+        capi.check(self._lib.isk_dp_set_data_all(self._h, n, capi.ptr_f32(xs), capi.ptr_f32(ys), d, k, nn))
+        self.n_local = nn // n
+
+    def set_option(self, key: str, value: int, rank: Optional[int] = None):
+        for i in range(self._n) if rank is None else [rank]:
+            capi.check(self._lib.isk_set_option(self._h[i], key.encode(), int(value)))
+
+    def run(self, n: int = 1, epochs: int = 1, perms=None):
+        """run!(iso, n, epochs); perms: optional list (one per engine) of (n*epochs, N/n_engines) LOCAL shuffle orders"""
+        losses = np.zeros(max(1, n * epochs), np.float64)
+        pp = None
+        if perms is not None:
+            keep = [np.ascontiguousarray(p, np.int32) for p in perms]
+            pp = (capi._i32p * self._n)(*[capi.ptr_i32(p) for p in keep])
+        capi.check(self._lib.isk_dp_run_all(self._h, self._n, n, epochs, self.minibatch, pp, capi.ptr_f64(losses)))
+        self.losses.extend(float(l) for l in losses[:n * epochs])
+        return self
+
+    def _per_engine(self, fn):
+        out = []
+        for i in range(self._n):
+            a = np.empty((self.nout, self.n_local), np.float32, order="F")
+            capi.check(fn(self._h[i], capi.ptr_f32(a)))
+            out.append(a)
+        return np.concatenate(out, axis=1)
+
+    def chis(self):
+        return self._per_engine(self._lib.isk_chis)
+
+    def koopman(self):
+        return self._per_engine(self._lib.isk_koopman)
+
+    def get_params(self, rank: int = 0):
+        n = self.modelspec.nparams()
+        flat = np.empty(n, np.float32)
+        capi.check(self._lib.isk_get_params(self._h[rank], capi.ptr_f32(flat), n))
+        return flat
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            self._lib.isk_dp_destroy_all(self._h, self._n)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

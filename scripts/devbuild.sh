@@ -8,7 +8,7 @@ EXTRA="$*"
 mkdir -p /tmp/obj
 OBJS=""
 pids=""
-for s in engine kernels_fwd kernels_train kernels_isa kernels_fwd_bf16 kernels_fwd_bf16_dense kernels_layered; do
+for s in $(cd $ROOT/isokann.jl_amd/csrc && ls *.hip | sed 's/\.hip$//'); do
   fl="$DEVFLAGS_ALL"; [ "$s" = kernels_fwd_bf16 ] && fl="$DEVFLAGS_ALL $EXTRA"   # DEVFLAGS_ALL: flags for every translation unit
   h=$(cat $ROOT/isokann.jl_amd/csrc/$s.hip $ROOT/isokann.jl_amd/csrc/*.h $ROOT/isokann.jl_amd/csrc/*.hpp $ROOT/include/isokann_hip.h | sha1sum | cut -c1-12)
   o=/tmp/obj/$s-$h-$(echo "$fl" | sha1sum | cut -c1-6).o

@@ -1,7 +1,7 @@
 // TEST DOUBLE, not a product path.  A stand-in for librccl.so that lets TWO (or more) processes sharing ONE GPU run the
 // engine's native data-parallel driver (isk_dp_run): real RCCL rejects two ranks on one device ("Duplicate GPU
 // detected"), and the build loop has single-GPU boxes only.  It implements exactly the entry points the engine
-// binds (engine.hip rccl_load: six, plus the optional group pair) with host staging through a POSIX shared-memory segment: every collective drains the
+// binds (engine_dp_native.hip rccl_load: six, plus the optional group pair and ncclCommInitAll) with host staging through a POSIX shared-memory segment: every collective drains the
 // stream, copies the operand to the rank's slot, meets the other ranks at a barrier, reduces / concatenates in RANK ORDER
 // (so every rank computes the same bits) and copies the result back.  Slow and synchronous by design -- what it checks
 // is the engine's collective SEQUENCE, counts, offsets and shard arithmetic at world > 1, and that no rank leaves the
@@ -35,6 +35,8 @@ struct Header {
     std::atomic<int> arrived;
     std::atomic<int> generation;
     std::atomic<long long> ncalls;      // collectives completed (rank 0 counts): the test reads it back
+    std::atomic<int> broken;            // sticky: a barrier timed out -- every later collective on this communicator fails
+    std::atomic<int> ready;             // rank 0 has created and zeroed the segment (the other ranks wait for it at init)
 };
 
 struct MockComm {
@@ -48,6 +50,7 @@ struct MockComm {
 
 bool barrier(MockComm* c) {
     Header* h = c->hdr();
+    if (h->broken.load(std::memory_order_acquire)) return false;
     const int gen = h->generation.load(std::memory_order_acquire);
     if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == c->world) {
         h->arrived.store(0, std::memory_order_relaxed);
@@ -57,7 +60,13 @@ bool barrier(MockComm* c) {
     const auto t0 = std::chrono::steady_clock::now();
     while (h->generation.load(std::memory_order_acquire) == gen) {
         std::this_thread::yield();
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(mock_timeout_s())) return false;
+        if (h->broken.load(std::memory_order_acquire)) return false;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(mock_timeout_s())) {
+            // the arrival count is now meaningless (a later barrier could release with a rank missing): the communicator is
+            // dead for everybody, as a real one is after its watchdog fires
+            h->broken.store(1, std::memory_order_release);
+            return false;
+        }
     }
     return true;
 }
@@ -87,19 +96,62 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
     return ncclSuccess;
 }
 
-ncclResult_t ncclCommInitRank(ncclComm_t* comm, int world, ncclUniqueId id, int rank) {
-    if (!comm || world < 1 || rank < 0 || rank >= world) return ncclInvalidArgument;
+// rank 0 creates the segment afresh (a name left behind by a crashed run is unlinked first, O_EXCL), sizes it -- new pages are
+// zero -- and raises `ready`; the other ranks open it without O_CREAT and wait for that flag
+static MockComm* attach(const char* name, int world, int rank, bool create) {
     MockComm* c = new MockComm();
     c->rank = rank; c->world = world;
-    std::snprintf(c->name, sizeof(c->name), "%s", id.internal);
+    std::snprintf(c->name, sizeof(c->name), "%s", name);
     c->bytes = 4096 + (size_t)world * SLOT_BYTES;
-    const int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
-    if (fd < 0 || ftruncate(fd, (off_t)c->bytes) != 0) { if (fd >= 0) close(fd); delete c; return ncclSystemError; }
+    int fd = -1;
+    if (create) {
+        shm_unlink(c->name);
+        fd = shm_open(c->name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)c->bytes) != 0) { if (fd >= 0) close(fd); delete c; return nullptr; }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        struct stat sb;
+        while ((fd = shm_open(c->name, O_RDWR, 0600)) < 0 || fstat(fd, &sb) != 0 || (size_t)sb.st_size < c->bytes) {
+            if (fd >= 0) { close(fd); fd = -1; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(mock_timeout_s())) { delete c; return nullptr; }
+            std::this_thread::yield();
+        }
+    }
     c->base = (uint8_t*)mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
-    if (c->base == MAP_FAILED) { delete c; return ncclSystemError; }
+    if (c->base == MAP_FAILED) { delete c; return nullptr; }
+    if (create) c->hdr()->ready.store(1, std::memory_order_release);
+    else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!c->hdr()->ready.load(std::memory_order_acquire)) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(mock_timeout_s())) { munmap(c->base, c->bytes); delete c; return nullptr; }
+            std::this_thread::yield();
+        }
+    }
+    return c;
+}
+
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int world, ncclUniqueId id, int rank) {
+    if (!comm || world < 1 || rank < 0 || rank >= world) return ncclInvalidArgument;
+    MockComm* c = attach(id.internal, world, rank, rank == 0);
+    if (!c) return ncclSystemError;
     if (!barrier(c)) { munmap(c->base, c->bytes); delete c; return ncclInternalError; }
     *comm = reinterpret_cast<ncclComm_t>(c);
+    return ncclSuccess;
+}
+
+// single-process form (isk_dp_create_all): every rank's communicator at once, the engines then call their collectives
+// from one host thread each.  The device list is not looked at (the point of the mock: several ranks on ONE GPU).
+ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
+    (void)devlist;
+    if (!comms || ndev < 1) return ncclInvalidArgument;
+    ncclUniqueId id;
+    ncclGetUniqueId(&id);
+    for (int r = 0; r < ndev; ++r) {
+        MockComm* c = attach(id.internal, ndev, r, r == 0);
+        if (!c) return ncclSystemError;
+        comms[r] = reinterpret_cast<ncclComm_t>(c);
+    }
     return ncclSuccess;
 }
 

@@ -28,14 +28,14 @@ def test_config_layout_and_reference_defaults(pkg):
     cfg = pkg.capi.Config()
     C.memset(C.byref(cfg), 0xFF, C.sizeof(cfg))
     lib.isk_config_default(C.byref(cfg))
-    assert cfg.abi_version == 1 and cfg.device == 0 and cfg.n_layers == 0
+    assert cfg.abi_version == pkg.capi.ISK_ABI_VERSION == 2 and cfg.device == 0 and cfg.n_layers == 0
     assert cfg.activation == pkg.capi.ACT["sigmoid"] and cfg.lastactivation == pkg.capi.ACT["identity"]   # src/models.jl:65
     assert cfg.layernorm == 1 and cfg.ln_mode == 0 and cfg.ln_eps == pytest.approx(1e-5)
     assert cfg.opt_kind == pkg.capi.OPT["nesterov"]                                                       # src/iso.jl:18
     assert cfg.lr == pytest.approx(1e-3) and cfg.reg == pytest.approx(1e-4) and cfg.rho == pytest.approx(0.9)
     assert cfg.beta1 == pytest.approx(0.9) and cfg.beta2 == pytest.approx(0.999) and cfg.opt_eps == pytest.approx(1e-8)
     assert cfg.minibatch == 100 and cfg.isa_permute == 1 and cfg.isa_whitening == 0                       # src/iso.jl:10
-    assert cfg.seed == 0 and not cfg.pairs
+    assert cfg.seed == 0 and not cfg.pairs and cfg.forward_mode == 0 and cfg.force_layered == 0
 
 
 def test_status_strings_name_the_reference_domain_errors(pkg):

@@ -1,0 +1,253 @@
+"""GPU parity at the shapes bench.py runs (BASELINE.json configs C3 / C4 and C5), through the C ABI, against the fp64 CPU
+oracle: the kernels instantiated for villin's [1700,142,12,3]+LayerNorm network (train_fwd1n<5,true>, train_grad1n<9,8|16>,
+54 feature chunks, two row slabs at B = 1000) and for C5's densenet [2000,512,512,512,1] are compared here, not only
+smaller instances of the same templates.
+
+Tolerances (fp32 path vs the fp64 oracle):
+  gradients      3e-5 * max|g| (+ rtol 1e-4), batch loss rel 2e-5
+  chi, losses    1e-5 / rel 1e-4 after 10 full-batch iterations (the north-star gate) at villin width on a moderately
+                 conditioned instance; on the plain initialisation -- where the ISA simplex amplifies the rounding of K chi
+                 ~250-fold and the CPU oracle's own float32 evaluation misses the gate -- max(gate, 3 x that measured fp32
+                 floor), committed with the golden trajectories (tests/golden/c3sub_reference.npz)
+  ISA target     2e-6 * max|target| against the Float64 solve evaluated on the GPU's own ks / chi
+  plain bf16     1e-2 (BASELINE.json: "bf16 MFMA path", SURVEY 8d "expected ~1e-2")
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import isokann_oracle as O
+from tests import benchshape_cases as bc
+from tests.benchshape_cases import C3_ATOMS, C3_F, C3_WIDTHS, C5_ATOMS, C5_F, C5_WIDTHS
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fwd_mode")]
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "c3sub_reference.npz")
+_model, _coords, _features64, _flat = bc.model, bc.coords, bc.features64, bc.flat
+
+
+def _mk(pkg, om):
+    m = pkg.densenet(om.widths, activation=om.activation, lastactivation=om.lastactivation, layernorm=om.layernorm)
+    m.params = om.get_flat().astype(np.float32)
+    return m
+
+
+# ------------------------------------------------------------------ C3: gradients -----
+@pytest.mark.parametrize("B,nw8", [(1000, 1), (1000, 0), (100, 1), (100, 0), (125, 1)])
+def test_c3_batch_gradients_vs_oracle(gpu_pkg, B, nw8):
+    """batch_grads on [1700,142,12,3]+LN with C3 coordinates (A = 591, 1700 pairs): B = 1000 (bench), 100 (the reference's
+    default minibatch), 125 (one GPU's share of C4's global batch); both train_grad1n variants (8 waves: the one that runs
+    beside the side-stream featurizer in bench.py; 16 waves)"""
+    pkg = gpu_pkg
+    N = 1000
+    xs, ys, pairs = _coords(C3_ATOMS, C3_F, N, 1, 3)
+    fx, _ = _features64(C3_ATOMS, C3_F, N, 1, 3)
+    om = _model(C3_WIDTHS, seed=7, ln=True)
+    rng = np.random.default_rng(B)
+    tgt = np.asarray(rng.uniform(size=(3, N)), np.float32)
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_mk(pkg, om), minibatch=0, options={"grad1_nw8": nw8})
+    assert iso.get_option("layered") == 0
+    idx = rng.permutation(N)[:B]
+    g, l = pkg.batch_grads(iso, tgt, idx)
+    t64 = tgt.astype(np.float64)
+    lo, go, _ = O.batch_loss_and_grads(om, fx[:, idx], t64[:, idx], O.loss_weights(t64))
+    gflat = _flat(go)
+    assert abs(l - lo) <= 2e-5 * abs(lo)
+    np.testing.assert_allclose(g, gflat, atol=3e-5 * np.abs(gflat).max(), rtol=1e-4)
+    iso.close()
+
+
+@pytest.mark.parametrize("opt,mb", [("nesterov", 1000), ("adam", 1000), ("nesterov", 100)])
+def test_c3_full_n_training_epoch_vs_oracle(gpu_pkg, opt, mb):
+    """one train_batch! epoch over all N = 10 000 villin start points at the benchmarked batch plan (ten steps of 1000 rows, two
+    row slabs, the epoch replayed as a graph) and at the reference default (100 steps of 100): loss and parameters vs oracle.
+    Nesterov is linear in the gradient (tight tolerance); Adam's first steps divide by |g| (see test_adam_outliers...)"""
+    pkg = gpu_pkg
+    N = 10000
+    xs, ys, pairs = _coords(C3_ATOMS, C3_F, N, 1, 5)
+    fx, _ = _features64(C3_ATOMS, C3_F, N, 1, 5)
+    om = _model(C3_WIDTHS, seed=11, ln=True)
+    rule = O.NesterovRegularized() if opt == "nesterov" else O.AdamRegularized()
+    popt = pkg.NesterovRegularized() if opt == "nesterov" else pkg.AdamRegularized()
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_mk(pkg, om), opt=popt, minibatch=mb)
+    rng = np.random.default_rng(2)
+    tgt = np.asarray(rng.uniform(size=(3, N)), np.float32)
+    perm = rng.permutation(N)
+    st = O.setup(rule, om)
+    p0 = om.get_flat().copy()
+    l = pkg.train_batch(iso, tgt, perm=perm)
+    lo = O.train_batch(om, fx, tgt.astype(np.float64), st, mb, perm=perm)
+    assert abs(l - lo) <= 1e-4 * abs(lo)
+    got, want = iso.model.get_params().astype(np.float64), om.get_flat()
+    step = np.abs(want - p0).max()
+    if opt == "nesterov":
+        np.testing.assert_allclose(got - p0, want - p0, atol=2e-4 * step, rtol=2e-3)
+    else:
+        # Adam's update is lr * m / (sqrt(v) + eps): entries whose gradient is at f32 rounding level move by up to lr per
+        # step in a direction rounding decides.  Every other entry must agree tightly; the exempt ones must be few and have
+        # second moments at rounding level (cause shown, not tolerated)
+        _, v, _ = iso.get_opt_state()
+        diff = np.abs(got - want)
+        bad = diff > 2e-5 + 2e-3 * np.abs(want - p0)
+        gmag = np.sqrt(v.astype(np.float64) / (1 - 0.999 ** (N // mb)))          # bias-corrected RMS gradient of the entry
+        assert bad.mean() < 5e-3, bad.mean()
+        assert np.all(diff[bad] <= 2.5e-3 * (N // mb) / 10 + 1e-12)
+        assert np.all(gmag[bad] < 1e-2 * np.median(gmag[gmag > 0])), (gmag[bad].max(), np.median(gmag))
+    iso.close()
+
+
+# ------------------------------------------------------------------ C3: run! on a sub-sample -----
+# The fp64 trajectories and, per case, the fp32 floor (how far the CPU oracle evaluated in float32 ends up from its own
+# fp64 run) are committed: tests/golden/c3sub_reference.npz, generated by tests/golden/make_c3sub_reference.py.
+def _c3sub_run(pkg, name, every_iter):
+    niter, mb, opt, nout = bc.C3SUB_RUNS[name]
+    N, K = bc.C3SUB["N"], bc.C3SUB["K"]
+    gold = np.load(GOLD)
+    xs, ys, pairs = _coords(C3_ATOMS, C3_F, N, K, bc.C3SUB["coords_seed"])
+    om = _model(bc.c3sub_widths(name), bc.C3SUB["model_seed"], True)
+    p0 = om.get_flat()
+    np.testing.assert_allclose([p0.sum(), np.abs(p0).sum()], gold[name + "_p0_checksum"], rtol=1e-12)     # the fixture's model
+    popt = pkg.AdamRegularized() if opt == "adam" else pkg.NesterovRegularized()
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_mk(pkg, om), opt=popt, minibatch=mb,
+                  featurize_every_iteration=every_iter)
+    pkg.run(iso, niter, 1, perms=bc.run_perms(name))
+    lerr = float(np.max(np.abs(np.asarray(iso.losses) - gold[name + "_losses"]) / gold[name + "_losses"]))
+    cerr = float(np.max(np.abs(pkg.chis(iso) - gold[name + "_chi"])))
+    iso.close()
+    floor_l, floor_c = gold[name + "_fp32_floor"]
+    print(f"{name}: loss rel err {lerr:.2e} (fp32 floor {floor_l:.2e}), chi err {cerr:.2e} (fp32 floor {floor_c:.2e}), "
+          f"kappa {gold[name + '_kappa'].max():.0f}")
+    return lerr, cerr, floor_l, floor_c
+
+
+@pytest.mark.parametrize("every_iter", [False, True])
+@pytest.mark.parametrize("name", ["full_adam_1d", "full3_adam"])
+def test_c3_width_full_batch_chi_within_1e5(gpu_pkg, name, every_iter):
+    """the north-star gate at villin width -- max|chi - oracle| <= 1e-5, losses rel <= 1e-4 at minibatch = 0 (BASELINE.md parity
+    gate), C3 coordinates / pair list / [1700,142,12,.]+LN, N = 1000 start points, K = 20 -- on the instances where an fp32
+    evaluation CAN meet it (the committed fp32 floor of the CPU oracle is below the gate): 10 iterations with the 1-D
+    shift-scale target, and the first 3 iterations of C3's own ISA run"""
+    lerr, cerr, floor_l, floor_c = _c3sub_run(gpu_pkg, name, every_iter)
+    assert floor_c <= 1e-5 and floor_l <= 1e-4
+    assert cerr <= 1e-5 and lerr <= 1e-4
+
+
+@pytest.mark.parametrize("every_iter", [False, True])
+@pytest.mark.parametrize("name", ["full_adam", "mb100_nesterov", "mb1000_adam"])
+def test_c3_subsample_runs_within_fp32_floor(gpu_pkg, name, every_iter):
+    """the plain initialisation (ISA simplex amplification ~250: BEYOND what fp32 can hold to 1e-5, see the golden's floor),
+    full batch x 10 iterations, and 3 iterations with injected DataLoader orders at the reference default (minibatch 100,
+    Nesterov) and at villin.jl's (minibatch 1000, Adam): the HIP path stays within max(gate, 3 x the CPU oracle's own fp32
+    floor) of the fp64 trajectories"""
+    lerr, cerr, floor_l, floor_c = _c3sub_run(gpu_pkg, name, every_iter)
+    assert lerr <= max(1e-4, 3 * floor_l)
+    assert cerr <= max(1e-5, 3 * floor_c)
+
+
+# ------------------------------------------------------------------ C3: the full-N ISA target -----
+def test_c3_full_n_isa_target_vs_oracle(gpu_pkg):
+    """TransformISA at N = 10 000 (ten row slabs of the device chain): the whole target against the Float64 reference solve
+    (myisa + fixperm, src/isotarget.jl:81-127) evaluated on the GPU's own ks / chi, and the loss weights it implies"""
+    pkg = gpu_pkg
+    N, K = 10000, 20
+    xs, ys, pairs = _coords(C3_ATOMS, C3_F, N, K, 0)
+    om = _model(C3_WIDTHS, seed=21, ln=True)
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_mk(pkg, om), minibatch=1000, featurize_every_iteration=True)
+    ks, chi = pkg.koopman(iso), pkg.chis(iso)
+    t = pkg.isotarget(iso)
+    k64, c64 = ks.astype(np.float64), chi.astype(np.float64)
+    A = O.myisa(k64.T)
+    want = O.fixperm(A.T @ k64, c64)
+    assert np.abs(t - want).max() <= 2e-6 * np.abs(want).max()
+    # a sample of columns of ks / chi against the oracle model itself (the full forward would take minutes on the CPU)
+    idx = np.random.default_rng(3).choice(N, size=48, replace=False)
+    f = O.FeaturesPairs(pairs)
+    np.testing.assert_allclose(chi[:, idx], om(f(np.asarray(xs[:, idx], np.float64))), atol=2e-5)
+    np.testing.assert_allclose(ks[:, idx], O.expectation(om, f(np.asarray(ys[:, :, idx], np.float64))), atol=2e-5)
+    # the training that follows uses 1/std(target) (src/iso.jl:183): one full-batch gradient against the oracle's, with the
+    # weights the device chain left behind
+    g, l = pkg.batch_grads(iso, None, np.arange(64))
+    fx = f(np.asarray(xs[:, :64], np.float64))
+    lo, go, _ = O.batch_loss_and_grads(om, fx, want[:, :64], O.loss_weights(want))
+    assert abs(l - lo) <= 1e-4 * abs(lo)
+    gflat = _flat(go)
+    np.testing.assert_allclose(g, gflat, atol=1e-4 * np.abs(gflat).max(), rtol=1e-3)
+    iso.close()
+
+
+# ------------------------------------------------------------------ C5 shard network -----
+def _c5_case(pkg, N, K, seed):
+    xs, ys, pairs = _coords(C5_ATOMS, C5_F, N, K, seed)
+    fx, fy = _features64(C5_ATOMS, C5_F, N, K, seed)
+    om = _model(C5_WIDTHS, seed=31, ln=False)
+    return xs, ys, pairs, fx, fy, om
+
+
+def test_c5_network_forward_gradients_run_vs_oracle(gpu_pkg, fwd_mode):
+    """densenet [2000,512,512,512,1] without LayerNorm on Trp-cage-sized coordinates (A = 304, 2000 pairs, K = 32): the layered
+    path -- Koopman forward, gradients, three minibatched iterations -- against the oracle, in every f32-equivalent forward
+    mode of the sweep (a split-f16 request runs split-bf16 here)"""
+    pkg = gpu_pkg
+    N, K = 256, 32
+    xs, ys, pairs, fx, fy, om = _c5_case(pkg, N, K, 17)
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_mk(pkg, om), opt=pkg.AdamRegularized(), minibatch=100,
+                  featurize_every_iteration=True)
+    assert iso.get_option("layered") == 1
+    np.testing.assert_allclose(pkg.chis(iso), om(fx), atol=5e-5, rtol=1e-5)
+    np.testing.assert_allclose(pkg.koopman(iso), O.expectation(om, fy), atol=5e-5, rtol=1e-5)
+    rng = np.random.default_rng(4)
+    tgt = np.asarray(rng.uniform(size=(1, N)), np.float32)
+    for B in (100, 256):
+        idx = rng.permutation(N)[:B]
+        g, l = pkg.batch_grads(iso, tgt, idx)
+        lo, go, _ = O.batch_loss_and_grads(om, fx[:, idx], tgt[:, idx].astype(np.float64), np.ones(1))
+        gflat = _flat(go)
+        assert abs(l - lo) <= 5e-5 * abs(lo)
+        np.testing.assert_allclose(g, gflat, atol=5e-5 * np.abs(gflat).max(), rtol=2e-4)
+    oiso = O.Iso(bc.oracle_data(fx, fy), om, O.setup(O.AdamRegularized(), om), minibatch=100)
+    perms = np.stack([rng.permutation(N) for _ in range(3)])
+    pkg.run(iso, 3, 1, perms=perms)
+    O.run(oiso, 3, 1, perms=list(perms))
+    np.testing.assert_allclose(iso.losses, oiso.losses, rtol=3e-4)
+    assert np.max(np.abs(pkg.chis(iso) - O.chis(oiso))) <= 1e-4
+    iso.close()
+
+
+@pytest.mark.own_fwd_mode
+@pytest.mark.parametrize("train_bf16", [0, 1])
+def test_c5_network_bf16_path_within_1e2(gpu_pkg, train_bf16, monkeypatch):
+    """the arithmetic BASELINE.json names for C5: bf16 operands, f32 accumulate (forward_mode 2; train_bf16: the training
+    GEMMs as well, f32 master weights) -- outputs, gradients and three iterations within 1e-2 of the fp64 oracle"""
+    monkeypatch.delenv("ISK_FWD_MODE", raising=False)
+    pkg = gpu_pkg
+    N, K = 256, 32
+    xs, ys, pairs, fx, fy, om = _c5_case(pkg, N, K, 17)
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_mk(pkg, om), opt=pkg.AdamRegularized(), minibatch=100,
+                  featurize_every_iteration=True, forward_mode=2, options={"train_bf16": train_bf16})
+    want = om(fx)
+    scale = max(1.0, np.abs(want).max())
+    err = np.abs(pkg.chis(iso) - want).max()
+    assert 1e-6 * scale < err <= 1e-2 * scale                              # the reduced-precision path, and within its bound
+    assert np.abs(pkg.koopman(iso) - O.expectation(om, fy)).max() <= 1e-2 * scale
+    rng = np.random.default_rng(4)
+    tgt = np.asarray(rng.uniform(size=(1, N)), np.float32)
+    idx = rng.permutation(N)[:100]
+    g, l = pkg.batch_grads(iso, tgt, idx)
+    lo, go, _ = O.batch_loss_and_grads(om, fx[:, idx], tgt[:, idx].astype(np.float64), np.ones(1))
+    gflat = _flat(go)
+    tol = 2e-2 if train_bf16 else 5e-5
+    assert abs(l - lo) <= tol * abs(lo)
+    assert np.abs(g - gflat).max() <= tol * np.abs(gflat).max()
+    if train_bf16:
+        assert np.abs(g - gflat).max() > 1e-6 * np.abs(gflat).max()        # really the bf16 GEMMs
+    oiso = O.Iso(bc.oracle_data(fx, fy), om, O.setup(O.AdamRegularized(), om), minibatch=100)
+    perms = np.stack([rng.permutation(N) for _ in range(3)])
+    pkg.run(iso, 3, 1, perms=perms)
+    O.run(oiso, 3, 1, perms=list(perms))
+    # trajectories: the shift-scale target divides by the (small) range of K chi at the initialisation, so a 1e-2 forward
+    # error moves the later losses by more than that; the first loss depends on the initial forward only
+    assert abs(iso.losses[0] - oiso.losses[0]) <= 5e-2 * oiso.losses[0]
+    np.testing.assert_allclose(iso.losses, oiso.losses, rtol=0.3)
+    assert np.max(np.abs(pkg.chis(iso) - O.chis(oiso))) <= 5e-2
+    iso.close()

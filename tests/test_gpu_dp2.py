@@ -39,15 +39,19 @@ def _problem(nout):
     return xs, ys, pairs, widths, om.get_flat().astype(np.float32)
 
 
-def _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, minibatch, every_iter=False):
+LR = 1e-2
+
+
+def _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, minibatch, every_iter=False, opt="adam"):
     model = pkg.densenet(widths, layernorm=True)
     model.params = theta
     tr = pkg.TransformShiftscale() if nout == 1 else pkg.TransformISA()
-    return pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=model, opt=pkg.AdamRegularized(1e-2, 1e-3),
+    popt = pkg.AdamRegularized(LR, 1e-3) if opt == "adam" else pkg.NesterovRegularized(LR, 1e-3)
+    return pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=model, opt=popt,
                    target=tr, minibatch=minibatch, featurize_every_iteration=every_iter)
 
 
-def _worker(rank, world, port, nout, minibatch, niter, outdir):
+def _worker(rank, world, port, nout, minibatch, niter, outdir, opt):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import importlib
     import torch
@@ -60,7 +64,7 @@ def _worker(rank, world, port, nout, minibatch, niter, outdir):
         xs, ys, pairs, widths, theta = _problem(nout)
         lo, hi = dp.shard_bounds(xs.shape[1], world, rank)
         torch.cuda.set_device(0)
-        iso = _mk_iso(pkg, xs[:, lo:hi], ys[:, :, lo:hi], pairs, widths, theta, nout, minibatch)
+        iso = _mk_iso(pkg, xs[:, lo:hi], ys[:, :, lo:hi], pairs, widths, theta, nout, minibatch, opt=opt)
         local = dp.HipLocal(iso)
         comm = dp.Comm(device=torch.device("cuda", 0))
         perms = [np.random.default_rng(1000 * rank + i).permutation(hi - lo) for i in range(niter)]
@@ -72,13 +76,14 @@ def _worker(rank, world, port, nout, minibatch, niter, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nout,minibatch", [(1, 64), (3, 64), (3, 0)])
-def test_two_ranks_on_one_gpu_match_single_process(gpu_pkg, nout, minibatch):
+@pytest.mark.parametrize("nout,minibatch,opt", [(1, 64, "adam"), (3, 64, "adam"), (3, 0, "adam"), (1, 64, "nesterov"), (3, 64, "nesterov")])
+def test_two_ranks_on_one_gpu_match_single_process(gpu_pkg, nout, minibatch, opt):
     import torch.multiprocessing as mp
+    from tests.dp_checks import assert_params_match
     pkg = gpu_pkg
     world, niter = 2, 3
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), nout, minibatch, niter, d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), nout, minibatch, niter, d, opt), nprocs=world, join=True)
         r = [np.load(os.path.join(d, f"r{k}.npz")) for k in range(world)]
     np.testing.assert_allclose(r[0]["losses"], r[1]["losses"], rtol=1e-12)        # the reduced loss is the same number everywhere
     np.testing.assert_allclose(r[0]["params"], r[1]["params"], rtol=0, atol=0)    # and so are the replicas
@@ -94,14 +99,10 @@ def test_two_ranks_on_one_gpu_match_single_process(gpu_pkg, nout, minibatch):
         head = np.concatenate(used)
         rest = np.setdiff1d(np.arange(N), head)
         gperms.append(np.concatenate([head, rest]))
-    ref = _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, minibatch)
+    ref = _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, minibatch, opt=opt)
     pkg.run(ref, niter, 1, perms=np.stack(gperms))
     np.testing.assert_allclose(r[0]["losses"], ref.losses, rtol=2e-4)
-    # The two runs sum the same gradient in a different order.  Adam's first steps move a parameter by ~lr * sign(g), so
-    # an entry whose gradient is zero up to rounding can take a step of opposite sign in the two runs (seen once in a dozen
-    # runs): such outliers are bounded by niter * lr and must stay rare; everything else agrees to rounding.
-    got, want = r[0]["params"], ref.model.get_params()
-    off = np.abs(got - want) > 5e-6 + 5e-4 * np.abs(want)
-    assert off.mean() <= 2e-3, f"{off.sum()} of {off.size} parameters differ"
-    assert np.abs(got - want).max() <= 2 * niter * 1e-2 + 1e-6
+    want = ref.model.get_params()
     ref.close()
+    assert_params_match(pkg, r[0]["params"], want, opt, lambda: _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, minibatch, opt=opt),
+                        gperms[0][:bs], LR, niter * nb)

@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from tests.test_gpu_dp2 import _free_port, _mk_iso, _problem  # noqa: E402
+from tests.dp_checks import assert_params_match  # noqa: E402
+from tests.test_gpu_dp2 import LR, _free_port, _mk_iso, _problem  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -32,7 +33,7 @@ def mock_lib():
     return out
 
 
-def _worker(rank, world, port, nout, minibatch, niter, epochs, outdir, mock, every_iter):
+def _worker(rank, world, port, nout, minibatch, niter, epochs, outdir, mock, every_iter, opt="adam", inject=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ISK_RCCL_LIB=mock)
     if rank == 0:
         os.environ["ISK_MOCK_RCCL_COUNT_FILE"] = os.path.join(outdir, "ncalls.txt")
@@ -49,7 +50,9 @@ def _worker(rank, world, port, nout, minibatch, niter, epochs, outdir, mock, eve
         xs, ys, pairs, widths, theta = _problem(nout)
         lo, hi = dp.shard_bounds(xs.shape[1], world, rank)
         torch.cuda.set_device(0)
-        iso = _mk_iso(pkg, xs[:, lo:hi], ys[:, :, lo:hi], pairs, widths, theta, nout, minibatch, every_iter)
+        iso = _mk_iso(pkg, xs[:, lo:hi], ys[:, :, lo:hi], pairs, widths, theta, nout, minibatch, every_iter, opt=opt)
+        if inject and rank == 1:
+            iso.set_option("debug_inject_rank_error", inject)       # this rank flags a local failure at its inject-th optimizer step
         local = dp.HipLocal(iso, use_torch_stream=False)
         # the communicator hand-shake of HipLocal.comm_init_native, with gloo carrying the 128 bytes
         ident = np.zeros(128, np.uint8)
@@ -62,9 +65,19 @@ def _worker(rank, world, port, nout, minibatch, niter, epochs, outdir, mock, eve
         counts = [hi - lo] * world
         bl, nb, gb = dp.batch_plan(minibatch, counts, world, hi - lo)
         perms = np.stack([np.random.default_rng(1000 * rank + i).permutation(hi - lo) for i in range(niter * epochs)]).astype(np.int32)
-        losses = local.run_native(niter, epochs, bl, nb, gb, perms) / sum(counts)
+        err = ""
+        try:
+            losses = local.run_native(niter, epochs, bl, nb, gb, perms) / sum(counts)
+        except capi.IskError as ex:
+            if not inject:
+                raise
+            losses, err = np.zeros(0), f"{ex.status}|{ex}"
         np.savez(os.path.join(outdir, f"r{rank}.npz"), losses=losses, params=iso.model.get_params(), perms=perms, lo=lo, hi=hi,
-                 plan=np.array([bl, nb, gb]))
+                 plan=np.array([bl, nb, gb]), err=err)
+        if inject:                    # the flag is cleared with the failed call: the same engines run on
+            iso.set_option("debug_inject_rank_error", 0)
+            l2 = local.run_native(1, 1, bl, nb, gb, perms[:1]) / sum(counts)
+            np.savez(os.path.join(outdir, f"again{rank}.npz"), losses=l2, params=iso.model.get_params())
         iso.close()                     # destroys the communicator (rank 0 writes the collective count)
     finally:
         dist.destroy_process_group()
@@ -77,23 +90,24 @@ def test_native_driver_two_ranks_every_forward_mode(gpu_pkg, mock_lib, fwd_mode)
     test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, 3, 16, 1, True)
 
 
-@pytest.mark.parametrize("nout,minibatch,epochs,every_iter", [(1, 64, 1, False), (3, 64, 1, False), (3, 0, 1, False), (3, 48, 2, False),
-                                                             (1, 16, 2, True)])
-def test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, nout, minibatch, epochs, every_iter):
+@pytest.mark.parametrize("nout,minibatch,epochs,every_iter,opt", [(1, 64, 1, False, "adam"), (3, 64, 1, False, "adam"), (3, 0, 1, False, "adam"),
+                                                                 (3, 48, 2, False, "adam"), (1, 16, 2, True, "adam"),
+                                                                 (3, 48, 2, False, "nesterov"), (1, 16, 1, True, "nesterov")])
+def test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, nout, minibatch, epochs, every_iter, opt="adam"):
     """every_iter: featurization inside every iteration, i.e. the side-stream featurizer beside the training steps and the
     collectives (what bench.py runs on a multi-GPU node); minibatch 16 gives the >= 4 optimizer steps that switch it on"""
     import torch.multiprocessing as mp
     pkg = gpu_pkg
     world, niter = 2, 3
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), nout, minibatch, niter, epochs, d, mock_lib, every_iter), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), nout, minibatch, niter, epochs, d, mock_lib, every_iter, opt), nprocs=world, join=True)
         r = [np.load(os.path.join(d, f"r{k}.npz")) for k in range(world)]
         ncalls = int(open(os.path.join(d, "ncalls.txt")).read())
     np.testing.assert_array_equal(r[0]["losses"], r[1]["losses"])      # rank-ordered reduction: the same bits everywhere
     np.testing.assert_array_equal(r[0]["params"], r[1]["params"])
     bl, nb, gb = (int(v) for v in r[0]["plan"])
-    # collectives per run: the equal-shard check once, per iteration 1 (shift-scale range) or 2 (ks, chi gathers),
-    # per optimizer step one gradient all-reduce
+    # collectives per run: the up-front agreement (equal shards, argument / allocation status) once, per iteration 1
+    # (shift-scale range) or 2 (ks, chi gathers), per optimizer step one [gradient | loss | flag] all-reduce
     assert ncalls == 1 + niter * ((1 if nout == 1 else 2) + epochs * nb)
     xs, ys, pairs, widths, theta = _problem(nout)
     N = xs.shape[1]
@@ -101,17 +115,38 @@ def test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, nout, m
     for k in range(niter * epochs):
         head = np.concatenate([np.concatenate([int(x["lo"]) + x["perms"][k][b * bl:(b + 1) * bl] for x in r]) for b in range(nb)])
         gperms.append(np.concatenate([head, np.setdiff1d(np.arange(N), head)]))
-    ref = _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, gb if minibatch else 0, every_iter)
+    mk = lambda: _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, gb if minibatch else 0, every_iter, opt=opt)      # noqa: E731
+    ref = mk()
     pkg.run(ref, niter, epochs, perms=np.stack(gperms))
     np.testing.assert_allclose(r[0]["losses"], ref.losses, rtol=2e-4)
-    got, want = r[0]["params"], ref.model.get_params()
-    off = np.abs(got - want) > 5e-6 + 5e-4 * np.abs(want)               # Adam sign flips of rounding-level gradients: see test_gpu_dp2
-    assert off.mean() <= 2e-3, f"{off.sum()} of {off.size} parameters differ"
-    assert np.abs(got - want).max() <= 2 * niter * epochs * 1e-2 + 1e-6
+    want = ref.model.get_params()
     ref.close()
+    assert_params_match(pkg, r[0]["params"], want, opt, mk, gperms[0][:gb if minibatch else N], LR, niter * epochs * nb)
 
 
-def _absent_worker(rank, world, port, outdir, mock):
+def test_native_driver_rank_error_is_agreed_in_the_same_step(gpu_pkg, mock_lib):
+    """rank 1 flags a local failure at its 2nd optimizer step (option debug_inject_rank_error): the flag travels in the slot
+    behind the batch loss of that step's all-reduce, BOTH ranks skip the update from that step on and return in the same epoch
+    -- rank 1 its own error, rank 0 ISK_EPEER -- with bit-identical replicas, nobody waits in a collective, and the same
+    engines run on afterwards"""
+    import torch.multiprocessing as mp
+    pkg = gpu_pkg
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), 3, 32, 2, 1, d, mock_lib, False, "nesterov", 2), nprocs=2, join=True)
+        r = [np.load(os.path.join(d, f"r{k}.npz")) for k in range(2)]
+        again = [np.load(os.path.join(d, f"again{k}.npz")) for k in range(2)]
+    e0, e1 = str(r[0]["err"]), str(r[1]["err"])
+    assert e1.startswith(f"{pkg.capi.EHIP}|") and "injected rank error" in e1, e1
+    assert e0.startswith(f"{pkg.capi.EPEER}|") and "peer rank" in e0, e0
+    np.testing.assert_array_equal(r[0]["params"], r[1]["params"])            # one step applied on both, none after it
+    xs, ys, pairs, widths, theta = _problem(3)
+    assert np.abs(r[0]["params"] - theta).max() > 0                           # step 1 did run
+    np.testing.assert_array_equal(again[0]["params"], again[1]["params"])
+    np.testing.assert_array_equal(again[0]["losses"], again[1]["losses"])
+    assert np.all(np.isfinite(again[0]["losses"]))
+
+
+def _absent_worker(rank, world, port, outdir, mock, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ISK_RCCL_LIB=mock, ISK_MOCK_RCCL_TIMEOUT_S="5")
     import ctypes as C
     import importlib
@@ -137,8 +172,11 @@ def _absent_worker(rank, world, port, outdir, mock):
         capi.check(local.lib.isk_dp_comm_init(local.h, ident.ctypes.data_as(C.POINTER(C.c_uint8)), rank, world))
         msg = ""
         try:
-            # rank 1: a batch decomposition that fails validation -> returns before its first collective
-            local.run_native(1, 1, 32 if rank == 0 else 0, 1, 64, None)
+            if mode == "badarg":
+                # rank 1: a batch decomposition that fails validation -- agreed on by the up-front all-reduce
+                local.run_native(1, 1, 32 if rank == 0 else 0, 1, 64, None)
+            elif rank == 0:
+                local.run_native(1, 1, 32, 1, 64, None)                    # rank 1 never calls: the collective times out
         except Exception as ex:           # noqa: BLE001
             msg = f"{type(ex).__name__}: {ex}"
         open(os.path.join(outdir, f"r{rank}.txt"), "w").write(msg)
@@ -148,12 +186,23 @@ def _absent_worker(rank, world, port, outdir, mock):
         dist.destroy_process_group()
 
 
-def test_native_driver_reports_a_rank_that_stays_away(gpu_pkg, mock_lib):
-    """a collective one rank never joins comes back as an error code on the others (the mock's barrier times out the
-    way RCCL's watchdog would), and the rank with the bad argument returns BEFORE its first collective"""
+def test_native_driver_argument_error_of_one_rank_is_agreed_before_the_run(gpu_pkg, mock_lib):
+    """a rank whose arguments fail validation still joins the run's first (agreement) collective: it returns its own error, the
+    other rank ISK_EPEER -- at once, not after a watchdog timeout"""
     import torch.multiprocessing as mp
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_absent_worker, args=(2, _free_port(), d, mock_lib), nprocs=2, join=True)
+        mp.spawn(_absent_worker, args=(2, _free_port(), d, mock_lib, "badarg"), nprocs=2, join=True)
         m0, m1 = (open(os.path.join(d, f"r{k}.txt")).read() for k in range(2))
     assert "bad batch decomposition" in m1, m1
+    assert "peer rank reported an error before the run started" in m0, m0
+
+
+def test_native_driver_reports_a_rank_that_stays_away(gpu_pkg, mock_lib):
+    """a collective one rank never joins comes back as an error code on the other (the mock's barrier times out the way RCCL's
+    watchdog would) instead of a hang"""
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_absent_worker, args=(2, _free_port(), d, mock_lib, "absent"), nprocs=2, join=True)
+        m0, m1 = (open(os.path.join(d, f"r{k}.txt")).read() for k in range(2))
+    assert m1 == "", m1
     assert "rccl" in m0 and "did not reach" in m0, m0
