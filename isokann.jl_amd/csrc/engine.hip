@@ -85,6 +85,7 @@ static void free_data(isk_engine* e) {
     e->d_isa_work = nullptr;
     free_dev(e->d_actA); free_dev(e->d_actB); e->d_actA = e->d_actB = nullptr;
     free_dev(e->d_xb); e->d_xb = nullptr;
+    bf16_train_release(e);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_lz[l]); free_dev(e->d_la[l]); free_dev(e->d_ld[l]); e->d_lz[l] = e->d_la[l] = e->d_ld[l] = nullptr; }
     e->d_in_xs = e->d_in_ys = e->d_xhat = e->d_xhat_alt = e->d_out = e->d_ks = e->d_target = e->d_z1 = e->d_delta1 = e->d_part = nullptr;
     e->d_perm = nullptr;
@@ -197,6 +198,7 @@ void launch_fold(isk_engine* e) {
             isk_launch_fold_T(e->d_theta, e->off_W[l], e->cfg.widths[l], e->cfg.widths[l + 1], e->d_WtT[l], e->stream);
     e->w16_dirty = true;
     e->wt_dirty = false;
+    e->b16.wt_dirty = true;
 }
 // fused path: the training steps read theta itself, the forward weight images are rebuilt when a forward needs them
 void ensure_folded(isk_engine* e) {
@@ -1024,6 +1026,7 @@ void launch_opt(isk_engine* e, float gscale, bool fold, bool capturing, bool pub
     e->loss_acc_zeroed = false;
     e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2;
     if (!dev) e->bt_dev_valid = false;           // this step advanced only the host copy
+    e->b16.wt_dirty = true;
     if (e->native) { e->wt_dirty = true; e->w16_dirty = true; }      // the training steps read theta; forwards re-fold on demand
     else if (fold) launch_fold(e);
 }
@@ -1158,7 +1161,9 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
     e->loss_acc_zeroed = false;
     {
         ScopedTimer t(e, ISK_T_TRAIN);
-        const bool lazy_fold = e->layered && !e->cfg.layernorm && blas_ready(e);
+        // layered path without LayerNorm: rocBLAS and the bf16 GEMMs read theta (or their own images of it), so the forward
+        // weight images are folded once, behind the epoch's last step
+        const bool lazy_fold = e->layered && !e->cfg.layernorm && (bf16_train_active(e) || blas_ready(e));
         if (!train_epoch_graph(e, bs, nb)) {
             for (long long b = 0; b < nb; ++b) {
                 launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, pick_slabs((int)bs));

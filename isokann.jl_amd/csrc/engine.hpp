@@ -91,6 +91,19 @@ struct isk_engine {
     float* d_xb = nullptr;                        // rocBLAS training path: the batch rows of layer 0, gathered contiguous
     float* d_W0g = nullptr;                       //                        layer-0 weights with the LayerNorm scale folded in (Flux layout)
     rocblas_handle blas = nullptr;
+    // bf16 training GEMMs (option train_bf16; kernels_gemm16.hip): images of the batch, of the activations / deltas (row-major and
+    // transposed) and of the weights, allocated on first use for the resident N
+    struct Bf16Train {
+        long long rows = 0;                           // Bp the buffers were sized for (0: not allocated)
+        void *xb = nullptr, *xt = nullptr;            // [Bp][Fp], [F + 1][Bp]
+        void* a16[ISK_MAX_LAYERS] = {nullptr};        // act_l          [Bp][pad32(N_l)]
+        void* at16[ISK_MAX_LAYERS] = {nullptr};       // act_l'         [N_l + 1][Bp], row N_l = ones
+        void* d16[ISK_MAX_LAYERS] = {nullptr};        // delta_l        [Bp][pad32(N_l)]
+        void* dt16[ISK_MAX_LAYERS] = {nullptr};       // delta_l'       [N_l][Bp]
+        void* Wt[ISK_MAX_LAYERS] = {nullptr};         // W_l' image     [N_l][pad32(K_l)]
+        float* G0 = nullptr;                          // LayerNorm: raw layer-0 gradient [F + 1][N_0] (row F = D)
+        bool wt_dirty = true;
+    } b16;
     float* d_zero = nullptr;                      // zero bias for the transposed GEMMs
     double* d_loss_acc = nullptr;
     int* d_status = nullptr;
@@ -222,6 +235,8 @@ void engine_options_init(isk_engine* e);                 // defaults, then ISK_<
 // ---- engine_layered.hip ----------------------------------------------------------------
 int forward_layered(isk_engine* e, const float* X, long long S, float* out, float* actA, float* actB);
 void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float inv_div);
+void bf16_train_release(isk_engine* e);
+bool bf16_train_active(const isk_engine* e);
 bool blas_ready(isk_engine* e);
 void blas_release(isk_engine* e);
 int bf16_planes(const isk_engine* e);

@@ -162,8 +162,116 @@ static bool launch_grads_layered_blas(isk_engine* e, const int* d_idx, int B, fl
     return ok;
 }
 
+// ---------------------------------------------------------------------------------------
+// bf16 MFMA training GEMMs (option train_bf16): the arithmetic BASELINE.json names for the wide C5 network -- bf16 operands,
+// f32 accumulate, f32 master weights and optimizer.  kernels_gemm16.hip explains the operand images.
+// ---------------------------------------------------------------------------------------
+bool bf16_train_active(const isk_engine* e) { return e->layered && e->opt.train_bf16 != 0; }
+
+void bf16_train_release(isk_engine* e) {
+    auto& b = e->b16;
+    free_dev(b.xb); free_dev(b.xt); free_dev(b.G0);
+    for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(b.a16[l]); free_dev(b.at16[l]); free_dev(b.d16[l]); free_dev(b.dt16[l]); free_dev(b.Wt[l]); }
+    b = isk_engine::Bf16Train();
+}
+
+__global__ void fill_u16_kernel(unsigned short* p, long long n, unsigned short v) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = v;
+}
+
+static bool bf16_train_ensure(isk_engine* e, long long Bp) {
+    auto& b = e->b16;
+    if (b.rows >= Bp) return true;
+    (void)hipStreamSynchronize(e->stream);
+    bf16_train_release(e);
+    const long long rows = isk_pad32((int)std::max<long long>(Bp, std::min<long long>(e->N, 4096)));     // usual batches without re-allocation
+    const int L = e->L;
+    bool ok = true;
+    auto alloc = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; if (ok) (void)hipMemsetAsync(*p, 0, bytes, e->stream); };
+    alloc(&b.xb, (size_t)rows * e->Fp * 2);
+    alloc(&b.xt, (size_t)(e->F + 1) * rows * 2);
+    for (int l = 0; l < L && ok; ++l) {
+        const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];
+        alloc(&b.a16[l], (size_t)rows * isk_pad32(N) * 2);
+        alloc(&b.at16[l], (size_t)(N + 1) * rows * 2);
+        alloc(&b.d16[l], (size_t)rows * isk_pad32(N) * 2);
+        alloc(&b.dt16[l], (size_t)N * rows * 2);
+        alloc(&b.Wt[l], (size_t)N * isk_pad32(K) * 2);
+        if (ok) hipLaunchKernelGGL(fill_u16_kernel, dim3(64), dim3(256), 0, e->stream, (unsigned short*)b.at16[l] + (size_t)N * rows, rows,
+                                   (unsigned short)0x3F80);           // the row of ones (bf16 1.0) behind the N activation rows
+    }
+    if (ok && e->cfg.layernorm) alloc((void**)&b.G0, (size_t)(e->F + 1) * e->cfg.widths[1] * sizeof(float));
+    if (!ok) { bf16_train_release(e); return false; }
+    b.rows = rows;
+    b.wt_dirty = true;
+    return true;
+}
+
+static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, float inv_div) {
+    const int L = e->L;
+    const int Bp = isk_pad32(B);
+    if (!bf16_train_ensure(e, Bp)) return false;
+    auto& b = e->b16;
+    const long long ldB = b.rows;                    // row length of the transposed images
+    hipStream_t st = e->stream;
+    const bool ln = e->cfg.layernorm != 0;
+    isk_launch_gather_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, st);
+    if (b.wt_dirty) {
+        WtImagesArgs w = {};
+        w.theta = e->d_theta; w.scale0 = ln ? e->d_theta + e->off_lns : nullptr; w.nlayers = L;
+        for (int l = 0; l < L; ++l) { w.off_W[l] = e->off_W[l]; w.K[l] = e->cfg.widths[l]; w.N[l] = e->cfg.widths[l + 1]; w.Kp[l] = isk_pad32(w.K[l]); w.Wt[l] = b.Wt[l]; }
+        isk_launch_wt_images(w, st);
+        b.wt_dirty = false;
+    }
+    bool ok = true;
+    for (int l = 0; l < L && ok; ++l) {
+        const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];
+        Gemm16Args g = {};
+        g.A = l == 0 ? b.xb : b.a16[l - 1]; g.lda = l == 0 ? e->Fp : isk_pad32(K); g.a_f32 = 0;
+        g.B = b.Wt[l]; g.ldb = isk_pad32(K); g.b_f32 = 0;
+        g.M = B; g.Nn = N; g.Kc = isk_pad32(K); g.kvalid = g.Kc;
+        g.epi = ISK_G16_FWD;
+        g.bias = (l == 0 && ln) ? e->d_bias[0] : e->d_theta + e->off_b[l];
+        g.act = l < L - 1 ? act_of_layer(e, l) : ISK_ACT_IDENTITY;          // the last layer's activation is applied by the loss kernel
+        g.z = e->d_lz[l]; g.ldz = isk_pad16(N);
+        if (l < L - 1) { g.o16 = b.a16[l]; g.ld16 = isk_pad32(N); g.M16 = Bp; g.ot16 = b.at16[l]; g.ldt = (int)ldB; }
+        ok = isk_launch_gemm16(g, st) == 0;
+    }
+    if (!ok) return false;
+    isk_launch_loss_delta16(e->d_lz[L - 1], isk_pad16(e->nout), e->d_target, e->d_lossw, d_idx, B, Bp, e->nout, inv_div, e->cfg.lastactivation,
+                            b.d16[L - 1], isk_pad32(e->nout), b.dt16[L - 1], ldB, e->d_grad + e->nparams, e->d_rank_err, st);
+    for (int l = L - 1; l >= 0 && ok; --l) {
+        const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];
+        const bool ln0 = l == 0 && ln;
+        Gemm16Args g = {};
+        g.A = l == 0 ? b.xt : b.at16[l - 1]; g.lda = ldB; g.a_f32 = 0;
+        g.B = b.dt16[l]; g.ldb = ldB; g.b_f32 = 0;
+        g.M = K + 1; g.Nn = N; g.Kc = Bp; g.kvalid = Bp;
+        g.epi = ISK_G16_DW;
+        g.gout = ln0 ? b.G0 : e->d_grad + e->off_W[l]; g.gld = N;           // row K lands on b_l: Flux keeps it right behind W_l
+        ok = isk_launch_gemm16(g, st) == 0;
+        if (ln0) {
+            (void)hipMemcpyAsync(e->d_grad + e->off_b[0], b.G0 + (size_t)K * N, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st);
+            isk_launch_ln_unfold(b.G0, b.G0 + (size_t)K * N, e->d_theta, e->off_W[0], e->off_lns, e->off_lnb, e->F, N, e->d_grad, st);
+        }
+        if (l > 0 && ok) {
+            Gemm16Args x = {};
+            x.A = b.d16[l]; x.lda = isk_pad32(N); x.a_f32 = 0;
+            x.B = e->d_theta + e->off_W[l]; x.ldb = N; x.b_f32 = 1;           // Flux (out, in) column-major == [k][n]: n contiguous
+            x.M = B; x.Nn = K; x.Kc = isk_pad32(N); x.kvalid = N;
+            x.epi = ISK_G16_DX;
+            x.zprev = e->d_lz[l - 1]; x.ldzp = isk_pad16(K); x.act = act_of_layer(e, l - 1);
+            x.o16 = b.d16[l - 1]; x.ld16 = isk_pad32(K); x.M16 = Bp; x.ot16 = b.dt16[l - 1]; x.ldt = (int)ldB;
+            ok = isk_launch_gemm16(x, st) == 0;
+        }
+    }
+    e->last_nslab = 1;
+    return ok;
+}
+
 // layered path: one optimizer step's gradient, layer by layer (see kernels_layered.hip)
 void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float inv_div) {
+    if (bf16_train_active(e) && launch_grads_layered_bf16(e, d_idx, B, inv_div)) return;
     if (launch_grads_layered_blas(e, d_idx, B, inv_div)) return;
     const int L = e->L;
     const long long Bpad = ((B + 15) / 16) * 16;

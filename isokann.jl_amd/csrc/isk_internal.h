@@ -164,6 +164,42 @@ void isk_launch_fold_T(const float* theta, long long off_W, int K, int N, float*
 void isk_launch_ln_unfold(const float* G, const float* D, const float* theta, long long off_W, long long off_lns, long long off_lnb,
                           int F, int H1, float* grad, hipStream_t st);
 
+// ---------------------------------------------------------------- bf16 training GEMMs (kernels_gemm16.hip) ----
+// C[i][j] = sum_k A[i][k] * B[j][k]  ("NT": both operands contiguous along the contraction), bf16 MFMA, f32 accumulate
+enum { ISK_G16_FWD = 0, ISK_G16_DX = 1, ISK_G16_DW = 2 };
+struct Gemm16Args {
+    const void* A; long long lda; int a_f32;     // [M][lda]   f32 (converted on load) or bf16
+    const void* B; long long ldb; int b_f32;     // [Nn][ldb]
+    int M, Nn, Kc, kvalid;                       // Kc: contraction length, a multiple of 32 (operands zero padded); kvalid < Kc:
+                                                 // elements k >= kvalid are NOT readable padding and are masked (slow path)
+    int epi;
+    // ISK_G16_FWD: z = C + bias (f32 [M][ldz]); images receive act(z).  ISK_G16_DX: images receive C .* act'(zprev)
+    const float* bias; int act;
+    float* z; int ldz;
+    const float* zprev; int ldzp;
+    float* o32; int ld32;                        // optional f32 image of the epilogue value (FWD)
+    void* o16; int ld16, M16;                    // optional row-major bf16 image [M16][ld16]: rows >= M and columns >= Nn are zeros
+    void* ot16; int ldt;                         // optional TRANSPOSED bf16 image [Nn][ldt]: columns i in [M, ldt) are zeros
+    // ISK_G16_DW: gout[i * gld + j] = C (f32)
+    float* gout; long long gld;
+};
+int  isk_launch_gemm16(const Gemm16Args& a, hipStream_t st);
+// gathered batch rows -> xb [Bp][Kp] bf16 and xt [K + 1][ldt] bf16 (row K = ones; columns [B, Bp) zeros)
+void isk_launch_gather_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
+                              hipStream_t st);
+struct WtImagesArgs {
+    const float* theta; const float* scale0;     // scale0: LayerNorm scale folded into layer 0's image (or nullptr)
+    int nlayers;
+    long long off_W[ISK_MAX_LAYERS];
+    int K[ISK_MAX_LAYERS], N[ISK_MAX_LAYERS], Kp[ISK_MAX_LAYERS];
+    void* Wt[ISK_MAX_LAYERS];                    // [N][Kp] bf16
+    int first_block[ISK_MAX_LAYERS];             // filled by the launcher
+};
+void isk_launch_wt_images(WtImagesArgs& a, hipStream_t st);
+void isk_launch_loss_delta16(const float* z, int ld, const float* target, const float* lossw, const int* perm, int B, int Bp, int nout,
+                             float inv_div, int lastact, void* d16, int ld16, void* dt16, long long ldt, float* loss_slot,
+                             const int* rank_err, hipStream_t st);
+
 // parameter "fold": flat Flux-order theta -> fragment-linear weights and folded bias
 struct FoldArgs {
     const float* theta;

@@ -1,0 +1,290 @@
+// bf16-MFMA GEMMs of the wide-network (layered) TRAINING path: C5 of BASELINE.json names "wide MLP [512,512,512], bf16 MFMA
+// path" -- bf16 operands, f32 accumulate, f32 master weights (engine option train_bf16).
+//
+// One kernel shape serves every product of an optimizer step.  The matrix cores want BOTH operands contiguous along the
+// contraction index (v_mfma_f32_16x16x32_bf16: lane (row|col = l & 15, kgroup = l >> 4) holds 8 consecutive k), so every product
+// is written as an "NT" GEMM   C[i][j] = sum_k A[i][k] * B[j][k]   over row-major images A [M][lda], B [Nn][ldb]:
+//   forward   z_l[b][n]       = sum_k a_{l-1}[b][k] * Wt_l[n][k]          Wt = bf16 TRANSPOSED weight image, refreshed per step
+//   dX        r_{l-1}[b][k]   = sum_n delta_l[b][n] * W_l(mem)[k][n]      Flux's column-major (out, in) IS [k][n]: no image needed
+//   dW + db   G_l[k][n]       = sum_b aT_{l-1}[k][b] * deltaT_l[n][b]     transposed bf16 images written by the producers'
+//                                                                         epilogues; aT carries a row of ones, so row K of G is
+//                                                                         db -- and Flux keeps b_l right behind W_l: ONE store
+// The products of a 1000-row batch are small (<= 2 GFLOP, operands L2-resident): what a step costs is the number of dependent
+// launches and their latency, not MFMA time.  So: no LDS staging -- fragments go global/L2 -> VGPR in MFMA shape, one step
+// ahead -- a 32 x 64 output tile per 256-thread workgroup whose four waves SPLIT K (256..504 workgroups for every product of
+// C5: the whole chip, 8..16 k-steps per wave), one LDS reduction, and fused epilogues (bias + activation + the bf16 / transposed
+// images the next products need), so that a layer is one launch forward and two backward.
+#include "isk_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ float g_sigmoid(float z) {
+    float e = __expf(-fabsf(z));
+    float r = 1.0f / (1.0f + e);
+    return z >= 0.f ? r : e * r;
+}
+__device__ __forceinline__ float g_act(int act, float z) {
+    switch (act) {
+        case ISK_ACT_SIGMOID: return g_sigmoid(z);
+        case ISK_ACT_TANH: return tanhf(z);
+        case ISK_ACT_RELU: return fmaxf(z, 0.f);
+        case ISK_ACT_SWISH: return z * g_sigmoid(z);
+        default: return z;
+    }
+}
+__device__ __forceinline__ float g_dact(int act, float z) {
+    switch (act) {
+        case ISK_ACT_SIGMOID: { float a = g_sigmoid(z); return a * (1.f - a); }
+        case ISK_ACT_TANH: { float a = tanhf(z); return 1.f - a * a; }
+        case ISK_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case ISK_ACT_SWISH: { float s = g_sigmoid(z); return s + z * s * (1.f - s); }
+        default: return 1.f;
+    }
+}
+__device__ __forceinline__ u16 to_bf16(float v) {
+    const __bf16 b = (__bf16)v;                          // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+    return __builtin_bit_cast(u16, b);
+}
+
+// 8 consecutive contraction elements of one operand row as an MFMA fragment; kmax: elements at k >= kmax read as 0 (only the
+// unaligned / ragged slow path passes kmax < the padded length)
+template <bool F32, bool SLOW>
+__device__ __forceinline__ bf16x8 load_frag(const void* base, long long off, int k0, int kmax) {
+    if (SLOW) {
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = 0.f;
+            if (k0 + j < kmax) v = F32 ? ((const float*)base)[off + j] : (float)((const __bf16*)base)[off + j];
+            r[j] = (__bf16)v;
+        }
+        return r;
+    }
+    if (F32) {
+        const f32x4* p = (const f32x4*)((const float*)base + off);
+        const f32x4 lo = p[0], hi = p[1];
+        const f32x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_convertvector(v, bf16x8);
+    }
+    return *(const bf16x8*)((const __bf16*)base + off);
+}
+
+#define G16_TM 32
+#define G16_TN 64
+#define G16_LDR 65           // LDS row stride of the reduction tile (floats): the transposed pass reads down a column
+
+template <bool AF32, bool BF32, bool SLOW>
+__global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args a) {
+    __shared__ float red[4][G16_TM][G16_LDR];
+    ISK_LATENCY_CHAIN_PRIO();
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lq = lane >> 4;
+    const int i0 = blockIdx.x * G16_TM, j0 = blockIdx.y * G16_TN;
+    long long offA[2], offB[4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) { int r = i0 + rt * 16 + li; r = r < a.M ? r : a.M - 1; offA[rt] = (long long)r * a.lda + lq * 8; }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { int r = j0 + ct * 16 + li; r = r < a.Nn ? r : a.Nn - 1; offB[ct] = (long long)r * a.ldb + lq * 8; }
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = a.Kc / 32;
+    bf16x8 fa[2], fb[4], na[2], nb[4];
+    int ks = wave;
+    if (ks < nk) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) fa[rt] = load_frag<AF32, SLOW>(a.A, offA[rt] + ks * 32, ks * 32 + lq * 8, a.kvalid);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) fb[ct] = load_frag<BF32, SLOW>(a.B, offB[ct] + ks * 32, ks * 32 + lq * 8, a.kvalid);
+    }
+    for (; ks < nk; ks += 4) {
+        const int kn = ks + 4;
+        if (kn < nk) {                                   // the next step's fragments are requested before this step's MFMAs
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) na[rt] = load_frag<AF32, SLOW>(a.A, offA[rt] + kn * 32, kn * 32 + lq * 8, a.kvalid);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) nb[ct] = load_frag<BF32, SLOW>(a.B, offB[ct] + kn * 32, kn * 32 + lq * 8, a.kvalid);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+        if (kn < nk) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) fa[rt] = na[rt];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) fb[ct] = nb[ct];
+        }
+    }
+    // C layout of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + r
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][rt * 16 + 4 * lq + r][ct * 16 + li] = acc[rt][ct][r];
+    __syncthreads();
+    // pass 1: consecutive threads along j -- the K-split sum, the epilogue, the row-major stores
+    const bool want_t = a.ot16 != nullptr;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int idx = tid + 256 * p, row = idx >> 6, col = idx & 63;
+        const int i = i0 + row, j = j0 + col;
+        float v = (red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col]);
+        const bool in = i < a.M && j < a.Nn;
+        float o = 0.f;                                   // what the bf16 images receive (0 in the padding)
+        if (a.epi == ISK_G16_FWD) {
+            if (in) {
+                v += a.bias ? a.bias[j] : 0.f;
+                a.z[(long long)i * a.ldz + j] = v;
+                o = g_act(a.act, v);
+                if (a.o32) a.o32[(long long)i * a.ld32 + j] = o;
+            }
+        } else if (a.epi == ISK_G16_DX) {
+            if (in) o = v * g_dact(a.act, a.zprev[(long long)i * a.ldzp + j]);
+        } else {                                         // ISK_G16_DW: rows 0..K-1 are dW (Flux layout [k][n]), row K is db
+            if (in) a.gout[(long long)i * a.gld + j] = v;
+        }
+        if (a.o16 && i < a.M16 && j < a.ld16) ((u16*)a.o16)[(long long)i * a.ld16 + j] = to_bf16(o);
+        if (want_t) red[0][row][col] = o;                // own element only: no other thread reads it before the barrier
+    }
+    if (!want_t) return;
+    __syncthreads();
+    // pass 2: consecutive threads along i -- the transposed bf16 image [j][i] (rows of it beyond Nn are never read)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int idx = tid + 256 * p, col = idx >> 5, row = idx & 31;
+        const int i = i0 + row, j = j0 + col;
+        if (j < a.Nn && i < a.ldt) ((u16*)a.ot16)[(long long)j * a.ldt + i] = to_bf16(red[0][row][col]);
+    }
+}
+
+int isk_launch_gemm16(const Gemm16Args& a, hipStream_t st) {
+    if (a.M < 1 || a.Nn < 1 || a.Kc < 32 || a.Kc % 32) return ISK_EINVAL;
+    const dim3 grid((a.M16 > a.M ? a.M16 : a.M) / G16_TM + (((a.M16 > a.M ? a.M16 : a.M) % G16_TM) ? 1 : 0), (a.Nn + G16_TN - 1) / G16_TN);
+    // vector loads need 16-byte aligned rows; anything else (odd widths, a contraction that is not a multiple of 32) takes the
+    // elementwise path
+    const bool a_al = ((uintptr_t)a.A % 16 == 0) && (a.lda % 8 == 0), b_al = ((uintptr_t)a.B % 16 == 0) && (a.ldb % 8 == 0);
+    const bool slow = !a_al || !b_al || a.kvalid < a.Kc;
+    void* args[] = {(void*)&a};
+    const void* fn;
+#define G16PICK(AF, BF) (slow ? (const void*)gemm16_kernel<AF, BF, true> : (const void*)gemm16_kernel<AF, BF, false>)
+    if (a.a_f32) fn = a.b_f32 ? G16PICK(true, true) : G16PICK(true, false);
+    else fn = a.b_f32 ? G16PICK(false, true) : G16PICK(false, false);
+#undef G16PICK
+    return hipLaunchKernel(fn, grid, dim3(256), args, 0, st) == hipSuccess ? 0 : ISK_EHIP;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// images around the GEMMs
+// ---------------------------------------------------------------------------------------------------------------------
+// batch rows (gathered by perm) -> xb [Bp][Kp] bf16 (A operand of the first layer's forward) and xt [K + 1 (+pad)][Bp] bf16 (its
+// transposed image with the row of ones behind the K features: the first layer's dW + db operand).  One 32 x 32 tile per
+// workgroup through LDS; rows >= B and columns >= K are written as zeros (they are contraction padding).
+__global__ __launch_bounds__(256) void gather_images_kernel(const float* __restrict__ X, int ldx, const int* __restrict__ perm, int B, int Bp,
+                                                            int K, int Kp, u16* __restrict__ xb, u16* __restrict__ xt, long long ldt) {
+    __shared__ float tile[32][33];
+    ISK_LATENCY_CHAIN_PRIO();
+    const int b0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 8 row groups
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int b = b0 + r, k = k0 + tx;
+        float v = 0.f;
+        if (b < B && k < K) v = X[(long long)(perm ? perm[b] : b) * ldx + k];
+        else if (b < B && k == K) v = 1.f;                            // the ones row of the transposed image
+        tile[r][tx] = v;
+        if (b < Bp && k < Kp) xb[(long long)b * Kp + k] = to_bf16(k < K ? v : 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, b = b0 + tx;
+        if (k <= K && b < Bp) xt[(long long)k * ldt + b] = to_bf16(tile[tx][r]);
+    }
+}
+void isk_launch_gather_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
+                              hipStream_t st) {
+    const dim3 grid((Bp + 31) / 32, (K + 1 + 31) / 32);              // covers k = K (the ones row)
+    hipLaunchKernelGGL(gather_images_kernel, grid, dim3(256), 0, st, X, ldx, perm, B, Bp, K, Kp, (u16*)xb, (u16*)xt, ldt);
+}
+
+// Wt_l[n][k] = bf16(W_l[n][k] * scale[k]) for every layer in one launch (forward B operands), W in Flux layout mem [k][n];
+// scale = the LayerNorm scale for layer 0 (or nullptr).  32 x 32 tiles through LDS; columns k >= K are zero padding.
+__global__ __launch_bounds__(256) void wt_images_kernel(WtImagesArgs a) {
+    __shared__ float tile[32][33];
+    ISK_LATENCY_CHAIN_PRIO();
+    int l = 0, blk = blockIdx.x;
+    while (l + 1 < a.nlayers && blk >= a.first_block[l + 1]) ++l;
+    blk -= a.first_block[l];
+    const int K = a.K[l], N = a.N[l], Kp = a.Kp[l];
+    const int tk = (Kp + 31) / 32;
+    const int k0 = (blk % tk) * 32, n0 = (blk / tk) * 32;
+    const float* W = a.theta + a.off_W[l];
+    const float* sc = (l == 0) ? a.scale0 : nullptr;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        tile[r][tx] = (k < K && n < N) ? W[(long long)k * N + n] * (sc ? sc[k] : 1.f) : 0.f;
+    }
+    __syncthreads();
+    u16* out = (u16*)a.Wt[l];
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        if (n < N && k < Kp) out[(long long)n * Kp + k] = to_bf16(tile[tx][r]);
+    }
+}
+void isk_launch_wt_images(WtImagesArgs& a, hipStream_t st) {
+    int total = 0;
+    for (int l = 0; l < a.nlayers; ++l) { a.first_block[l] = total; total += ((a.Kp[l] + 31) / 32) * ((a.N[l] + 31) / 32); }
+    hipLaunchKernelGGL(wt_images_kernel, dim3(total), dim3(256), 0, st, a);
+}
+
+// delta_L and the batch loss from the last layer's pre-activations (as loss_delta_kernel of kernels_layered.hip), plus the
+// bf16 images of delta_L: d16 [Bp][ld16] (A operand of dX) and dt16 [nout][Bp] (B operand of dW + db)
+__global__ __launch_bounds__(1024) void loss_delta16_kernel(const float* __restrict__ z, int ld, const float* __restrict__ target,
+                                                            const float* __restrict__ lossw, const int* __restrict__ perm, int B, int Bp,
+                                                            int nout, float inv_div, int lastact, u16* __restrict__ d16, int ld16,
+                                                            u16* __restrict__ dt16, long long ldt, float* __restrict__ loss_slot,
+                                                            const int* __restrict__ rank_err) {
+    __shared__ float red[16];
+    float ls = 0.f;
+    const long long tot = (long long)Bp * ld16;
+    for (long long e = threadIdx.x; e < tot; e += 1024) {
+        const int n = (int)(e / ld16), o = (int)(e % ld16);
+        float d = 0.f;
+        if (n < B && o < nout) {
+            const long long prow = perm ? perm[n] : n;
+            const float zz = z[(long long)n * ld + o];
+            const float w = lossw[o];
+            const float r = (g_act(lastact, zz) - target[prow * nout + o]) * w;
+            ls += r * r;
+            d = 2.f * r * w * inv_div * g_dact(lastact, zz);
+        }
+        d16[e] = to_bf16(d);
+        if (o < nout) dt16[(long long)o * ldt + n] = to_bf16(d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ls;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        loss_slot[0] = t;
+        loss_slot[1] = rank_err ? (float)*rank_err : 0.f;
+    }
+}
+void isk_launch_loss_delta16(const float* z, int ld, const float* target, const float* lossw, const int* perm, int B, int Bp, int nout,
+                             float inv_div, int lastact, void* d16, int ld16, void* dt16, long long ldt, float* loss_slot,
+                             const int* rank_err, hipStream_t st) {
+    hipLaunchKernelGGL(loss_delta16_kernel, dim3(1), dim3(1024), 0, st, z, ld, target, lossw, perm, B, Bp, nout, inv_div, lastact,
+                       (u16*)d16, ld16, (u16*)dt16, ldt, loss_slot, rank_err);
+}

@@ -87,13 +87,13 @@ def test_native_driver_two_ranks_every_forward_mode(gpu_pkg, mock_lib, fwd_mode)
     """what bench.py runs on a multi-GPU node -- ISA target, featurization inside every iteration, the side-stream featurizer
     beside the training steps and the collectives -- in the f32, split-bf16 and split-f16 (unit-blocked operand planes)
     forward modes (ISK_FWD_MODE is inherited by the ranks)"""
-    test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, 3, 16, 1, True)
+    test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, 3, 16, 1, True, "adam")
 
 
 @pytest.mark.parametrize("nout,minibatch,epochs,every_iter,opt", [(1, 64, 1, False, "adam"), (3, 64, 1, False, "adam"), (3, 0, 1, False, "adam"),
                                                                  (3, 48, 2, False, "adam"), (1, 16, 2, True, "adam"),
                                                                  (3, 48, 2, False, "nesterov"), (1, 16, 1, True, "nesterov")])
-def test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, nout, minibatch, epochs, every_iter, opt="adam"):
+def test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, nout, minibatch, epochs, every_iter, opt):
     """every_iter: featurization inside every iteration, i.e. the side-stream featurizer beside the training steps and the
     collectives (what bench.py runs on a multi-GPU node); minibatch 16 gives the >= 4 optimizer steps that switch it on"""
     import torch.multiprocessing as mp
