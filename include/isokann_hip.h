@@ -144,6 +144,7 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *   dense_groups        1        wide networks, bf16 forward: one grouped launch per layer
  *   layered_blas        1        wide networks, f32 training: rocBLAS sgemm for the plain layer GEMMs (0: in-house kernels)
  *   train_bf16          0        wide networks: training GEMMs on bf16 operands (f32 master weights, f32 accumulate)
+ *   wide_fused          1        wide networks, plain-bf16 forward (forward_mode 2): one fused kernel, activations in LDS
  *   dp_force_coll       0        issue the native collectives on a one-rank communicator (tests)
  *   debug_feat_copy / debug_stamps / debug_rowmod   0   diagnostics
  * Read-only keys of isk_get_option: forward_mode (effective), layered, planes, nparams_engine. */

@@ -388,6 +388,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
         ALLOC(e->d_W0g, (size_t)F * cfg->widths[1] * sizeof(float));
         ALLOC(e->d_zero, (size_t)4096 * sizeof(float));
         (void)hipMemset(e->d_zero, 0, (size_t)4096 * sizeof(float));
+        if (bf16_weight_images_alloc(e) != ISK_OK) { isk_destroy(e); return fail(ISK_ENOMEM, "hipMalloc: bf16 weight images"); }
     }
 #undef ALLOC
     if (e->cfg.forward_mode == 3) {
@@ -427,6 +428,7 @@ extern "C" void isk_destroy(isk_engine* e) {
     free_dev(e->d_W16); free_dev(e->d_wmax); free_dev(e->d_wscale);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_W16L[l]); free_dev(e->d_WtT[l]); }
     free_dev(e->d_G0); free_dev(e->d_D0); free_dev(e->d_zero); free_dev(e->d_W0g);
+    for (int l = 0; l < ISK_MAX_LAYERS; ++l) free_dev(e->b16.Wt[l]);
     blas_release(e);
     dp_comm_release(e);
     free_dev(e->d_gks); free_dev(e->d_gchi);

@@ -237,6 +237,8 @@ int forward_layered(isk_engine* e, const float* X, long long S, float* out, floa
 void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float inv_div);
 void bf16_train_release(isk_engine* e);
 bool bf16_train_active(const isk_engine* e);
+int bf16_weight_images_alloc(isk_engine* e);             // isk_create, layered engines: the [max(N, 512)][pad32 K] bf16 images W_l'
+void bf16_weight_images_ensure(isk_engine* e);           // refresh them if theta changed since they were built
 bool blas_ready(isk_engine* e);
 void blas_release(isk_engine* e);
 int bf16_planes(const isk_engine* e);

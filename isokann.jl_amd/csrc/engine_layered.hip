@@ -8,7 +8,25 @@ int bf16_planes(const isk_engine* e) { return e->cfg.forward_mode == 1 ? 3 : (e-
 
 // layer-by-layer forward: every layer is a sequence of dense-block launches of the same GEMM kernels; hidden
 // activations [S][pad32(H)] ping-pong between actA / actB (zero-initialised: the padding columns stay 0)
+// plain-bf16 forward (forward_mode 2) of a network whose hidden layers are <= 512 wide: ONE fused kernel, activations in LDS
+static int forward_wide_bf16(isk_engine* e, const float* X, long long S, float* out) {
+    WideFwdArgs a = {};
+    a.X = X; a.S = S; a.Fp = e->Fp; a.nhidden = e->L - 1;
+    for (int l = 0; l + 1 < e->L; ++l) {
+        a.N[l] = e->cfg.widths[l + 1]; a.Kp[l] = isk_pad32(e->cfg.widths[l]); a.Wt[l] = e->b16.Wt[l];
+        a.bias[l] = (l == 0 && e->cfg.layernorm) ? e->d_bias[0] : e->d_theta + e->off_b[l];
+    }
+    a.act = e->cfg.activation;
+    a.Wlast = e->d_theta + e->off_W[e->L - 1]; a.blast = e->d_theta + e->off_b[e->L - 1];
+    a.Klast = e->cfg.widths[e->L - 1]; a.nout = e->nout; a.lastact = e->cfg.lastactivation;
+    a.out = out; a.out_ld = e->nout;
+    if (e->L < 2 || !e->b16.Wt[0] || !isk_wide_fwd_ok(a)) return ISK_EUNSUPPORTED;
+    bf16_weight_images_ensure(e);
+    return isk_launch_wide_fwd(a, e->stream);
+}
+
 int forward_layered(isk_engine* e, const float* X, long long S, float* out, float* actA, float* actB) {
+    if (bf16_planes(e) == 1 && e->opt.wide_fused && forward_wide_bf16(e, X, S, out) == 0) return 0;
     const float* in = X;
     int in_ld = e->Fp;
     for (int l = 0; l < e->L; ++l) {
@@ -168,11 +186,38 @@ static bool launch_grads_layered_blas(isk_engine* e, const int* d_idx, int B, fl
 // ---------------------------------------------------------------------------------------
 bool bf16_train_active(const isk_engine* e) { return e->layered && e->opt.train_bf16 != 0; }
 
+// the per-batch images (the weight images belong to the engine, not to the data)
 void bf16_train_release(isk_engine* e) {
     auto& b = e->b16;
     free_dev(b.xb); free_dev(b.xt); free_dev(b.G0);
-    for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(b.a16[l]); free_dev(b.at16[l]); free_dev(b.d16[l]); free_dev(b.dt16[l]); free_dev(b.Wt[l]); }
-    b = isk_engine::Bf16Train();
+    b.xb = b.xt = nullptr; b.G0 = nullptr;
+    for (int l = 0; l < ISK_MAX_LAYERS; ++l) {
+        free_dev(b.a16[l]); free_dev(b.at16[l]); free_dev(b.d16[l]); free_dev(b.dt16[l]);
+        b.a16[l] = b.at16[l] = b.d16[l] = b.dt16[l] = nullptr;
+    }
+    b.rows = 0;
+}
+
+int bf16_weight_images_alloc(isk_engine* e) {
+    for (int l = 0; l < e->L; ++l) {
+        const size_t bytes = (size_t)std::max(e->cfg.widths[l + 1], 512) * isk_pad32(e->cfg.widths[l]) * 2;    // rows >= N stay zero
+        if (hipMalloc(&e->b16.Wt[l], bytes) != hipSuccess) return ISK_ENOMEM;
+        (void)hipMemset(e->b16.Wt[l], 0, bytes);
+    }
+    e->b16.wt_dirty = true;
+    return ISK_OK;
+}
+
+void bf16_weight_images_ensure(isk_engine* e) {
+    auto& b = e->b16;
+    if (!b.wt_dirty || !b.Wt[0]) return;
+    WtImagesArgs w = {};
+    w.theta = e->d_theta; w.scale0 = e->cfg.layernorm ? e->d_theta + e->off_lns : nullptr; w.nlayers = e->L;
+    for (int l = 0; l < e->L; ++l) {
+        w.off_W[l] = e->off_W[l]; w.K[l] = e->cfg.widths[l]; w.N[l] = e->cfg.widths[l + 1]; w.Kp[l] = isk_pad32(w.K[l]); w.Wt[l] = b.Wt[l];
+    }
+    isk_launch_wt_images(w, e->stream);
+    b.wt_dirty = false;
 }
 
 __global__ void fill_u16_kernel(unsigned short* p, long long n, unsigned short v) {
@@ -196,14 +241,13 @@ static bool bf16_train_ensure(isk_engine* e, long long Bp) {
         alloc(&b.at16[l], (size_t)(N + 1) * rows * 2);
         alloc(&b.d16[l], (size_t)rows * isk_pad32(N) * 2);
         alloc(&b.dt16[l], (size_t)N * rows * 2);
-        alloc(&b.Wt[l], (size_t)N * isk_pad32(K) * 2);
+        (void)K;
         if (ok) hipLaunchKernelGGL(fill_u16_kernel, dim3(64), dim3(256), 0, e->stream, (unsigned short*)b.at16[l] + (size_t)N * rows, rows,
                                    (unsigned short)0x3F80);           // the row of ones (bf16 1.0) behind the N activation rows
     }
     if (ok && e->cfg.layernorm) alloc((void**)&b.G0, (size_t)(e->F + 1) * e->cfg.widths[1] * sizeof(float));
     if (!ok) { bf16_train_release(e); return false; }
     b.rows = rows;
-    b.wt_dirty = true;
     return true;
 }
 
@@ -215,16 +259,13 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
     const long long ldB = b.rows;                    // row length of the transposed images
     hipStream_t st = e->stream;
     const bool ln = e->cfg.layernorm != 0;
-    isk_launch_gather_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, st);
-    if (b.wt_dirty) {
-        WtImagesArgs w = {};
-        w.theta = e->d_theta; w.scale0 = ln ? e->d_theta + e->off_lns : nullptr; w.nlayers = L;
-        for (int l = 0; l < L; ++l) { w.off_W[l] = e->off_W[l]; w.K[l] = e->cfg.widths[l]; w.N[l] = e->cfg.widths[l + 1]; w.Kp[l] = isk_pad32(w.K[l]); w.Wt[l] = b.Wt[l]; }
-        isk_launch_wt_images(w, st);
-        b.wt_dirty = false;
-    }
+    // head fusion: last layer forward + loss + the deltas of the last TWO layers in one launch (nout <= 16)
+    const bool head = L >= 2 && e->nout <= 16 && e->cfg.widths[L - 1] <= 1024;
+    isk_launch_gather_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, head ? e->d_grad + e->nparams : nullptr,
+                             e->d_rank_err, st);
+    bf16_weight_images_ensure(e);
     bool ok = true;
-    for (int l = 0; l < L && ok; ++l) {
+    for (int l = 0; l < (head ? L - 1 : L) && ok; ++l) {
         const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];
         Gemm16Args g = {};
         g.A = l == 0 ? b.xb : b.a16[l - 1]; g.lda = l == 0 ? e->Fp : isk_pad32(K); g.a_f32 = 0;
@@ -238,31 +279,54 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
         ok = isk_launch_gemm16(g, st) == 0;
     }
     if (!ok) return false;
-    isk_launch_loss_delta16(e->d_lz[L - 1], isk_pad16(e->nout), e->d_target, e->d_lossw, d_idx, B, Bp, e->nout, inv_div, e->cfg.lastactivation,
-                            b.d16[L - 1], isk_pad32(e->nout), b.dt16[L - 1], ldB, e->d_grad + e->nparams, e->d_rank_err, st);
+    if (head) {
+        Head16Args h = {};
+        const int Kh = e->cfg.widths[L - 1];
+        h.a16 = b.a16[L - 2]; h.lda = isk_pad32(Kh);
+        h.zprev = e->d_lz[L - 2]; h.ldzp = isk_pad16(Kh);
+        h.W = e->d_theta + e->off_W[L - 1]; h.bias = e->d_theta + e->off_b[L - 1];
+        h.target = e->d_target; h.lossw = e->d_lossw; h.perm = d_idx;
+        h.B = B; h.Bp = Bp; h.Kh = Kh; h.nout = e->nout; h.act = act_of_layer(e, L - 2); h.lastact = e->cfg.lastactivation;
+        h.inv_div = inv_div;
+        h.z = e->d_lz[L - 1]; h.ldz = isk_pad16(e->nout);
+        h.dt16_last = b.dt16[L - 1]; h.ldt = ldB;
+        h.d16 = b.d16[L - 2]; h.ld16 = isk_pad32(Kh); h.dt16 = b.dt16[L - 2];
+        h.loss_slot = e->d_grad + e->nparams;
+        if (isk_launch_head16(h, st) != 0) return false;
+    } else {
+        isk_launch_loss_delta16(e->d_lz[L - 1], isk_pad16(e->nout), e->d_target, e->d_lossw, d_idx, B, Bp, e->nout, inv_div, e->cfg.lastactivation,
+                                b.d16[L - 1], isk_pad32(e->nout), b.dt16[L - 1], ldB, e->d_grad + e->nparams, e->d_rank_err, st);
+    }
+    Gemm16Args carry = {};                           // head: dW of the last layer rides in the next group
+    bool have_carry = false;
     for (int l = L - 1; l >= 0 && ok; --l) {
         const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];
         const bool ln0 = l == 0 && ln;
-        Gemm16Args g = {};
+        Gemm16Args pair[3] = {};
+        Gemm16Args& g = pair[0];
         g.A = l == 0 ? b.xt : b.at16[l - 1]; g.lda = ldB; g.a_f32 = 0;
         g.B = b.dt16[l]; g.ldb = ldB; g.b_f32 = 0;
         g.M = K + 1; g.Nn = N; g.Kc = Bp; g.kvalid = Bp;
         g.epi = ISK_G16_DW;
         g.gout = ln0 ? b.G0 : e->d_grad + e->off_W[l]; g.gld = N;           // row K lands on b_l: Flux keeps it right behind W_l
-        ok = isk_launch_gemm16(g, st) == 0;
-        if (ln0) {
-            (void)hipMemcpyAsync(e->d_grad + e->off_b[0], b.G0 + (size_t)K * N, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st);
-            isk_launch_ln_unfold(b.G0, b.G0 + (size_t)K * N, e->d_theta, e->off_W[0], e->off_lns, e->off_lnb, e->F, N, e->d_grad, st);
-        }
-        if (l > 0 && ok) {
-            Gemm16Args x = {};
+        if (head && l == L - 1) { carry = g; have_carry = true; continue; }       // its delta_{L-1} came out of the head kernel
+        int np = 1;
+        if (l > 0) {
+            np = 2;
+            Gemm16Args& x = pair[1];
             x.A = b.d16[l]; x.lda = isk_pad32(N); x.a_f32 = 0;
             x.B = e->d_theta + e->off_W[l]; x.ldb = N; x.b_f32 = 1;           // Flux (out, in) column-major == [k][n]: n contiguous
             x.M = B; x.Nn = K; x.Kc = isk_pad32(N); x.kvalid = N;
             x.epi = ISK_G16_DX;
             x.zprev = e->d_lz[l - 1]; x.ldzp = isk_pad16(K); x.act = act_of_layer(e, l - 1);
             x.o16 = b.d16[l - 1]; x.ld16 = isk_pad32(K); x.M16 = Bp; x.ot16 = b.dt16[l - 1]; x.ldt = (int)ldB;
-            ok = isk_launch_gemm16(x, st) == 0;
+        }
+        if (have_carry) { pair[np++] = carry; have_carry = false; }
+        // dW_l + db_l and delta_{l-1} both need only delta_l: one launch
+        ok = isk_launch_gemm16_group(pair, np, st) == 0;
+        if (ln0) {
+            (void)hipMemcpyAsync(e->d_grad + e->off_b[0], b.G0 + (size_t)K * N, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st);
+            isk_launch_ln_unfold(b.G0, b.G0 + (size_t)K * N, e->d_theta, e->off_W[0], e->off_lns, e->off_lnb, e->F, N, e->d_grad, st);
         }
     }
     e->last_nslab = 1;

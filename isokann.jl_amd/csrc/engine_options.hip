@@ -26,6 +26,7 @@ const OptDesc kOptions[] = {
     {"fwd_waves_per_simd", &IskOptions::fwd_waves_per_simd, 1, 4},
     {"dp_force_coll", &IskOptions::dp_force_coll, 0, 1},
     {"train_bf16", &IskOptions::train_bf16, 0, 1},
+    {"wide_fused", &IskOptions::wide_fused, 0, 1},
     {"debug_inject_rank_error", &IskOptions::debug_inject_rank_error, 0, 1 << 30},
     {"debug_feat_copy", &IskOptions::debug_feat_copy, 0, 64},
     {"debug_stamps", &IskOptions::debug_stamps, 0, 1},

@@ -32,6 +32,7 @@ struct IskOptions {
     int grad1_nw8 = -1;           // train_grad1n variant: 1 = 8 waves, 0 = 16 waves, -1 = 8 while the featurizer shares the CUs
     int fwd_waves_per_simd = 1;   // residency of the f32 forward kernel
     int dp_force_coll = 0;        // issue the native collectives on a one-rank communicator (tests)
+    int wide_fused = 1;           // layered path, plain-bf16 forward: the fused wide kernel (0: layer by layer through HBM)
     int train_bf16 = 0;           // layered path: training GEMMs with bf16 operands (f32 master weights, f32 accumulate): the C5
                                   // arithmetic of BASELINE.json; 0 = f32
     int debug_inject_rank_error = 0;   // tests: in the native data-parallel run this rank flags an error at its n-th optimizer step
@@ -138,6 +139,21 @@ void isk_launch_fold_f16(const float* Wt, void* out, int Kp, int nt, const unsig
 #define ISK_MAX_NT_BF16 16   // output tiles per workgroup of the plain-bf16 forward
 int  isk_bf16_chunks(int Kp);     // 32-feature chunks in the plane image (padded to the kernel's ring size)
 
+// ---------------------------------------------------------------- fused bf16 forward for wide networks (kernels_fwd_wide.hip) ----
+struct WideFwdArgs {
+    const float* X; long long S; int Fp;          // [S][Fp] f32 standardised feature rows (zero padded)
+    int nhidden;                                  // hidden layers (all layers but the last), each of width <= 512
+    int N[ISK_MAX_LAYERS], Kp[ISK_MAX_LAYERS];    // width and padded contraction (multiple of 32) per hidden layer
+    const void* Wt[ISK_MAX_LAYERS];               // bf16 images [512][Kp] (rows >= N zero): isk_launch_wt_images
+    const float* bias[ISK_MAX_LAYERS];
+    int act;
+    const float* Wlast; const float* blast;       // last layer, f32, Flux layout (out, in) column-major; Klast = N[nhidden - 1]
+    int Klast, nout, lastact;
+    float* out; long long out_ld;                 // [S][out_ld]
+};
+int isk_wide_fwd_ok(const WideFwdArgs& a);
+int isk_launch_wide_fwd(const WideFwdArgs& a, hipStream_t st);
+
 // ---------------------------------------------------------------- layered (wide-network) path ----
 void isk_launch_act(const float* z, float* a, long long rows, int ld, int width, int act, hipStream_t st);
 // helpers of the rocBLAS variant of the layered training path (the library runs the plain GEMMs)
@@ -184,9 +200,29 @@ struct Gemm16Args {
     float* gout; long long gld;
 };
 int  isk_launch_gemm16(const Gemm16Args& a, hipStream_t st);
+#define ISK_G16_MAXGROUP 3
+struct Gemm16Group {                             // several independent products as ONE launch (kernels_gemm16.hip)
+    Gemm16Args g[ISK_G16_MAXGROUP];
+    int n, gx[ISK_G16_MAXGROUP], first[ISK_G16_MAXGROUP];
+};
+int  isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st);
 // gathered batch rows -> xb [Bp][Kp] bf16 and xt [K + 1][ldt] bf16 (row K = ones; columns [B, Bp) zeros)
 void isk_launch_gather_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
-                              hipStream_t st);
+                              float* loss_slot /* optional: zeroed, [1] <- *rank_err */, const int* rank_err, hipStream_t st);
+// last layer forward + loss + delta_L + delta_{L-1} (with its two bf16 images) in one launch, nout <= 16 (kernels_gemm16.hip)
+struct Head16Args {
+    const void* a16; long long lda;              // activations of the last hidden layer, bf16 [Bp][lda]
+    const float* zprev; int ldzp;                // its pre-activations (f32)
+    const float* W; const float* bias;           // last layer: W (out, in) column-major == [k][o], bias [nout]
+    const float* target; const float* lossw; const int* perm;
+    int B, Bp, Kh, nout, act, lastact;
+    float inv_div;
+    float* z; int ldz;                           // optional: z_L
+    void* dt16_last; long long ldt;              // delta_L' [nout][ldt]
+    void* d16; int ld16; void* dt16;             // delta_{L-1} [Bp][ld16] and its transpose [Kh][ldt]
+    float* loss_slot;                            // += batch loss (atomic; zeroed by the step's gather kernel)
+};
+int  isk_launch_head16(const Head16Args& a, hipStream_t st);
 struct WtImagesArgs {
     const float* theta; const float* scale0;     // scale0: LayerNorm scale folded into layer 0's image (or nullptr)
     int nlayers;

@@ -14,6 +14,8 @@
 // ahead -- a 32 x 64 output tile per 256-thread workgroup whose four waves SPLIT K (256..504 workgroups for every product of
 // C5: the whole chip, 8..16 k-steps per wave), one LDS reduction, and fused epilogues (bias + activation + the bf16 / transposed
 // images the next products need), so that a layer is one launch forward and two backward.
+#include <type_traits>
+
 #include "isk_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -51,8 +53,8 @@ __device__ __forceinline__ u16 to_bf16(float v) {
 
 // 8 consecutive contraction elements of one operand row as an MFMA fragment; kmax: elements at k >= kmax read as 0 (only the
 // unaligned / ragged slow path passes kmax < the padded length)
-template <bool F32, bool SLOW>
-__device__ __forceinline__ bf16x8 load_frag(const void* base, long long off, int k0, int kmax) {
+template <bool SLOW>
+__device__ __forceinline__ bf16x8 load_frag(const void* base, const int F32, long long off, int k0, int kmax) {
     if (SLOW) {
         bf16x8 r;
 #pragma unroll
@@ -76,13 +78,14 @@ __device__ __forceinline__ bf16x8 load_frag(const void* base, long long off, int
 #define G16_TN 64
 #define G16_LDR 65           // LDS row stride of the reduction tile (floats): the transposed pass reads down a column
 
-template <bool AF32, bool BF32, bool SLOW>
-__global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args a) {
-    __shared__ float red[4][G16_TM][G16_LDR];
-    ISK_LATENCY_CHAIN_PRIO();
+// one 32 x 64 output tile (bx, by) of problem `a`; the operand element types are wave-uniform run-time flags (a grouped launch
+// mixes products with bf16 and f32 operands)
+template <bool SLOW>
+__device__ __forceinline__ void gemm16_tile(const Gemm16Args& a, const int bx, const int by, float (*red)[G16_TM][G16_LDR]) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lq = lane >> 4;
-    const int i0 = blockIdx.x * G16_TM, j0 = blockIdx.y * G16_TN;
+    const int i0 = bx * G16_TM, j0 = by * G16_TN;
+    const int AF32 = a.a_f32, BF32 = a.b_f32;
     long long offA[2], offB[4];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) { int r = i0 + rt * 16 + li; r = r < a.M ? r : a.M - 1; offA[rt] = (long long)r * a.lda + lq * 8; }
@@ -94,32 +97,38 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args a) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = a.Kc / 32;
-    bf16x8 fa[2], fb[4], na[2], nb[4];
-    int ks = wave;
-    if (ks < nk) {
+    // this wave's k-steps: wave, wave + 4, ...  Fragments are requested TWO steps ahead (three register sets, rotated statically):
+    // the chain of a wave is 8..16 dependent memory round trips long, and beside the side-stream featurizer one of them is ~1 us
+    bf16x8 fa[3][2], fb[3][4];
+    auto loadset = [&](int ks, auto SLOT) {
+        constexpr int sl = decltype(SLOT)::value;
+        if (ks < nk) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) fa[rt] = load_frag<AF32, SLOW>(a.A, offA[rt] + ks * 32, ks * 32 + lq * 8, a.kvalid);
+            for (int rt = 0; rt < 2; ++rt) fa[sl][rt] = load_frag<SLOW>(a.A, AF32, offA[rt] + ks * 32, ks * 32 + lq * 8, a.kvalid);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) fb[ct] = load_frag<BF32, SLOW>(a.B, offB[ct] + ks * 32, ks * 32 + lq * 8, a.kvalid);
-    }
-    for (; ks < nk; ks += 4) {
-        const int kn = ks + 4;
-        if (kn < nk) {                                   // the next step's fragments are requested before this step's MFMAs
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) na[rt] = load_frag<AF32, SLOW>(a.A, offA[rt] + kn * 32, kn * 32 + lq * 8, a.kvalid);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) nb[ct] = load_frag<BF32, SLOW>(a.B, offB[ct] + kn * 32, kn * 32 + lq * 8, a.kvalid);
+            for (int ct = 0; ct < 4; ++ct) fb[sl][ct] = load_frag<SLOW>(a.B, BF32, offB[ct] + ks * 32, ks * 32 + lq * 8, a.kvalid);
         }
+    };
+    auto mma = [&](auto SLOT) {
+        constexpr int sl = decltype(SLOT)::value;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
-        if (kn < nk) {
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) fa[rt] = na[rt];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) fb[ct] = nb[ct];
-        }
+            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[sl][rt], fb[sl][ct], acc[rt][ct], 0, 0, 0);
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+    int ks = wave;
+    loadset(ks, S0{});
+    loadset(ks + 4, S1{});
+    for (; ks < nk; ks += 12) {
+        loadset(ks + 8, S2{});
+        mma(S0{});
+        if (ks + 4 >= nk) break;
+        loadset(ks + 12, S0{});
+        mma(S1{});
+        if (ks + 8 >= nk) break;
+        loadset(ks + 16, S1{});
+        mma(S2{});
     }
     // C layout of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + r
 #pragma unroll
@@ -129,8 +138,20 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][rt * 16 + 4 * lq + r][ct * 16 + li] = acc[rt][ct][r];
     __syncthreads();
-    // pass 1: consecutive threads along j -- the K-split sum, the epilogue, the row-major stores
+    // pass 1: consecutive threads along j -- the K-split sum, the epilogue, the row-major stores.  Every global operand of the
+    // epilogue (bias / previous pre-activations) is requested UNCONDITIONALLY, from clamped addresses, before the first use: behind
+    // a per-element `if` the eight loads of a thread became eight dependent memory round trips (~1 us each: the whole kernel took
+    // 12 us for a product that needs 2)
     const bool want_t = a.ot16 != nullptr;
+    float ext[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int idx = tid + 256 * p, row = idx >> 6, col = idx & 63;
+        const int ic = (i0 + row) < a.M ? (i0 + row) : a.M - 1, jc = (j0 + col) < a.Nn ? (j0 + col) : a.Nn - 1;
+        ext[p] = 0.f;
+        if (a.epi == ISK_G16_FWD) { if (a.bias) ext[p] = a.bias[jc]; }
+        else if (a.epi == ISK_G16_DX) ext[p] = a.zprev[(long long)ic * a.ldzp + jc];
+    }
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int idx = tid + 256 * p, row = idx >> 6, col = idx & 63;
@@ -139,14 +160,16 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args a) {
         const bool in = i < a.M && j < a.Nn;
         float o = 0.f;                                   // what the bf16 images receive (0 in the padding)
         if (a.epi == ISK_G16_FWD) {
+            v += ext[p];
+            const float av = g_act(a.act, v);
             if (in) {
-                v += a.bias ? a.bias[j] : 0.f;
                 a.z[(long long)i * a.ldz + j] = v;
-                o = g_act(a.act, v);
+                o = av;
                 if (a.o32) a.o32[(long long)i * a.ld32 + j] = o;
             }
         } else if (a.epi == ISK_G16_DX) {
-            if (in) o = v * g_dact(a.act, a.zprev[(long long)i * a.ldzp + j]);
+            const float dv = v * g_dact(a.act, ext[p]);
+            if (in) o = dv;
         } else {                                         // ISK_G16_DW: rows 0..K-1 are dW (Flux layout [k][n]), row K is db
             if (in) a.gout[(long long)i * a.gld + j] = v;
         }
@@ -164,20 +187,63 @@ __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args a) {
     }
 }
 
-int isk_launch_gemm16(const Gemm16Args& a, hipStream_t st) {
-    if (a.M < 1 || a.Nn < 1 || a.Kc < 32 || a.Kc % 32) return ISK_EINVAL;
-    const dim3 grid((a.M16 > a.M ? a.M16 : a.M) / G16_TM + (((a.M16 > a.M ? a.M16 : a.M) % G16_TM) ? 1 : 0), (a.Nn + G16_TN - 1) / G16_TN);
+template <bool SLOW>
+__global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args a) {
+    __shared__ float red[4][G16_TM][G16_LDR];
+    ISK_LATENCY_CHAIN_PRIO();
+    gemm16_tile<SLOW>(a, blockIdx.x, blockIdx.y, red);
+}
+
+// several INDEPENDENT products in one launch (dW_l beside dX_l: both need only delta_l): a step of the layered training path is a
+// chain of dependent launches, and two products that do not depend on each other should not wait for each other
+__global__ __launch_bounds__(256) void gemm16_group_kernel(Gemm16Group g) {
+    __shared__ float red[4][G16_TM][G16_LDR];
+    ISK_LATENCY_CHAIN_PRIO();
+    int p = 0, b = blockIdx.x;
+    while (p + 1 < g.n && b >= g.first[p + 1]) ++p;
+    b -= g.first[p];
+    gemm16_tile<false>(g.g[p], b % g.gx[p], b / g.gx[p], red);
+}
+
+static bool g16_grid(const Gemm16Args& a, int* gx, int* gy, bool* slow) {
+    if (a.M < 1 || a.Nn < 1 || a.Kc < 32 || a.Kc % 32) return false;
+    const int rows = a.M16 > a.M ? a.M16 : a.M;
+    *gx = (rows + G16_TM - 1) / G16_TM; *gy = (a.Nn + G16_TN - 1) / G16_TN;
     // vector loads need 16-byte aligned rows; anything else (odd widths, a contraction that is not a multiple of 32) takes the
     // elementwise path
-    const bool a_al = ((uintptr_t)a.A % 16 == 0) && (a.lda % 8 == 0), b_al = ((uintptr_t)a.B % 16 == 0) && (a.ldb % 8 == 0);
-    const bool slow = !a_al || !b_al || a.kvalid < a.Kc;
+    const int ea = a.a_f32 ? 4 : 8, eb = a.b_f32 ? 4 : 8;
+    const bool a_al = ((uintptr_t)a.A % 16 == 0) && (a.lda % ea == 0), b_al = ((uintptr_t)a.B % 16 == 0) && (a.ldb % eb == 0);
+    *slow = !a_al || !b_al || a.kvalid < a.Kc;
+    return true;
+}
+
+int isk_launch_gemm16(const Gemm16Args& a, hipStream_t st) {
+    int gx, gy; bool slow;
+    if (!g16_grid(a, &gx, &gy, &slow)) return ISK_EINVAL;
     void* args[] = {(void*)&a};
-    const void* fn;
-#define G16PICK(AF, BF) (slow ? (const void*)gemm16_kernel<AF, BF, true> : (const void*)gemm16_kernel<AF, BF, false>)
-    if (a.a_f32) fn = a.b_f32 ? G16PICK(true, true) : G16PICK(true, false);
-    else fn = a.b_f32 ? G16PICK(false, true) : G16PICK(false, false);
-#undef G16PICK
-    return hipLaunchKernel(fn, grid, dim3(256), args, 0, st) == hipSuccess ? 0 : ISK_EHIP;
+    const void* fn = slow ? (const void*)gemm16_kernel<true> : (const void*)gemm16_kernel<false>;
+    return hipLaunchKernel(fn, dim3(gx, gy), dim3(256), args, 0, st) == hipSuccess ? 0 : ISK_EHIP;
+}
+
+int isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st) {
+    if (n < 1 || n > ISK_G16_MAXGROUP) return ISK_EINVAL;
+    Gemm16Group g;
+    g.n = n;
+    int total = 0;
+    bool any_slow = false;
+    for (int p = 0; p < n; ++p) {
+        int gx, gy; bool slow;
+        if (!g16_grid(list[p], &gx, &gy, &slow)) return ISK_EINVAL;
+        any_slow |= slow;
+        g.g[p] = list[p]; g.gx[p] = gx; g.first[p] = total;
+        total += gx * gy;
+    }
+    if (any_slow || n == 1) {                            // the rare ragged shapes: one launch per product
+        for (int p = 0; p < n; ++p) { const int r = isk_launch_gemm16(list[p], st); if (r) return r; }
+        return 0;
+    }
+    void* args[] = {(void*)&g};
+    return hipLaunchKernel((const void*)gemm16_group_kernel, dim3(total), dim3(256), args, 0, st) == hipSuccess ? 0 : ISK_EHIP;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -187,16 +253,33 @@ int isk_launch_gemm16(const Gemm16Args& a, hipStream_t st) {
 // transposed image with the row of ones behind the K features: the first layer's dW + db operand).  One 32 x 32 tile per
 // workgroup through LDS; rows >= B and columns >= K are written as zeros (they are contraction padding).
 __global__ __launch_bounds__(256) void gather_images_kernel(const float* __restrict__ X, int ldx, const int* __restrict__ perm, int B, int Bp,
-                                                            int K, int Kp, u16* __restrict__ xb, u16* __restrict__ xt, long long ldt) {
+                                                            int K, int Kp, u16* __restrict__ xb, u16* __restrict__ xt, long long ldt,
+                                                            float* __restrict__ loss_slot, const int* __restrict__ rank_err) {
     __shared__ float tile[32][33];
     ISK_LATENCY_CHAIN_PRIO();
+    // the step's first kernel: the batch loss is accumulated with atomics by the head kernel, the flag slot behind it is set here
+    if (loss_slot && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { loss_slot[0] = 0.f; loss_slot[1] = rank_err ? (float)*rank_err : 0.f; }
     const int b0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 8 row groups
+    // the four rows of a thread: indices, then values, requested together from clamped addresses (no load behind a branch: each
+    // would be a memory round trip of its own)
+    long long src[4];
+    float val[4];
 #pragma unroll
-    for (int r = ty; r < 32; r += 8) {
+    for (int q = 0; q < 4; ++q) {
+        const int b = b0 + ty + 8 * q;
+        const int bc = b < B ? b : B - 1;
+        src[q] = perm ? perm[bc] : bc;
+    }
+    const int kc = (k0 + tx) < K ? (k0 + tx) : K - 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) val[q] = X[src[q] * ldx + kc];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = ty + 8 * q;
         const int b = b0 + r, k = k0 + tx;
         float v = 0.f;
-        if (b < B && k < K) v = X[(long long)(perm ? perm[b] : b) * ldx + k];
+        if (b < B && k < K) v = val[q];
         else if (b < B && k == K) v = 1.f;                            // the ones row of the transposed image
         tile[r][tx] = v;
         if (b < Bp && k < Kp) xb[(long long)b * Kp + k] = to_bf16(k < K ? v : 0.f);
@@ -209,9 +292,9 @@ __global__ __launch_bounds__(256) void gather_images_kernel(const float* __restr
     }
 }
 void isk_launch_gather_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
-                              hipStream_t st) {
+                              float* loss_slot, const int* rank_err, hipStream_t st) {
     const dim3 grid((Bp + 31) / 32, (K + 1 + 31) / 32);              // covers k = K (the ones row)
-    hipLaunchKernelGGL(gather_images_kernel, grid, dim3(256), 0, st, X, ldx, perm, B, Bp, K, Kp, (u16*)xb, (u16*)xt, ldt);
+    hipLaunchKernelGGL(gather_images_kernel, grid, dim3(256), 0, st, X, ldx, perm, B, Bp, K, Kp, (u16*)xb, (u16*)xt, ldt, loss_slot, rank_err);
 }
 
 // Wt_l[n][k] = bf16(W_l[n][k] * scale[k]) for every layer in one launch (forward B operands), W in Flux layout mem [k][n];
@@ -228,10 +311,19 @@ __global__ __launch_bounds__(256) void wt_images_kernel(WtImagesArgs a) {
     const float* W = a.theta + a.off_W[l];
     const float* sc = (l == 0) ? a.scale0 : nullptr;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float wv[4], sv[4];
+    const int nc = (n0 + tx) < N ? (n0 + tx) : N - 1;
 #pragma unroll
-    for (int r = ty; r < 32; r += 8) {
+    for (int q = 0; q < 4; ++q) {                                     // unconditional, clamped: four loads in flight, not four round trips
+        const int kc = (k0 + ty + 8 * q) < K ? (k0 + ty + 8 * q) : K - 1;
+        wv[q] = W[(long long)kc * N + nc];
+        sv[q] = sc ? sc[kc] : 1.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = ty + 8 * q;
         const int k = k0 + r, n = n0 + tx;
-        tile[r][tx] = (k < K && n < N) ? W[(long long)k * N + n] * (sc ? sc[k] : 1.f) : 0.f;
+        tile[r][tx] = (k < K && n < N) ? wv[q] * sv[q] : 0.f;
     }
     __syncthreads();
     u16* out = (u16*)a.Wt[l];
@@ -256,11 +348,13 @@ __global__ __launch_bounds__(1024) void loss_delta16_kernel(const float* __restr
                                                             const int* __restrict__ rank_err) {
     __shared__ float red[16];
     float ls = 0.f;
-    const long long tot = (long long)Bp * ld16;
+    // rows n < Bp of the nout live columns only: the padding columns of d16 are never read (the dX product masks k >= nout), its
+    // rows >= B neither (operand rows are clamped); the columns [B, Bp) of dt16 ARE contraction padding of dW and must be zeros
+    const long long tot = (long long)Bp * nout;
     for (long long e = threadIdx.x; e < tot; e += 1024) {
-        const int n = (int)(e / ld16), o = (int)(e % ld16);
+        const int n = (int)(e / nout), o = (int)(e % nout);
         float d = 0.f;
-        if (n < B && o < nout) {
+        if (n < B) {
             const long long prow = perm ? perm[n] : n;
             const float zz = z[(long long)n * ld + o];
             const float w = lossw[o];
@@ -268,8 +362,8 @@ __global__ __launch_bounds__(1024) void loss_delta16_kernel(const float* __restr
             ls += r * r;
             d = 2.f * r * w * inv_div * g_dact(lastact, zz);
         }
-        d16[e] = to_bf16(d);
-        if (o < nout) dt16[(long long)o * ldt + n] = to_bf16(d);
+        d16[(long long)n * ld16 + o] = to_bf16(d);
+        dt16[(long long)o * ldt + n] = to_bf16(d);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o, 64);
@@ -287,4 +381,92 @@ void isk_launch_loss_delta16(const float* z, int ld, const float* target, const 
                              const int* rank_err, hipStream_t st) {
     hipLaunchKernelGGL(loss_delta16_kernel, dim3(1), dim3(1024), 0, st, z, ld, target, lossw, perm, B, Bp, nout, inv_div, lastact,
                        (u16*)d16, ld16, (u16*)dt16, ldt, loss_slot, rank_err);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the head of a network with few outputs (nout <= 16: every reference network) as ONE launch instead of four: the last layer's
+// forward z_L = a W_L' + b_L, the weighted loss and delta_L (as loss_delta16_kernel), and the back-propagation through that layer
+//   delta_{L-1}[b][k] = (sum_o delta_L[b][o] W_L[o][k]) * act'(z_{L-1}[b][k])
+// with its two bf16 images.  These are matrix-vector sized products (1000 x 512 x 1 for C5) that each cost a full dependent launch
+// as GEMMs.  Workgroup = 32 batch rows (four waves x 8 rows, a lane takes the hidden units lane, lane + 64, ...); the transposed
+// image goes through an LDS tile so that its stores are whole 64-byte segments.
+// ---------------------------------------------------------------------------------------------------------------------
+#define HEAD_MAXK 1024
+__global__ __launch_bounds__(256) void head16_kernel(Head16Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    u16* tile = (u16*)hsm;                                   // [32 rows][Kh + 2] bf16: delta_{L-1} of this workgroup's rows
+    __shared__ float wloss[4];
+    ISK_LATENCY_CHAIN_PRIO();
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Kh = a.Kh, nout = a.nout, ldt_tile = Kh + 2;
+    const int b0 = blockIdx.x * 32;
+    constexpr int NE = HEAD_MAXK / 64;                       // hidden units per lane (<= 16)
+    const int ne = (Kh + 63) / 64;
+    // the layer's weights of this lane's hidden units, for every output: W_L (out, in) column-major == [k][o]
+    float ls = 0.f;
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = wave * 8 + rr, b = b0 + r;
+        const bool live = b < a.B;
+        const int bc = live ? b : a.B - 1;
+        float av[NE], zp[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int k = lane + 64 * u;
+            const int kc = k < Kh ? k : Kh - 1;
+            const u16 h = ((const u16*)a.a16)[(long long)bc * a.lda + kc];
+            av[u] = (u < ne && k < Kh) ? __builtin_bit_cast(float, (unsigned)h << 16) : 0.f;
+            zp[u] = a.zprev[(long long)bc * a.ldzp + kc];
+        }
+        const long long prow = a.perm ? a.perm[bc] : bc;
+        float back[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) back[u] = 0.f;
+        for (int o = 0; o < nout; ++o) {
+            float s = 0.f;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int k = lane + 64 * u;
+                if (u < ne && k < Kh) s = fmaf(av[u], a.W[(long long)k * nout + o], s);
+            }
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_xor(s, sft, 64);
+            const float zz = s + a.bias[o];
+            const float w = a.lossw[o];
+            const float rsd = (g_act(a.lastact, zz) - a.target[prow * nout + o]) * w;
+            float d = 2.f * rsd * w * a.inv_div * g_dact(a.lastact, zz);
+            if (!live) d = 0.f;
+            if (live && lane == 0) { ls += rsd * rsd; if (a.z) a.z[(long long)b * a.ldz + o] = zz; }
+            if (lane == 0 && b < a.Bp) ((u16*)a.dt16_last)[(long long)o * a.ldt + b] = to_bf16(d);      // delta_L' (zeros for b in [B, Bp))
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int k = lane + 64 * u;
+                if (u < ne && k < Kh) back[u] = fmaf(d, a.W[(long long)k * nout + o], back[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int k = lane + 64 * u;
+            if (u < ne && k < Kh) {
+                const float dv = live ? back[u] * g_dact(a.act, zp[u]) : 0.f;
+                const u16 hb = to_bf16(dv);
+                tile[r * ldt_tile + k] = hb;
+                if (b < a.Bp) ((u16*)a.d16)[(long long)b * a.ld16 + k] = hb;
+            }
+        }
+    }
+    if (lane == 0) wloss[wave] = ls;
+    __syncthreads();
+    if (tid == 0) atomicAdd(a.loss_slot, (wloss[0] + wloss[1]) + (wloss[2] + wloss[3]));
+    // transposed image dt16[k][b0 .. b0 + 31]: 32 consecutive threads write one hidden unit's 32 rows (64 B)
+    for (int e = tid; e < 32 * Kh; e += 256) {
+        const int k = e >> 5, r = e & 31;
+        if (b0 + r < a.Bp) ((u16*)a.dt16)[(long long)k * a.ldt + b0 + r] = tile[r * ldt_tile + k];
+    }
+}
+int isk_launch_head16(const Head16Args& a, hipStream_t st) {
+    if (a.Kh < 1 || a.Kh > HEAD_MAXK || a.nout < 1 || a.nout > 16) return ISK_EUNSUPPORTED;
+    const size_t lds = (size_t)32 * (a.Kh + 2) * sizeof(u16);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)head16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(head16_kernel, dim3((a.Bp + 31) / 32), dim3(256), lds, st, a);
+    return 0;
 }
