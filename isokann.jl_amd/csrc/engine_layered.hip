@@ -259,13 +259,10 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
     const long long ldB = b.rows;                    // row length of the transposed images
     hipStream_t st = e->stream;
     const bool ln = e->cfg.layernorm != 0;
-    // head fusion: last layer forward + loss + the deltas of the last TWO layers in one launch (nout <= 16)
-    const bool head = L >= 2 && e->nout <= 16 && e->cfg.widths[L - 1] <= 1024;
-    isk_launch_gather_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, head ? e->d_grad + e->nparams : nullptr,
-                             e->d_rank_err, st);
+    isk_launch_gather_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, st);
     bf16_weight_images_ensure(e);
     bool ok = true;
-    for (int l = 0; l < (head ? L - 1 : L) && ok; ++l) {
+    for (int l = 0; l < L && ok; ++l) {
         const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];
         Gemm16Args g = {};
         g.A = l == 0 ? b.xb : b.a16[l - 1]; g.lda = l == 0 ? e->Fp : isk_pad32(K); g.a_f32 = 0;
@@ -279,26 +276,10 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
         ok = isk_launch_gemm16(g, st) == 0;
     }
     if (!ok) return false;
-    if (head) {
-        Head16Args h = {};
-        const int Kh = e->cfg.widths[L - 1];
-        h.a16 = b.a16[L - 2]; h.lda = isk_pad32(Kh);
-        h.zprev = e->d_lz[L - 2]; h.ldzp = isk_pad16(Kh);
-        h.W = e->d_theta + e->off_W[L - 1]; h.bias = e->d_theta + e->off_b[L - 1];
-        h.target = e->d_target; h.lossw = e->d_lossw; h.perm = d_idx;
-        h.B = B; h.Bp = Bp; h.Kh = Kh; h.nout = e->nout; h.act = act_of_layer(e, L - 2); h.lastact = e->cfg.lastactivation;
-        h.inv_div = inv_div;
-        h.z = e->d_lz[L - 1]; h.ldz = isk_pad16(e->nout);
-        h.dt16_last = b.dt16[L - 1]; h.ldt = ldB;
-        h.d16 = b.d16[L - 2]; h.ld16 = isk_pad32(Kh); h.dt16 = b.dt16[L - 2];
-        h.loss_slot = e->d_grad + e->nparams;
-        if (isk_launch_head16(h, st) != 0) return false;
-    } else {
-        isk_launch_loss_delta16(e->d_lz[L - 1], isk_pad16(e->nout), e->d_target, e->d_lossw, d_idx, B, Bp, e->nout, inv_div, e->cfg.lastactivation,
-                                b.d16[L - 1], isk_pad32(e->nout), b.dt16[L - 1], ldB, e->d_grad + e->nparams, e->d_rank_err, st);
-    }
-    Gemm16Args carry = {};                           // head: dW of the last layer rides in the next group
-    bool have_carry = false;
+    // (the last layer + loss + both deltas as ONE "head" kernel was built and measured: 59 us against the 45 us of the four launches
+    // it replaced -- eight rows per wave are eight dependent round trips; not kept)
+    isk_launch_loss_delta16(e->d_lz[L - 1], isk_pad16(e->nout), e->d_target, e->d_lossw, d_idx, B, Bp, e->nout, inv_div, e->cfg.lastactivation,
+                            b.d16[L - 1], isk_pad32(e->nout), b.dt16[L - 1], ldB, e->d_grad + e->nparams, e->d_rank_err, st);
     for (int l = L - 1; l >= 0 && ok; --l) {
         const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];
         const bool ln0 = l == 0 && ln;
@@ -309,7 +290,6 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
         g.M = K + 1; g.Nn = N; g.Kc = Bp; g.kvalid = Bp;
         g.epi = ISK_G16_DW;
         g.gout = ln0 ? b.G0 : e->d_grad + e->off_W[l]; g.gld = N;           // row K lands on b_l: Flux keeps it right behind W_l
-        if (head && l == L - 1) { carry = g; have_carry = true; continue; }       // its delta_{L-1} came out of the head kernel
         int np = 1;
         if (l > 0) {
             np = 2;
@@ -321,7 +301,6 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
             x.zprev = e->d_lz[l - 1]; x.ldzp = isk_pad16(K); x.act = act_of_layer(e, l - 1);
             x.o16 = b.d16[l - 1]; x.ld16 = isk_pad32(K); x.M16 = Bp; x.ot16 = b.dt16[l - 1]; x.ldt = (int)ldB;
         }
-        if (have_carry) { pair[np++] = carry; have_carry = false; }
         // dW_l + db_l and delta_{l-1} both need only delta_l: one launch
         ok = isk_launch_gemm16_group(pair, np, st) == 0;
         if (ln0) {

@@ -208,21 +208,7 @@ struct Gemm16Group {                             // several independent products
 int  isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st);
 // gathered batch rows -> xb [Bp][Kp] bf16 and xt [K + 1][ldt] bf16 (row K = ones; columns [B, Bp) zeros)
 void isk_launch_gather_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
-                              float* loss_slot /* optional: zeroed, [1] <- *rank_err */, const int* rank_err, hipStream_t st);
-// last layer forward + loss + delta_L + delta_{L-1} (with its two bf16 images) in one launch, nout <= 16 (kernels_gemm16.hip)
-struct Head16Args {
-    const void* a16; long long lda;              // activations of the last hidden layer, bf16 [Bp][lda]
-    const float* zprev; int ldzp;                // its pre-activations (f32)
-    const float* W; const float* bias;           // last layer: W (out, in) column-major == [k][o], bias [nout]
-    const float* target; const float* lossw; const int* perm;
-    int B, Bp, Kh, nout, act, lastact;
-    float inv_div;
-    float* z; int ldz;                           // optional: z_L
-    void* dt16_last; long long ldt;              // delta_L' [nout][ldt]
-    void* d16; int ld16; void* dt16;             // delta_{L-1} [Bp][ld16] and its transpose [Kh][ldt]
-    float* loss_slot;                            // += batch loss (atomic; zeroed by the step's gather kernel)
-};
-int  isk_launch_head16(const Head16Args& a, hipStream_t st);
+                              hipStream_t st);
 struct WtImagesArgs {
     const float* theta; const float* scale0;     // scale0: LayerNorm scale folded into layer 0's image (or nullptr)
     int nlayers;

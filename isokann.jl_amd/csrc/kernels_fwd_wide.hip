@@ -69,6 +69,11 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* dst) {
 }
 
 #define WF_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+// diagnostic builds only (timing valid, results not): -DWF_ABLATE=bits -- 1: the A-tile loads of layer 1 re-read ONE tile (cache
+// resident: no HBM stream), 2: likewise the layer-1 W-tile loads, 4: no MFMAs (the fragment reads stay), 8: no LDS-DMA at all
+#ifndef WF_ABLATE
+#define WF_ABLATE 0
+#endif
 
 template <int ACT>
 __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
@@ -80,7 +85,12 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
     const long long nblk = (a.S + WF_BM - 1) / WF_BM;
     // Register budget (two waves per SIMD: 256): uniform 64-bit bases + 32-bit lane offsets, LDS offsets as instruction immediates
     // on top of one base per stream -- per-tile address registers next to the accumulators made hipcc spill into the K-loops.
-    const unsigned w_ld_off = (unsigned)((64 * cg + li) * 64 + lq * 16);                 // B fragment of column tile (h = 0, c = 0) inside a W slot
+    // W tiles are [column][4 x 16 B]; the 16-byte part index is XORed with f((column >> 2) & 3), f = {0, 2, 3, 1}, through the DMA's
+    // SOURCE addresses: with that f the sixteen lanes the LDS serves together for a ds_read_b128 ({lq0: li 0-3, 12-15; lq1: li 4-11}
+    // and its mirror images) fall on sixteen different 4-bank groups -- unswizzled, the B-fragment reads were 2-way conflicts
+    auto wswz = [](unsigned x) { return ((x << 1) ^ ((x >> 1) * 3u)) & 3u; };
+    const unsigned w_ld_off = (unsigned)((64 * cg + li) * 64) + (((unsigned)lq ^ wswz((unsigned)(li >> 2) & 3u)) << 4);   // B fragment of column tile (h = 0, c = 0)
+    const unsigned w_src_part = ((unsigned)(lane & 3) ^ wswz((unsigned)(lane >> 4) & 3u)) * 8u;     // features this lane's 16 B hold (column 16 g + lane / 4)
     const unsigned a_swz = (unsigned)(li >> 1);                                          // ((row >> 1) & 7) of every row this lane reads: rows 48 rg + 16 rt + li
     const unsigned a_ld_lo = (unsigned)((48 * rg + li) * 128) + (((2u * lq) ^ a_swz) << 4);       // features 8 lq .. 8 lq + 3 of row tile 0
     const unsigned a_ld_hi = (unsigned)((48 * rg + li) * 128) + (((2u * lq + 1u) ^ a_swz) << 4);  // features 8 lq + 4 .. + 7
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
             const int Kp = a.Kp[0];
             // W: 16 columns x 64 B per wave-instruction (lane L -> column 16 g + L / 4, features 8 (L % 4) ..), groups g = 4 wave + i.
             const unsigned char* wb = (const unsigned char*)a.Wt[0] + (size_t)(64 * wave) * Kp * 2;     // uniform
-            const unsigned w_g_off = (unsigned)(((lane >> 2) * Kp + (lane & 3) * 8) * 2);
+            const unsigned w_g_off = (unsigned)(((lane >> 2) * Kp + w_src_part) * 2);
             const unsigned wstep = (unsigned)(16 * Kp * 2);
             // A: 8 rows x 128 B per wave-instruction (lane L -> row L / 8, PHYSICAL chunk L % 8 holding logical chunk
             // (L % 8) ^ ((row >> 1) & 7)); wave w stages rows 12 w .. 12 w + 11: one full instruction and one of 32 lanes
@@ -113,11 +123,12 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
                 a_g_off[j] = (unsigned)(((xr - row0) * a.Fp + 4 * ((lane & 7) ^ ((row >> 1) & 7))) * 4);
             }
             auto issue = [&](int ks, int slot) {
+                if (WF_ABLATE & 8) return;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    glds16(wb + (size_t)i * wstep + (size_t)ks * 64 + w_g_off, Wr + slot * WF_W1_SLOT + (4 * wave + i) * 1024);
-                glds16(xb + (size_t)ks * 128 + a_g_off[0], Ar + slot * WF_A1_SLOT + (12 * wave) * 128);
-                if (lane < 32) glds16(xb + (size_t)ks * 128 + a_g_off[1], Ar + slot * WF_A1_SLOT + (12 * wave + 8) * 128);
+                    glds16((WF_ABLATE & 2) ? wb + w_g_off : wb + (size_t)i * wstep + (size_t)ks * 64 + w_g_off, Wr + slot * WF_W1_SLOT + (4 * wave + i) * 1024);
+                glds16((WF_ABLATE & 1) ? xb + a_g_off[0] : xb + (size_t)ks * 128 + a_g_off[0], Ar + slot * WF_A1_SLOT + (12 * wave) * 128);
+                if (lane < 32) glds16((WF_ABLATE & 1) ? xb + a_g_off[1] : xb + (size_t)ks * 128 + a_g_off[1], Ar + slot * WF_A1_SLOT + (12 * wave + 8) * 128);
             };
             issue(0, 0);
             if (nk > 1) issue(1, 1);
@@ -141,7 +152,10 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
                 for (int ct = 0; ct < 8; ++ct) {
                     const bf16x8 fb = *(const bf16x8*)(Ws + (ct >> 2) * 16384 + (ct & 3) * 1024);
 #pragma unroll
-                    for (int rt = 0; rt < 3; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[rt], fb, acc[rt][ct], 0, 0, 0);
+                    for (int rt = 0; rt < 3; ++rt) {
+                        if (WF_ABLATE & 4) asm volatile("" :: "v"(fa[rt]), "v"(fb));
+                        else acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[rt], fb, acc[rt][ct], 0, 0, 0);
+                    }
                 }
                 slot = slot == 2 ? 0 : slot + 1;
             }
@@ -189,9 +203,10 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
             const int nsteps = 2 * nk;
             // W: two column groups of 16 per wave and step (g = 2 wave + i)
             const unsigned char* wb = (const unsigned char*)a.Wt[l] + (size_t)(32 * wave) * Kp * 2;        // uniform
-            const unsigned w_g_off = (unsigned)(((lane >> 2) * Kp + (lane & 3) * 8) * 2);
+            const unsigned w_g_off = (unsigned)(((lane >> 2) * Kp + w_src_part) * 2);
             const unsigned a_row_off = (unsigned)((48 * rg + li) * (WF_NP * 2));
             auto issue = [&](int s2, int slot) {
+                if (WF_ABLATE & 8) return;
                 const int h = s2 >= nk ? 1 : 0, ks = s2 - h * nk;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -215,8 +230,10 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
                     for (int c = 0; c < 4; ++c) {
                         const bf16x8 fb = *(const bf16x8*)(Ws + c * 1024);
 #pragma unroll
-                        for (int rt = 0; rt < 3; ++rt)
-                            acc[rt][4 * h + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[rt], fb, acc[rt][4 * h + c], 0, 0, 0);
+                        for (int rt = 0; rt < 3; ++rt) {
+                            if (WF_ABLATE & 4) asm volatile("" :: "v"(fa[rt]), "v"(fb));
+                            else acc[rt][4 * h + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[rt], fb, acc[rt][4 * h + c], 0, 0, 0);
+                        }
                     }
                     slot = slot == 2 ? 0 : slot + 1;
                 }

@@ -253,12 +253,9 @@ int isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st) {
 // transposed image with the row of ones behind the K features: the first layer's dW + db operand).  One 32 x 32 tile per
 // workgroup through LDS; rows >= B and columns >= K are written as zeros (they are contraction padding).
 __global__ __launch_bounds__(256) void gather_images_kernel(const float* __restrict__ X, int ldx, const int* __restrict__ perm, int B, int Bp,
-                                                            int K, int Kp, u16* __restrict__ xb, u16* __restrict__ xt, long long ldt,
-                                                            float* __restrict__ loss_slot, const int* __restrict__ rank_err) {
+                                                            int K, int Kp, u16* __restrict__ xb, u16* __restrict__ xt, long long ldt) {
     __shared__ float tile[32][33];
     ISK_LATENCY_CHAIN_PRIO();
-    // the step's first kernel: the batch loss is accumulated with atomics by the head kernel, the flag slot behind it is set here
-    if (loss_slot && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { loss_slot[0] = 0.f; loss_slot[1] = rank_err ? (float)*rank_err : 0.f; }
     const int b0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 8 row groups
     // the four rows of a thread: indices, then values, requested together from clamped addresses (no load behind a branch: each
@@ -292,9 +289,9 @@ __global__ __launch_bounds__(256) void gather_images_kernel(const float* __restr
     }
 }
 void isk_launch_gather_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
-                              float* loss_slot, const int* rank_err, hipStream_t st) {
+                              hipStream_t st) {
     const dim3 grid((Bp + 31) / 32, (K + 1 + 31) / 32);              // covers k = K (the ones row)
-    hipLaunchKernelGGL(gather_images_kernel, grid, dim3(256), 0, st, X, ldx, perm, B, Bp, K, Kp, (u16*)xb, (u16*)xt, ldt, loss_slot, rank_err);
+    hipLaunchKernelGGL(gather_images_kernel, grid, dim3(256), 0, st, X, ldx, perm, B, Bp, K, Kp, (u16*)xb, (u16*)xt, ldt);
 }
 
 // Wt_l[n][k] = bf16(W_l[n][k] * scale[k]) for every layer in one launch (forward B operands), W in Flux layout mem [k][n];
@@ -383,90 +380,3 @@ void isk_launch_loss_delta16(const float* z, int ld, const float* target, const 
                        (u16*)d16, ld16, (u16*)dt16, ldt, loss_slot, rank_err);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// the head of a network with few outputs (nout <= 16: every reference network) as ONE launch instead of four: the last layer's
-// forward z_L = a W_L' + b_L, the weighted loss and delta_L (as loss_delta16_kernel), and the back-propagation through that layer
-//   delta_{L-1}[b][k] = (sum_o delta_L[b][o] W_L[o][k]) * act'(z_{L-1}[b][k])
-// with its two bf16 images.  These are matrix-vector sized products (1000 x 512 x 1 for C5) that each cost a full dependent launch
-// as GEMMs.  Workgroup = 32 batch rows (four waves x 8 rows, a lane takes the hidden units lane, lane + 64, ...); the transposed
-// image goes through an LDS tile so that its stores are whole 64-byte segments.
-// ---------------------------------------------------------------------------------------------------------------------
-#define HEAD_MAXK 1024
-__global__ __launch_bounds__(256) void head16_kernel(Head16Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
-    u16* tile = (u16*)hsm;                                   // [32 rows][Kh + 2] bf16: delta_{L-1} of this workgroup's rows
-    __shared__ float wloss[4];
-    ISK_LATENCY_CHAIN_PRIO();
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int Kh = a.Kh, nout = a.nout, ldt_tile = Kh + 2;
-    const int b0 = blockIdx.x * 32;
-    constexpr int NE = HEAD_MAXK / 64;                       // hidden units per lane (<= 16)
-    const int ne = (Kh + 63) / 64;
-    // the layer's weights of this lane's hidden units, for every output: W_L (out, in) column-major == [k][o]
-    float ls = 0.f;
-    for (int rr = 0; rr < 8; ++rr) {
-        const int r = wave * 8 + rr, b = b0 + r;
-        const bool live = b < a.B;
-        const int bc = live ? b : a.B - 1;
-        float av[NE], zp[NE];
-#pragma unroll
-        for (int u = 0; u < NE; ++u) {
-            const int k = lane + 64 * u;
-            const int kc = k < Kh ? k : Kh - 1;
-            const u16 h = ((const u16*)a.a16)[(long long)bc * a.lda + kc];
-            av[u] = (u < ne && k < Kh) ? __builtin_bit_cast(float, (unsigned)h << 16) : 0.f;
-            zp[u] = a.zprev[(long long)bc * a.ldzp + kc];
-        }
-        const long long prow = a.perm ? a.perm[bc] : bc;
-        float back[NE];
-#pragma unroll
-        for (int u = 0; u < NE; ++u) back[u] = 0.f;
-        for (int o = 0; o < nout; ++o) {
-            float s = 0.f;
-#pragma unroll
-            for (int u = 0; u < NE; ++u) {
-                const int k = lane + 64 * u;
-                if (u < ne && k < Kh) s = fmaf(av[u], a.W[(long long)k * nout + o], s);
-            }
-#pragma unroll
-            for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_xor(s, sft, 64);
-            const float zz = s + a.bias[o];
-            const float w = a.lossw[o];
-            const float rsd = (g_act(a.lastact, zz) - a.target[prow * nout + o]) * w;
-            float d = 2.f * rsd * w * a.inv_div * g_dact(a.lastact, zz);
-            if (!live) d = 0.f;
-            if (live && lane == 0) { ls += rsd * rsd; if (a.z) a.z[(long long)b * a.ldz + o] = zz; }
-            if (lane == 0 && b < a.Bp) ((u16*)a.dt16_last)[(long long)o * a.ldt + b] = to_bf16(d);      // delta_L' (zeros for b in [B, Bp))
-#pragma unroll
-            for (int u = 0; u < NE; ++u) {
-                const int k = lane + 64 * u;
-                if (u < ne && k < Kh) back[u] = fmaf(d, a.W[(long long)k * nout + o], back[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NE; ++u) {
-            const int k = lane + 64 * u;
-            if (u < ne && k < Kh) {
-                const float dv = live ? back[u] * g_dact(a.act, zp[u]) : 0.f;
-                const u16 hb = to_bf16(dv);
-                tile[r * ldt_tile + k] = hb;
-                if (b < a.Bp) ((u16*)a.d16)[(long long)b * a.ld16 + k] = hb;
-            }
-        }
-    }
-    if (lane == 0) wloss[wave] = ls;
-    __syncthreads();
-    if (tid == 0) atomicAdd(a.loss_slot, (wloss[0] + wloss[1]) + (wloss[2] + wloss[3]));
-    // transposed image dt16[k][b0 .. b0 + 31]: 32 consecutive threads write one hidden unit's 32 rows (64 B)
-    for (int e = tid; e < 32 * Kh; e += 256) {
-        const int k = e >> 5, r = e & 31;
-        if (b0 + r < a.Bp) ((u16*)a.dt16)[(long long)k * a.ldt + b0 + r] = tile[r * ldt_tile + k];
-    }
-}
-int isk_launch_head16(const Head16Args& a, hipStream_t st) {
-    if (a.Kh < 1 || a.Kh > HEAD_MAXK || a.nout < 1 || a.nout > 16) return ISK_EUNSUPPORTED;
-    const size_t lds = (size_t)32 * (a.Kh + 2) * sizeof(u16);
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)head16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(head16_kernel, dim3((a.Bp + 31) / 32), dim3(256), lds, st, a);
-    return 0;
-}

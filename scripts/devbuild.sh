@@ -19,6 +19,7 @@ for s in $(cd $ROOT/isokann.jl_amd/csrc && ls *.hip | sed 's/\.hip$//'); do
   OBJS="$OBJS $o"
 done
 for p in $pids; do wait $p; done
+echo $OBJS > /tmp/obj/last_objs.txt          # (ablation builds relink this list with one object replaced)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared $OBJS -o $OUT
 if [ "$OUT" = "$ROOT/isokann.jl_amd/lib/libisokann_hip.so" ]; then
   python - <<PY

@@ -1,7 +1,7 @@
 #!/bin/bash
 # regenerate the committed evidence under profiles/ (run on the GPU box): scripts/refresh_profiles.sh r01
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 mkdir -p gpurun_out/ref
 b() { name=$1; shift; python3 bench.py "$@" 2> gpurun_out/ref/$name.err | tail -1 > gpurun_out/ref/${tag}_bench_$name.json; python3 -c "
 import json,sys; d=json.load(open('gpurun_out/ref/${tag}_bench_$name.json')); print('$name', round(d['ms_per_step'],3), 'ms', round(d['value']/1e6,1), 'M/s frac', round(d['roofline']['frac'],3))"; }
@@ -15,9 +15,18 @@ b c2 --workload c2
 b c5shard --workload c5shard --no-cpu-baseline
 b c5shard_f32fwd --workload c5shard --forward-mode 0 --no-cpu-baseline
 b c5shard_bf16fwd --workload c5shard --forward-mode 2 --no-cpu-baseline
+b c5shard_bf16 --workload c5shard --forward-mode 2 --train-bf16 --no-cpu-baseline          # the arithmetic BASELINE names for C5: forward AND training GEMMs on bf16
 b c3_bf16fwd --forward-mode 2 --no-cpu-baseline
+# one rank's share of the 8-way strong-scaled runs (C4: N = 1250, local batch 125; collectives on a one-rank communicator)
+b c4_shard_of_8 --shard-of 8 --no-cpu-baseline
+b c4_shard_of_4 --shard-of 4 --no-cpu-baseline
+b c4_shard_of_2 --shard-of 2 --no-cpu-baseline
 bash scripts/prof_bench.sh c3stats > gpurun_out/ref/prof.txt 2>&1 || true
 cp gpurun_out/prof_c3stats/c3stats_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c3.csv
+bash scripts/prof_bench.sh c3mb100 --minibatch 100 --opt nesterov >> gpurun_out/ref/prof.txt 2>&1 || true
+cp gpurun_out/prof_c3mb100/c3mb100_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c3_mb100_nesterov.csv
+bash scripts/prof_bench.sh c5stats --workload c5shard --forward-mode 2 --train-bf16 >> gpurun_out/ref/prof.txt 2>&1 || true
+cp gpurun_out/prof_c5stats/c5stats_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c5shard.csv
 bash scripts/pmc.sh > gpurun_out/ref/pmc.txt 2>&1 || true
 python3 - <<PY
 import json

@@ -104,3 +104,44 @@ def test_data_from_trajectory_matches_reference_slicing(pkg):
     assert xx.shape == (2, 7 + 3) and yy.shape == (2, 2, 10)
     d = pkg.SimulationData(*pkg.data_from_trajectory(np.random.default_rng(0).normal(size=(6, 20))), pkg.FeaturesAll())
     assert len(d) == 18 and d.nk == 2
+
+
+def test_config_struct_agrees_between_header_ctypes_and_julia_shim(pkg):
+    """isk_config is mirrored by hand in two places -- capi.Config (ctypes) and `struct IskConfig` of julia/IsokannHIP.jl (which
+    cannot be executed here: no Julia toolchain): the field NAMES and their ORDER must be the header's"""
+    hdr = open(os.path.join(ROOT, "include", "isokann_hip.h")).read()
+    start = hdr.index("typedef struct isk_config {") + len("typedef struct isk_config {")
+    body = re.sub(r"/\*.*?\*/", "", hdr[start:hdr.index("} isk_config;")], flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl or decl.startswith("typedef"):
+            continue
+        for part in decl.split(","):
+            m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(\[[^\]]*\])?\s*$", part.strip())
+            names.append(m.group(1))
+    assert names[0] == "abi_version" and names[-1] == "force_layered" and len(names) == len(pkg.capi.Config._fields_)
+    assert [f[0] for f in pkg.capi.Config._fields_] == names
+    jl = open(os.path.join(ROOT, "julia", "IsokannHIP.jl")).read()
+    sbody = jl[jl.index("struct IskConfig"):]
+    sbody = re.sub(r"#.*", "", sbody[:sbody.index("\nend")])
+    jl_names = re.findall(r"([A-Za-z_][A-Za-z0-9_]*)::", sbody)
+    assert jl_names == names
+    assert f"const ABI_VERSION = Int32({pkg.capi.ISK_ABI_VERSION})" in jl
+    # every entry point the shim calls is declared in the header
+    called = set(re.findall(r"\(:(isk_[a-z0-9_]+), LIB\[\]\)", jl)) | set(re.findall(r"fetch\(:(isk_[a-z0-9_]+)", jl))
+    assert called and called <= set(pkg.capi.PROTOTYPES), called - set(pkg.capi.PROTOTYPES)
+
+
+def test_options_are_per_engine_and_validated(pkg):
+    lib = pkg.capi.load()
+    assert lib.isk_set_option(None, b"train_graph", 0) == pkg.capi.EINVAL
+    v = C.c_int64(0)
+    assert lib.isk_get_option(None, b"train_graph", C.byref(v)) == pkg.capi.EINVAL
+    # the documented keys of the header are the keys of the option table (isk_get_option on a live engine is a GPU test)
+    hdr = open(os.path.join(ROOT, "include", "isokann_hip.h")).read()
+    doc = hdr[hdr.index("/* ---- options"):hdr.index("int  isk_set_option")]
+    keys = set(re.findall(r"^ \*   ([a-z0-9_]+) ", doc, flags=re.M)) | {"feat_bg_wgs", "feat_early_wgs", "debug_stamps", "debug_rowmod", "debug_feat_copy"}
+    src = open(os.path.join(ROOT, "isokann.jl_amd", "csrc", "engine_options.hip")).read()
+    table = set(re.findall(r'\{"([a-z0-9_]+)", &IskOptions::', src))
+    assert table - {"debug_inject_rank_error"} == keys - {"key"}, (table ^ keys)
