@@ -539,6 +539,7 @@ FeatArgs feat_args(const isk_engine* e) {
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
     a.bg_wg_per_cu = e->opt.feat_wg_per_cu; a.bg_wgs_total = e->opt.feat_bg_wgs; a.bg_pf = e->opt.feat_pf;
     a.dbg_copy = e->opt.debug_feat_copy;
+    a.out_bf16 = e->xh16;
     return a;
 }
 
@@ -552,6 +553,7 @@ static void featurize_rows(isk_engine* e, const float* in, long long S, float* x
     a.background = (st != nullptr) ? bg_wgs : 0;       // 1: the default throttle; > 1: that many workgroups in total
     a.planes = xscale != nullptr;
     if (a.planes) { a.xhat = xhat; a.row0 = row0; a.xscale = xscale + row0; }
+    else if (e->xh16) a.xhat = (float*)((unsigned short*)xhat + row0 * e->Fp);      // bf16 rows
     else a.xhat = xhat + row0 * e->Fp;
     a.xhat32 = xs32; a.x32_first = x32_first;
     isk_launch_featurize(a, st ? st : e->stream);
@@ -669,6 +671,13 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
     HIPCHK(hipStreamSynchronize(e->stream));
     free_data(e);
     e->N = N; e->K = K; e->D = D;
+    {
+        // wide networks, plain-bf16 forward: the featurizer writes the Koopman rows as bf16, exactly the A operand of the fused
+        // forward (half the feature bytes written and read); decided here, with the buffers (option wide_fused: next set_data)
+        FeatArgs fa = {};
+        fa.pairs = e->d_pairs; fa.packed_pairs = e->d_packed; fa.D = e->Din; fa.F = e->F; fa.Fp = e->Fp;
+        e->xh16 = e->layered && bf16_planes(e) == 1 && e->opt.wide_fused && wide_forward_shape_ok(e) && isk_featurize_reg_ok(fa);
+    }
     const long long S = N * K + N;
     const long long Bpad = ((N + 15) / 16) * 16;
     const int H1p = isk_pad16(e->cfg.widths[1]);
@@ -705,10 +714,12 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
     if (e->layered) {
         int mh = 32;
         for (int l = 1; l < e->L; ++l) mh = std::max(mh, isk_pad32(e->cfg.widths[l]));
-        HIPCHK(hipMalloc((void**)&e->d_actA, (size_t)S * mh * sizeof(float)));
-        HIPCHK(hipMalloc((void**)&e->d_actB, (size_t)S * mh * sizeof(float)));
-        HIPCHK(hipMemsetAsync(e->d_actA, 0, (size_t)S * mh * sizeof(float), e->stream));
-        HIPCHK(hipMemsetAsync(e->d_actB, 0, (size_t)S * mh * sizeof(float), e->stream));
+        if (!e->xh16) {                  // (the fused wide forward keeps the activations in LDS)
+            HIPCHK(hipMalloc((void**)&e->d_actA, (size_t)S * mh * sizeof(float)));
+            HIPCHK(hipMalloc((void**)&e->d_actB, (size_t)S * mh * sizeof(float)));
+            HIPCHK(hipMemsetAsync(e->d_actA, 0, (size_t)S * mh * sizeof(float), e->stream));
+            HIPCHK(hipMemsetAsync(e->d_actB, 0, (size_t)S * mh * sizeof(float), e->stream));
+        }
         for (int l = 0; l < e->L; ++l) {
             const size_t nb = (size_t)Bpad * isk_pad16(e->cfg.widths[l + 1]) * sizeof(float);
             HIPCHK(hipMalloc((void**)&e->d_lz[l], nb));
@@ -769,6 +780,7 @@ void fold_ahead(isk_engine* e) {
 // the forward over feature rows: f32 MFMA or split-bf16 (cfg.forward_mode)
 int launch_forward(isk_engine* e, const MlpFwdArgs& f) {
     ensure_folded(e);
+    if (e->layered && e->xh16) return forward_layered(e, f.X, f.S, f.out, nullptr, nullptr);     // fused wide kernel: no activation buffers
     if (e->layered) {
         float *a = e->d_actA, *b = e->d_actB;
         TmpBuf ta, tb;
@@ -820,7 +832,11 @@ int forward_resident(isk_engine* e, int which, bool ahead) {
     long long S = nys + e->N;
     int tid = ISK_T_FWD_YS;
     if (which == 1) S = nys;
-    if (which == 2) { if (!e->planes) X += nys * e->Fp; out += nys * e->nout; S = e->N; tid = ISK_T_FWD_XS; }
+    if (which == 2) {
+        if (e->xh16) X = (const float*)((const unsigned short*)X + nys * e->Fp);      // bf16 rows
+        else if (!e->planes) X += nys * e->Fp;
+        out += nys * e->nout; S = e->N; tid = ISK_T_FWD_XS;
+    }
     if (ahead) (void)hipEventRecord(e->ev_fwd_done, e->stream);
     {
         ScopedTimer t(e, tid);

@@ -81,6 +81,7 @@ struct isk_engine {
     float* d_xs32_alt = nullptr;     //         the copy the side-stream featurizer writes for the next iteration
     // layered path (networks too wide for the fused kernels): per-layer images and HBM activations
     bool layered = false;
+    bool xh16 = false;               // layered + plain-bf16 forward + fused wide kernel: d_xhat holds bf16 rows (decided at isk_set_data)
     void* d_W16L[ISK_MAX_LAYERS] = {nullptr};     // bf16 planes per layer (forward_mode 1)
     float* d_WtT[ISK_MAX_LAYERS] = {nullptr};     // fragment-linear W' per layer l >= 1 (delta back-propagation)
     float *d_actA = nullptr, *d_actB = nullptr;   // resident forward ping-pong [(N*K+N)][max pad32(H)]
@@ -242,6 +243,7 @@ void bf16_weight_images_ensure(isk_engine* e);           // refresh them if thet
 bool blas_ready(isk_engine* e);
 void blas_release(isk_engine* e);
 int bf16_planes(const isk_engine* e);
+bool wide_forward_shape_ok(const isk_engine* e);         // the fused wide forward covers this network (hidden widths <= 512, nout <= 16)
 // ---- engine_isa_host.hip ---------------------------------------------------------------
 int isa_solve_host(const isk_engine* e, const std::vector<float>& ks, const std::vector<float>& chi, long long N, int d,
                    std::vector<double>& At, std::vector<int>& rowperm, std::vector<double>* target_out);

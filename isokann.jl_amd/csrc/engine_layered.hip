@@ -8,10 +8,21 @@ int bf16_planes(const isk_engine* e) { return e->cfg.forward_mode == 1 ? 3 : (e-
 
 // layer-by-layer forward: every layer is a sequence of dense-block launches of the same GEMM kernels; hidden
 // activations [S][pad32(H)] ping-pong between actA / actB (zero-initialised: the padding columns stay 0)
+static void wide_args_shape(const isk_engine* e, WideFwdArgs& a) {
+    a.Fp = e->Fp; a.nhidden = e->L - 1;
+    for (int l = 0; l + 1 < e->L; ++l) { a.N[l] = e->cfg.widths[l + 1]; a.Kp[l] = isk_pad32(e->cfg.widths[l]); }
+    a.Klast = e->cfg.widths[e->L - 1]; a.nout = e->nout;
+}
+bool wide_forward_shape_ok(const isk_engine* e) {
+    WideFwdArgs a = {};
+    wide_args_shape(e, a);
+    return e->L >= 2 && e->b16.Wt[0] && isk_wide_fwd_ok(a);
+}
+
 // plain-bf16 forward (forward_mode 2) of a network whose hidden layers are <= 512 wide: ONE fused kernel, activations in LDS
 static int forward_wide_bf16(isk_engine* e, const float* X, long long S, float* out) {
     WideFwdArgs a = {};
-    a.X = X; a.S = S; a.Fp = e->Fp; a.nhidden = e->L - 1;
+    a.X = X; a.x_bf16 = e->xh16; a.S = S; a.Fp = e->Fp; a.nhidden = e->L - 1;
     for (int l = 0; l + 1 < e->L; ++l) {
         a.N[l] = e->cfg.widths[l + 1]; a.Kp[l] = isk_pad32(e->cfg.widths[l]); a.Wt[l] = e->b16.Wt[l];
         a.bias[l] = (l == 0 && e->cfg.layernorm) ? e->d_bias[0] : e->d_theta + e->off_b[l];
@@ -26,7 +37,8 @@ static int forward_wide_bf16(isk_engine* e, const float* X, long long S, float* 
 }
 
 int forward_layered(isk_engine* e, const float* X, long long S, float* out, float* actA, float* actB) {
-    if (bf16_planes(e) == 1 && e->opt.wide_fused && forward_wide_bf16(e, X, S, out) == 0) return 0;
+    // (feature rows written as bf16 can only be read by the fused kernel: xh16 was decided with them)
+    if (e->xh16) return forward_wide_bf16(e, X, S, out);
     const float* in = X;
     int in_ld = e->Fp;
     for (int l = 0; l < e->L; ++l) {

@@ -61,6 +61,8 @@ struct FeatArgs {
     float* stats;           // optional [S][2]: mean, 1/denominator of the LayerNorm standardisation
     // split-f16 output (forward_mode 3; register featurizer only, see isk_featurize_reg_ok): xhat rows are written as
     // [Fp/32 chunks][32 x f16 hi | 32 x f16 lo] of xhat * 2^s (same 4*Fp bytes per row), 2^-s goes to xscale[row]
+    int out_bf16;           // xhat rows are written as bf16 [S][Fp] (2 Fp bytes per row): the A operand of the fused wide forward
+                            // (forward_mode 2 on the layered path); register featurizer only; not together with `planes`
     int planes;
     long long row0;         // planes only: `xhat` is the BASE of the plane buffer and local row s is global row row0 + s of its
                             // unit-blocked layout (isk_plane_off): a unit = 16 consecutive rows, per 32-feature chunk one 2 KiB
@@ -141,7 +143,8 @@ int  isk_bf16_chunks(int Kp);     // 32-feature chunks in the plane image (padde
 
 // ---------------------------------------------------------------- fused bf16 forward for wide networks (kernels_fwd_wide.hip) ----
 struct WideFwdArgs {
-    const float* X; long long S; int Fp;          // [S][Fp] f32 standardised feature rows (zero padded)
+    const void* X; long long S; int Fp;           // [S][Fp] standardised feature rows (zero padded): f32, or bf16 (x_bf16) as
+    int x_bf16;                                   //   the featurizer writes them for this path (FeatArgs.out_bf16)
     int nhidden;                                  // hidden layers (all layers but the last), each of width <= 512
     int N[ISK_MAX_LAYERS], Kp[ISK_MAX_LAYERS];    // width and padded contraction (multiple of 32) per hidden layer
     const void* Wt[ISK_MAX_LAYERS];               // bf16 images [512][Kp] (rows >= N zero): isk_launch_wt_images

@@ -115,6 +115,7 @@ __device__ isk_f32x3 isk_raw_buffer_load_f32x3(isk_i32x4 rsrc, int voffset, int 
 
 typedef float isk_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 isk_f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 isk_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ void isk_raw_buffer_store_f32x2(isk_f32x2 v, isk_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
 __device__ void isk_raw_buffer_store_u32(unsigned v, isk_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i32");
 
@@ -331,6 +332,13 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
                 }
             }
             if (lane == 0 && srow < a.S) a.xscale[srow] = inv;
+        } else if (a.out_bf16) {                             // wave-uniform: bf16 rows (2 Fp bytes each) for the fused wide forward
+            const isk_i32x4 ro = row_rv(a.xhat, srow, a.Fp / 2, a.Fp / 2);
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+                const isk_bf16x2 h = __builtin_convertvector((isk_f32x2){tt[2 * pb] * rstd, tt[2 * pb + 1] * rstd}, isk_bf16x2);
+                isk_raw_buffer_store_u32(__builtin_bit_cast(unsigned, h), ro, (128 * pb + 2 * lane) * 2, 0, FEAT_AUX);
+            }
         } else {
             const isk_i32x4 ro = row_rv(a.xhat, srow, a.Fp, a.Fp);
 #pragma unroll

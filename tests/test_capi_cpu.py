@@ -145,3 +145,34 @@ def test_options_are_per_engine_and_validated(pkg):
     src = open(os.path.join(ROOT, "isokann.jl_amd", "csrc", "engine_options.hip")).read()
     table = set(re.findall(r'\{"([a-z0-9_]+)", &IskOptions::', src))
     assert table - {"debug_inject_rank_error"} == keys - {"key"}, (table ^ keys)
+
+
+def test_product_pseudoinv_host_algebra_has_analytic_answers(pkg):
+    """TransformPseudoInv's d x d algebra runs on the host in the product too (api._pseudoinv_target, as in the reference's `|> cpu`,
+    src/isotarget.jl:152-179).  Checked against known answers, not against its twin in the oracle: if chi = M * kchi for an
+    invertible M, then chi * pinv(kchi) * kchi == chi (no eigenvectors / normalisation / permutation); the Schur vectors are
+    orthogonal (the transform only rotates that target); normalize makes every row's L1 norm N; permute returns rows of the
+    un-permuted result"""
+    api = pkg.api if hasattr(pkg, "api") else __import__("isokann_jl_amd.api", fromlist=["api"])
+    rng = np.random.default_rng(3)
+    d, n = 3, 200
+    kchi = rng.uniform(size=(d, n)).astype(np.float32)
+    M = np.array([[0.9, 0.1, 0.0], [0.05, 0.8, 0.15], [0.0, 0.2, 0.8]])
+    chi = (M @ kchi.astype(np.float64)).astype(np.float32)
+    plain = api.TransformPseudoInv(normalize=False, direct=True, eigenvecs=False, permute=False)
+    t0 = api._pseudoinv_target(plain, chi, kchi)
+    np.testing.assert_allclose(t0, chi, atol=2e-6)
+    t1 = api._pseudoinv_target(api.TransformPseudoInv(normalize=False, direct=True, eigenvecs=True, permute=False), chi, kchi)
+    # t1 = Z * t0 with Z orthogonal: the Gram matrix of the columns is unchanged
+    np.testing.assert_allclose(t1.T.astype(np.float64) @ t1, t0.T.astype(np.float64) @ t0, atol=1e-4)
+    t2 = api._pseudoinv_target(api.TransformPseudoInv(normalize=True, direct=True, eigenvecs=False, permute=False), chi, kchi)
+    np.testing.assert_allclose(np.abs(t2).sum(axis=1), n, rtol=1e-5)
+    t3 = api._pseudoinv_target(api.TransformPseudoInv(normalize=True, direct=True, eigenvecs=True, permute=True), chi, kchi)
+    t3u = api._pseudoinv_target(api.TransformPseudoInv(normalize=True, direct=True, eigenvecs=True, permute=False), chi, kchi)
+    assert sorted(map(tuple, np.round(t3, 5))) == sorted(map(tuple, np.round(t3u, 5)))
+    # fixperm picks the row order closest to chi in the entrywise 1-norm: no other order of the same rows is closer
+    import itertools
+    best = min(np.abs(t3u[list(p)] - chi).sum() for p in itertools.permutations(range(d)))
+    assert np.abs(t3 - chi).sum() <= best * (1 + 1e-6)
+    with pytest.raises(ValueError):
+        api._pseudoinv_target(plain, chi[:1], kchi[:1])
