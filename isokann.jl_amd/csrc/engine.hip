@@ -198,7 +198,7 @@ void launch_fold(isk_engine* e) {
             isk_launch_fold_T(e->d_theta, e->off_W[l], e->cfg.widths[l], e->cfg.widths[l + 1], e->d_WtT[l], e->stream);
     e->w16_dirty = true;
     e->wt_dirty = false;
-    e->b16.wt_dirty = true;
+    e->b16.wt_dirty = e->b16.wf_dirty = true;
 }
 // fused path: the training steps read theta itself, the forward weight images are rebuilt when a forward needs them
 void ensure_folded(isk_engine* e) {
@@ -428,7 +428,7 @@ extern "C" void isk_destroy(isk_engine* e) {
     free_dev(e->d_W16); free_dev(e->d_wmax); free_dev(e->d_wscale);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_W16L[l]); free_dev(e->d_WtT[l]); }
     free_dev(e->d_G0); free_dev(e->d_D0); free_dev(e->d_zero); free_dev(e->d_W0g);
-    for (int l = 0; l < ISK_MAX_LAYERS; ++l) free_dev(e->b16.Wt[l]);
+    for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->b16.Wt[l]); free_dev(e->b16.Wf[l]); }
     blas_release(e);
     dp_comm_release(e);
     free_dev(e->d_gks); free_dev(e->d_gchi);
@@ -1044,7 +1044,7 @@ void launch_opt(isk_engine* e, float gscale, bool fold, bool capturing, bool pub
     e->loss_acc_zeroed = false;
     e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2;
     if (!dev) e->bt_dev_valid = false;           // this step advanced only the host copy
-    e->b16.wt_dirty = true;
+    e->b16.wt_dirty = e->b16.wf_dirty = true;
     if (e->native) { e->wt_dirty = true; e->w16_dirty = true; }      // the training steps read theta; forwards re-fold on demand
     else if (fold) launch_fold(e);
 }

@@ -101,9 +101,10 @@ struct isk_engine {
         void* at16[ISK_MAX_LAYERS] = {nullptr};       // act_l'         [N_l + 1][Bp], row N_l = ones
         void* d16[ISK_MAX_LAYERS] = {nullptr};        // delta_l        [Bp][pad32(N_l)]
         void* dt16[ISK_MAX_LAYERS] = {nullptr};       // delta_l'       [N_l][Bp]
-        void* Wt[ISK_MAX_LAYERS] = {nullptr};         // W_l' image     [N_l][pad32(K_l)]
+        void* Wt[ISK_MAX_LAYERS] = {nullptr};         // W_l' image     [N_l][pad32(K_l)]      (training GEMMs)
+        void* Wf[ISK_MAX_LAYERS] = {nullptr};         // the same numbers, fragment-linear [pad32(K_l) / 32][32][64][8] (fused wide forward; hidden layers <= 512 wide)
         float* G0 = nullptr;                          // LayerNorm: raw layer-0 gradient [F + 1][N_0] (row F = D)
-        bool wt_dirty = true;
+        bool wt_dirty = true, wf_dirty = true;
     } b16;
     float* d_zero = nullptr;                      // zero bias for the transposed GEMMs
     double* d_loss_acc = nullptr;
@@ -239,7 +240,7 @@ void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float inv_div)
 void bf16_train_release(isk_engine* e);
 bool bf16_train_active(const isk_engine* e);
 int bf16_weight_images_alloc(isk_engine* e);             // isk_create, layered engines: the [max(N, 512)][pad32 K] bf16 images W_l'
-void bf16_weight_images_ensure(isk_engine* e);           // refresh them if theta changed since they were built
+void bf16_weight_images_ensure(isk_engine* e, bool want_wt, bool want_wf);           // refresh them if theta changed since they were built
 bool blas_ready(isk_engine* e);
 void blas_release(isk_engine* e);
 int bf16_planes(const isk_engine* e);

@@ -11,12 +11,14 @@ int bf16_planes(const isk_engine* e) { return e->cfg.forward_mode == 1 ? 3 : (e-
 static void wide_args_shape(const isk_engine* e, WideFwdArgs& a) {
     a.Fp = e->Fp; a.nhidden = e->L - 1;
     for (int l = 0; l + 1 < e->L; ++l) { a.N[l] = e->cfg.widths[l + 1]; a.Kp[l] = isk_pad32(e->cfg.widths[l]); }
-    a.Klast = e->cfg.widths[e->L - 1]; a.nout = e->nout;
+    a.Klast = e->cfg.widths[e->L - 1]; a.nout = e->nout; a.x_bf16 = 1;
 }
 bool wide_forward_shape_ok(const isk_engine* e) {
     WideFwdArgs a = {};
     wide_args_shape(e, a);
-    return e->L >= 2 && e->b16.Wt[0] && isk_wide_fwd_ok(a);
+    if (e->L < 2 || !isk_wide_fwd_ok(a)) return false;
+    for (int l = 0; l + 1 < e->L; ++l) if (!e->b16.Wf[l]) return false;
+    return true;
 }
 
 // plain-bf16 forward (forward_mode 2) of a network whose hidden layers are <= 512 wide: ONE fused kernel, activations in LDS
@@ -24,15 +26,15 @@ static int forward_wide_bf16(isk_engine* e, const float* X, long long S, float* 
     WideFwdArgs a = {};
     a.X = X; a.x_bf16 = e->xh16; a.S = S; a.Fp = e->Fp; a.nhidden = e->L - 1;
     for (int l = 0; l + 1 < e->L; ++l) {
-        a.N[l] = e->cfg.widths[l + 1]; a.Kp[l] = isk_pad32(e->cfg.widths[l]); a.Wt[l] = e->b16.Wt[l];
+        a.N[l] = e->cfg.widths[l + 1]; a.Kp[l] = isk_pad32(e->cfg.widths[l]); a.Wt[l] = e->b16.Wf[l];
         a.bias[l] = (l == 0 && e->cfg.layernorm) ? e->d_bias[0] : e->d_theta + e->off_b[l];
     }
     a.act = e->cfg.activation;
     a.Wlast = e->d_theta + e->off_W[e->L - 1]; a.blast = e->d_theta + e->off_b[e->L - 1];
     a.Klast = e->cfg.widths[e->L - 1]; a.nout = e->nout; a.lastact = e->cfg.lastactivation;
     a.out = out; a.out_ld = e->nout;
-    if (e->L < 2 || !e->b16.Wt[0] || !isk_wide_fwd_ok(a)) return ISK_EUNSUPPORTED;
-    bf16_weight_images_ensure(e);
+    if (!wide_forward_shape_ok(e) || !isk_wide_fwd_ok(a)) return ISK_EUNSUPPORTED;
+    bf16_weight_images_ensure(e, false, true);
     return isk_launch_wide_fwd(a, e->stream);
 }
 
@@ -215,21 +217,33 @@ int bf16_weight_images_alloc(isk_engine* e) {
         const size_t bytes = (size_t)std::max(e->cfg.widths[l + 1], 512) * isk_pad32(e->cfg.widths[l]) * 2;    // rows >= N stay zero
         if (hipMalloc(&e->b16.Wt[l], bytes) != hipSuccess) return ISK_ENOMEM;
         (void)hipMemset(e->b16.Wt[l], 0, bytes);
+        if (l + 1 < e->L && e->cfg.widths[l + 1] <= 512) {           // hidden layer the fused wide forward can take: 512 (padded) columns
+            const size_t fb = (size_t)512 * ((e->cfg.widths[l] + 127) / 128 * 128) * 2;     // zero steps up to a multiple of four
+            if (hipMalloc(&e->b16.Wf[l], fb) != hipSuccess) return ISK_ENOMEM;
+            (void)hipMemset(e->b16.Wf[l], 0, fb);
+        }
     }
-    e->b16.wt_dirty = true;
+    e->b16.wt_dirty = e->b16.wf_dirty = true;
     return ISK_OK;
 }
 
-void bf16_weight_images_ensure(isk_engine* e) {
+// the row-major images feed the training GEMMs (rebuilt every optimizer step), the fragment-linear ones the fused forward
+// (rebuilt once per forward after a parameter change)
+void bf16_weight_images_ensure(isk_engine* e, bool want_wt, bool want_wf) {
     auto& b = e->b16;
-    if (!b.wt_dirty || !b.Wt[0]) return;
+    want_wt = want_wt && b.wt_dirty && b.Wt[0];
+    want_wf = want_wf && b.wf_dirty && b.Wf[0];
+    if (!want_wt && !want_wf) return;
     WtImagesArgs w = {};
     w.theta = e->d_theta; w.scale0 = e->cfg.layernorm ? e->d_theta + e->off_lns : nullptr; w.nlayers = e->L;
     for (int l = 0; l < e->L; ++l) {
-        w.off_W[l] = e->off_W[l]; w.K[l] = e->cfg.widths[l]; w.N[l] = e->cfg.widths[l + 1]; w.Kp[l] = isk_pad32(w.K[l]); w.Wt[l] = b.Wt[l];
+        w.off_W[l] = e->off_W[l]; w.K[l] = e->cfg.widths[l]; w.N[l] = e->cfg.widths[l + 1]; w.Kp[l] = isk_pad32(w.K[l]);
+        w.Wt[l] = want_wt ? b.Wt[l] : nullptr;
+        w.Wf[l] = want_wf ? b.Wf[l] : nullptr;
     }
     isk_launch_wt_images(w, e->stream);
-    b.wt_dirty = false;
+    if (want_wt) b.wt_dirty = false;
+    if (want_wf) b.wf_dirty = false;
 }
 
 __global__ void fill_u16_kernel(unsigned short* p, long long n, unsigned short v) {
@@ -272,7 +286,7 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
     hipStream_t st = e->stream;
     const bool ln = e->cfg.layernorm != 0;
     isk_launch_gather_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, st);
-    bf16_weight_images_ensure(e);
+    bf16_weight_images_ensure(e, true, false);
     bool ok = true;
     for (int l = 0; l < L && ok; ++l) {
         const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];

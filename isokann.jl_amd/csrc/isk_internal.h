@@ -143,11 +143,11 @@ int  isk_bf16_chunks(int Kp);     // 32-feature chunks in the plane image (padde
 
 // ---------------------------------------------------------------- fused bf16 forward for wide networks (kernels_fwd_wide.hip) ----
 struct WideFwdArgs {
-    const void* X; long long S; int Fp;           // [S][Fp] standardised feature rows (zero padded): f32, or bf16 (x_bf16) as
-    int x_bf16;                                   //   the featurizer writes them for this path (FeatArgs.out_bf16)
+    const void* X; long long S; int Fp;           // [S][Fp] standardised feature rows (zero padded), bf16 as the featurizer
+    int x_bf16;                                   //   writes them for this path (FeatArgs.out_bf16; must be 1)
     int nhidden;                                  // hidden layers (all layers but the last), each of width <= 512
     int N[ISK_MAX_LAYERS], Kp[ISK_MAX_LAYERS];    // width and padded contraction (multiple of 32) per hidden layer
-    const void* Wt[ISK_MAX_LAYERS];               // bf16 images [512][Kp] (rows >= N zero): isk_launch_wt_images
+    const void* Wt[ISK_MAX_LAYERS];               // fragment-linear bf16 images (WtImagesArgs.Wf; columns >= N zero): isk_launch_wt_images
     const float* bias[ISK_MAX_LAYERS];
     int act;
     const float* Wlast; const float* blast;       // last layer, f32, Flux layout (out, in) column-major; Klast = N[nhidden - 1]
@@ -217,7 +217,9 @@ struct WtImagesArgs {
     int nlayers;
     long long off_W[ISK_MAX_LAYERS];
     int K[ISK_MAX_LAYERS], N[ISK_MAX_LAYERS], Kp[ISK_MAX_LAYERS];
-    void* Wt[ISK_MAX_LAYERS];                    // [N][Kp] bf16
+    void* Wt[ISK_MAX_LAYERS];                    // [N][Kp] bf16 (nullptr: not wanted)
+    void* Wf[ISK_MAX_LAYERS];                    // fragment-linear [pad128(K) / 32][32][64 lanes][8] bf16 of a layer <= 512 wide, zero
+                                                 //   initialised by the owner (steps >= Kp / 32 are never written); nullptr: not wanted
     int first_block[ISK_MAX_LAYERS];             // filled by the launcher
 };
 void isk_launch_wt_images(WtImagesArgs& a, hipStream_t st);

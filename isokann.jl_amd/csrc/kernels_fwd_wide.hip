@@ -1,43 +1,47 @@
 // Fused bf16 forward for WIDE networks (hidden widths <= 512: C5's densenet [2000,512,512,512,1]): the Koopman forward of
 // forward_mode 2 (bf16 operands, f32 accumulate -- the arithmetic BASELINE.json names for C5) as ONE kernel in which the
 // activations of a 128-row block never leave the CU.  The layer-by-layer path it replaces wrote and re-read a [rows][512]
-// activation buffer per layer through HBM (8.4 GB per launch at C5-shard size against 3.3 GB of features) and re-streamed the
-// sample rows per column block.
+// activation buffer per layer through HBM (8.4 GB per launch at C5-shard size against 1.6 GB of bf16 features).
 //
-// Workgroup = 8 waves = 128 rows; wave (rg = w >> 2, cg = w & 3) owns rows [64 rg, +64) x columns {256 h + 64 cg + 16 c + li : h < 2,
-// c < 4} of a layer's (padded) 512 outputs: 4 x 8 accumulator tiles of v_mfma_f32_16x16x32_bf16 = 128 registers.
-//   layer 1   K-loop over the features, 32 per step.  BOTH tiles of a step go global -> LDS directly (global_load_lds_dwordx4, no
-//             staging registers): the W tile (512 columns x 32, bf16 image [n][k], 32 KiB) and the A tile -- 128 rows x 32
-//             features, either bf16 as the featurizer wrote them for this path (8 KiB; FeatArgs.out_bf16) or f32 (16 KiB, converted
-//             when the fragments are read).  16-byte chunks are XOR-swizzled through the DMA's SOURCE addresses so that every
-//             fragment read is conflict-free.  Three ring slots, tiles requested TWO steps ahead, ONE raw s_barrier per step
-//             behind a counted s_waitcnt vmcnt(N) (N = the DMA instructions of one tile: the newest tile stays in flight).
-//   layer l>1 A = the previous layer's activations, resident in LDS as bf16 [128][512] (chunks XOR-swizzled by row); the outputs
-//             stay in registers until every wave has finished reading, then overwrite the activations in place.  The W tiles of
-//             the two column halves are streamed one after the other through a two-slot ring of 16 KiB tiles (the activations
-//             take 128 of the 160 KiB), one tile ahead.
+// Workgroup = 8 waves = 128 rows; wave w owns ALL 128 rows x the 64 columns [64 w, +64) of a layer's (padded) 512 outputs:
+// 8 x 4 accumulator tiles of v_mfma_f32_16x16x32_bf16 = 128 registers.  The product is computed transposed -- the WEIGHT
+// fragment is the MFMA's A operand, the sample fragment its B operand -- so a lane ends up with four consecutive output
+// COLUMNS of one row: the next layer's contraction index, one ds_write_b64 per tile.
+//   weights   never pass through LDS.  Every layer has a FRAGMENT-LINEAR bf16 image (isk_launch_wt_images, Wf): the 16 bytes
+//             lane L feeds the MFMA for 16-column block nb and 32-feature step kb sit at ((kb * 32 + nb) * 64 + L) * 16, so a
+//             wave's four fragments of a step are 4 contiguous KiB, read with four fully coalesced global_load_dwordx4 straight
+//             into registers, FOUR steps ahead (a ring of 4 x 16 registers).  No two waves read the same bytes, nothing
+//             is staged or re-read through LDS, and no barrier guards them: with the 64 x 128 wave tiles of the previous
+//             kernel the W fragments were two thirds of the LDS traffic (96 KiB read + 40 KiB written per 32-feature step
+//             against 1024 matrix-pipe clocks: the LDS port was as busy as the matrix pipe).
+//   layer 1   the feature rows (bf16, as the featurizer writes them for this path: FeatArgs.out_bf16) go global -> LDS by
+//             LDS-DMA, 128 rows x 128 features (32 KiB) per ring slot, three slots, two groups ahead, ONE barrier per 128
+//             features.  A DMA instruction moves 4 rows x 256 contiguous bytes; the 16-byte pieces of a row are XOR-swizzled
+//             with row & 15 through the SOURCE addresses, so the fragment reads are conflict-free.
+//   layer l>1 B operand = the previous layer's activations, resident in LDS as bf16 [128][512] (16-byte chunks XORed with
+//             row & 15); NO barrier inside the K-loop (waves drift apart: one wave's LDS reads run under its SIMD partner's
+//             MFMAs); the outputs stay in registers until every wave has finished reading, then overwrite the activations.
 //   last      nout <= 16 outputs per row: plain f32 dot products against the f32 weights, four lanes per row.
-// What bounds it is how many bytes a CU takes in per MFMA: the accumulators of a 128 x 512 block fill half the register file, so
-// the W tiles are re-streamed from L2 per 128 rows (320 B per row and step with bf16 rows); see DESIGN.md section 3 for the
-// measured ablations.
-// LDS: layer 1: [W ring 3 x 32 KiB | A ring 3 x 8 (16) KiB] <= 144 KiB; afterwards [activations 128 KiB | W ring 2 x 16 KiB] = 160 KiB.
+//   next block: its first feature group is requested into the ring slot that lies outside the activation image as soon as
+//             layer 1 is done, its first weight fragments before the last layer -- the block boundary exposes no round trip.
+// LDS: [activations 128 KiB | ring slot 0 32 KiB]; ring slots 1, 2 alias the first 64 KiB of the activation image (dead
+// while layer 1 runs).
 #include <type_traits>
 
 #include "isk_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16;
 
 #define WF_BM 128
 #define WF_NP 512
 #define WF_ACT_BYTES (WF_BM * WF_NP * 2)                 // 131072
-#define WF_W1_SLOT (512 * 64)                            // layer-1 W tile: 512 columns x 32 bf16
-#define WF_A1_SLOT_F32 (WF_BM * 128)                     // layer-1 A tile: 128 rows x 32 f32
-#define WF_A1_SLOT_B16 (WF_BM * 64)                      //                 128 rows x 32 bf16
-#define WF_W2_SLOT (256 * 64)                            // later layers: 256 columns x 32 bf16
-#define WF_LDS_BYTES (WF_ACT_BYTES + 2 * WF_W2_SLOT)     // 163840 >= 3 * (WF_W1_SLOT + WF_A1_SLOT_F32) = 147456
+#define WF_A_SLOT (WF_BM * 256)                          // layer-1 ring slot: 128 rows x 128 bf16 features
+#define WF_LDS_BYTES (WF_ACT_BYTES + WF_A_SLOT)          // 163840
+#define WF_WSTEP (32 * 1024)                             // bytes of a layer's fragment-linear image per 32-feature step
 
 __device__ __forceinline__ float wf_sigmoid(float z) {
     float e = __expf(-fabsf(z));
@@ -64,215 +68,214 @@ __device__ __forceinline__ float wf_act_rt(int act, float z) {
         default: return z;
     }
 }
-// byte offset of column `col` of row `row` inside the swizzled activation image
-__device__ __forceinline__ int act_off(int row, int col) { return row * (WF_NP * 2) + ((((col >> 3) ^ (row & 15))) << 4) + ((col & 7) << 1); }
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-// one wave-instruction: 64 lanes x 16 B from per-lane global addresses to the contiguous KiB at `dst` (lane L lands at dst + 16 L)
-__device__ __forceinline__ void glds16(const void* src, unsigned char* dst) {
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to the contiguous KiB at LDS byte
+// address `dst` (lane L lands at dst + 16 L).  Issued as inline assembly ON PURPOSE: hipcc makes every LDS read that follows a
+// __builtin_amdgcn_global_load_lds wait for vmcnt(0) (it cannot know which bytes the DMA writes) -- i.e. for the tile requested
+// a moment ago, which serialises the whole pipeline.  Landing is synchronised by hand (WF_WAIT_VM + barrier below); the "memory"
+// clobber keeps the compiler from carrying LDS contents across the request.
+// (M0 carries the LDS address of an LDS-DMA; nothing else in this kernel uses it -- gfx950 DS instructions do not read M0.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 #define WF_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-// diagnostic builds only (timing valid, results not): -DWF_ABLATE=bits -- 1: the A-tile loads of layer 1 re-read ONE tile (cache
-// resident: no HBM stream), 2: likewise the layer-1 W-tile loads, 4: no MFMAs (the fragment reads stay), 8: no LDS-DMA at all
+// diagnostic builds only (timing valid, results not): -DWF_ABLATE=bits -- 1: the feature groups re-read ONE group (cache
+// resident: no HBM stream), 2: every weight step re-reads the layer's first step, 4: no MFMAs (the fragment reads stay),
+// 8: no feature DMA at all, 16: no weight loads after a layer's first four steps
 #ifndef WF_ABLATE
 #define WF_ABLATE 0
 #endif
 
-template <int ACT, bool XB16>
+template <int ACT>
 __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave-uniform: addresses built from it stay in SGPRs
-    const int li = lane & 15, lq = lane >> 4;
-    const int rg = wave >> 2, cg = wave & 3;
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;
     const long long nblk = (a.S + WF_BM - 1) / WF_BM;
-    // Register budget (two waves per SIMD: 256): uniform 64-bit bases + 32-bit lane offsets, LDS offsets as instruction immediates
-    // on top of one base per stream -- per-tile address registers next to the accumulators made hipcc spill into the K-loops.
-    // bf16 tiles are [row | column][4 x 16 B]; the 16-byte part index is XORed with f((index >> 2) & 3), f = {0, 2, 3, 1}, through the
-    // DMA's SOURCE addresses: with that f the sixteen lanes the LDS serves together for a ds_read_b128 ({lq0: li 0-3, 12-15;
-    // lq1: li 4-11} and its mirror images) fall on sixteen different 4-bank groups -- unswizzled, the fragment reads were 2-way conflicts
-    auto wswz = [](unsigned x) { return ((x << 1) ^ ((x >> 1) * 3u)) & 3u; };
-    const unsigned frag_part = (((unsigned)lq ^ wswz((unsigned)(li >> 2) & 3u)) << 4);     // this lane's 16 B inside a 64-byte row of a bf16 tile
-    const unsigned w_ld_off = (unsigned)((64 * cg + li) * 64) + frag_part;                 // B fragment of column tile (h = 0, c = 0)
-    const unsigned src_part = ((unsigned)(lane & 3) ^ wswz((unsigned)(lane >> 4) & 3u)) * 8u;     // features this lane's 16 B hold in a 16-row DMA piece
-    const unsigned a16_ld_off = (unsigned)((64 * rg + li) * 64) + frag_part;               // bf16 rows: A fragment of row tile 0
-    const unsigned a_swz = (unsigned)(li >> 1);                                            // f32 rows: ((row >> 1) & 7) of every row this lane reads
-    const unsigned a32_ld_lo = (unsigned)((64 * rg + li) * 128) + (((2u * lq) ^ a_swz) << 4);      // features 8 lq .. 8 lq + 3 of row tile 0
-    const unsigned a32_ld_hi = (unsigned)((64 * rg + li) * 128) + (((2u * lq + 1u) ^ a_swz) << 4); // features 8 lq + 4 .. + 7
-    constexpr int A1_SLOT = XB16 ? WF_A1_SLOT_B16 : WF_A1_SLOT_F32;
-    for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const long long row0 = blk * WF_BM;
-        f32x4 acc[4][8];
+    const int ng1 = (a.Kp[0] + 127) >> 7;                                // ring groups of layer 1: 128 features (four steps) each
+    const int kbytes1 = a.Kp[0] * 2;
+    // Register budget (two waves per SIMD: 256): 128 accumulators + 64 weight-ring + 32 sample fragments leave ~30 for everything
+    // else.  Addresses are therefore (uniform 64-bit base in SGPRs) + (one 32-bit lane offset) + (instruction immediate), and
+    // whatever depends on the lane index is re-derived where it is used from a copy of it the compiler cannot see through
+    // (WF_LANE): hoisted out of the loops, the per-instruction address registers were spilled (300 registers of scratch).
+#define WF_LANE(l_) unsigned l_ = (unsigned)lane; asm volatile("" : "+v"(l_))
+    // ring slot offsets: slot 0 behind the activation image, slots 1 and 2 over its first 64 KiB
+    auto slot_off = [](int s) -> unsigned { return s == 0 ? (unsigned)WF_ACT_BYTES : (unsigned)(s - 1) * WF_A_SLOT; };
+
+    // the weight-fragment ring: set i holds step (4 g + i) of the running layer.  Every image is padded with zero steps to a
+    // multiple of FOUR steps, and the stream of (layer, step) pairs a block consumes is continuous: the group that runs a layer's
+    // last four steps requests the first four of the next layer (after the last hidden layer: of layer 1, for the next block) --
+    // every group is the same straight-line code, the ring never drains, and no load is conditional
+    bf16x8 fw[4][4];
+    const unsigned w_lane = (unsigned)lane * 16u;
+    auto load_w = [&](const unsigned char* p, auto I) {            // p: uniform
+        constexpr int i = decltype(I)::value;
+        asm volatile("" : "+s"(p));
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int c = 0; c < 4; ++c) fw[i][c] = *(const __attribute__((address_space(1))) bf16x8*)(p + w_lane + c * 1024);
+    };
+    // feature group g of block `row0` -> ring slot: instruction q moves rows 16 wave + 4 q + lq, physical piece li of a row holding
+    // logical piece li ^ (row & 15) = li ^ (4 q + lq); bytes past the (padded) row re-read its last 16 (their step is never run);
+    // rows past the end re-read the last row (never stored)
+    auto issue_a = [&](long long row0, int g, int slot) {
+        if (WF_ABLATE & 8) return;
+        const unsigned char* xb = (const unsigned char*)a.X + (size_t)row0 * kbytes1;            // uniform (Fp == Kp[0])
+        asm volatile("" : "+s"(xb));
+        const unsigned dst = lds_base + slot_off(slot) + (16 * wave) * 256;
+        const int gg = (WF_ABLATE & 1) ? 0 : g;
+        const long long left = a.S - 1 - row0;
+        const int rmax = left < WF_BM - 1 ? (int)left : WF_BM - 1;
+        WF_LANE(ln);
+        const int li_ = ln & 15, lq_ = ln >> 4;
 #pragma unroll
-            for (int ct = 0; ct < 8; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // ------------------------------------------------------------------ layer 1: A and W tiles by LDS-DMA ----------------
-        {
-            unsigned char* const Wr = lds;                           // [3][512 cols][64 B]
-            unsigned char* const Ar = lds + 3 * WF_W1_SLOT;          // [3][128 rows][64 | 128 B]
-            const int nk = a.Kp[0] / 32;
-            const int Kp = a.Kp[0];
-            // W: 16 columns x 64 B per wave-instruction (lane L -> column 16 g + L / 4, features src_part ..), groups g = 4 wave + i.
-            const unsigned char* wb = (const unsigned char*)a.Wt[0] + (size_t)(64 * wave) * Kp * 2;     // uniform
-            const unsigned w_g_off = (unsigned)(((lane >> 2) * Kp + src_part) * 2);
-            const unsigned wstep = (unsigned)(16 * Kp * 2);
-            // A, bf16 rows: ONE instruction per wave (rows 16 wave + L / 4, as a W piece).  A, f32 rows: two (8 rows x 128 B each:
-            // lane L -> row 16 wave + 8 j + L / 8, PHYSICAL chunk L % 8 holding logical chunk (L % 8) ^ ((row >> 1) & 7)).
-            // Rows past the end re-read the last row (never stored).
-            const int xes = XB16 ? 2 : 4;
-            const unsigned char* xb = (const unsigned char*)a.X + (size_t)row0 * a.Fp * xes;             // uniform
-            unsigned a_g_off[2];
-            if (XB16) {
-                long long xr = row0 + 16 * wave + (lane >> 2);
-                xr = xr < a.S ? xr : a.S - 1;
-                a_g_off[0] = (unsigned)(((xr - row0) * a.Fp + src_part) * 2);
-                a_g_off[1] = 0;
-            } else {
+        for (int q = 0; q < 4; ++q) {
+            int r = 16 * wave + 4 * q + lq_;
+            r = r < rmax ? r : rmax;
+            int kb = gg * 256 + ((li_ ^ (4 * q + lq_)) << 4);
+            kb = kb < kbytes1 - 16 ? kb : kbytes1 - 16;
+            glds16(xb, (unsigned)(r * kbytes1 + kb), dst + q * 1024);
+        }
+    };
+
+    f32x4 acc[8][4];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int row = 16 * wave + 8 * j + (lane >> 3);
-                    long long xr = row0 + row;
-                    xr = xr < a.S ? xr : a.S - 1;
-                    a_g_off[j] = (unsigned)(((xr - row0) * a.Fp + 4 * ((lane & 7) ^ ((row >> 1) & 7))) * 4);
+    for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // A group of four 32-feature steps.  `abx` = LDS offset of this lane's row (li) of row tile 0 in the group's 256-byte run,
+    // with the swizzle bits of step 0 merged in: piece (4 i + lq) ^ li = (4 i) ^ (lq ^ li), so step i is abx ^ 64 i; row tile rt
+    // is rt * rstride further.  `wr` = the four steps that follow the ring's contents in the weight stream (this wave's 4 KiB of
+    // each).  The sample fragments of a step are read in two halves of four row tiles, each half one phase ahead of the sixteen
+    // MFMAs that use it (rows 0-63 of step i + 1 are requested before the MFMAs on rows 64-127 of step i): a wave's own LDS
+    // latency hides under its own MFMAs, whatever its SIMD partner is doing.  The scheduling barriers pin exactly this order.
+    auto group = [&](auto RS, unsigned abx, const unsigned char* wr) {
+        constexpr int rstride = decltype(RS)::value;
+        bf16x8 lo[4], hi[4];
+        auto rd4 = [&](unsigned base, bf16x8 (&f)[4]) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f[t] = *(const bf16x8*)(lds + base + t * rstride);
+        };
+        auto mm16 = [&](bf16x8 (&f)[4], auto RT0, auto I) {
+            constexpr int rt0 = decltype(RT0)::value, i = decltype(I)::value;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (WF_ABLATE & 4) asm volatile("" :: "v"(f[t]), "v"(fw[i][c]));
+                    else acc[rt0 + t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i][c], f[t], acc[rt0 + t][c], 0, 0, 0);
                 }
+        };
+        rd4(abx, lo);
+#define WF_STEP(I_)                                                                                                         \
+        rd4((abx ^ (64u * I_)) + 4u * rstride, hi);                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        mm16(lo, std::integral_constant<int, 0>{}, std::integral_constant<int, I_>{});                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        if (I_ < 3) rd4(abx ^ (64u * (I_ + 1)), lo);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        mm16(hi, std::integral_constant<int, 4>{}, std::integral_constant<int, I_>{});                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        if (!(WF_ABLATE & 16)) load_w(wr + ((WF_ABLATE & 2) ? 0 : I_ * WF_WSTEP), std::integral_constant<int, I_>{});       \
+        __builtin_amdgcn_sched_barrier(0);
+        WF_STEP(0) WF_STEP(1) WF_STEP(2) WF_STEP(3)
+#undef WF_STEP
+    };
+
+    // epilogue of layer l: bias + activation, bf16, in place over the ring / the previous activations.  Element (rt, c, r) is row
+    // 16 rt + li, column 64 wave + 16 c + 4 lq + r: the four r of a tile are 8 contiguous bytes of the row
+    auto epilogue = [&](int l) {
+        const float* bias = a.bias[l];
+        const int Nl = a.N[l];
+        WF_LANE(ln);
+        const int li_ = ln & 15, lq_ = ln >> 4;
+        float bv[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                    // the bias loads together, from clamped addresses (no load behind a branch)
+                const int col = 64 * wave + 16 * c + 4 * lq_ + r;
+                bv[c][r] = bias[col < Nl ? col : Nl - 1];
             }
-            auto issue = [&](int ks, int slot) {
-                if (WF_ABLATE & 8) return;
+        const unsigned rowoff = (unsigned)(li_ * (WF_NP * 2)) + (unsigned)((lq_ & 1) << 3);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    glds16((WF_ABLATE & 2) ? wb + w_g_off : wb + (size_t)i * wstep + (size_t)ks * 64 + w_g_off, Wr + slot * WF_W1_SLOT + (4 * wave + i) * 1024);
-                const size_t kx = (WF_ABLATE & 1) ? 0 : (size_t)ks * 32 * xes;
-                if (XB16) {
-                    glds16(xb + kx + a_g_off[0], Ar + slot * A1_SLOT + (16 * wave) * 64);
-                } else {
-                    glds16(xb + kx + a_g_off[0], Ar + slot * A1_SLOT + (16 * wave) * 128);
-                    glds16(xb + kx + a_g_off[1], Ar + slot * A1_SLOT + (16 * wave + 8) * 128);
+        for (int c = 0; c < 4; ++c) {
+            const int col0 = 64 * wave + 16 * c + 4 * lq_;
+            const unsigned off = rowoff + ((((unsigned)(col0 >> 3)) ^ (unsigned)li_) << 4);
+#pragma unroll
+            for (int rt = 0; rt < 8; ++rt) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = wf_act<ACT>(acc[rt][c][r] + bv[c][r]);
+                    v[r] = (col0 + r < Nl) ? z : 0.f;        // padded columns feed zeros into the next contraction
                 }
-            };
-            issue(0, 0);
-            if (nk > 1) issue(1, 1);
+                const bf16x4 h = __builtin_convertvector(v, bf16x4);
+                *(u32x2*)(lds + off + rt * (16 * WF_NP * 2)) = __builtin_bit_cast(u32x2, h);
+                acc[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();
+    };
+
+    const unsigned char* const wf0 = (const unsigned char*)a.Wt[0] + (size_t)wave * 4096;
+    long long blk = blockIdx.x;
+    if (blk < nblk) {
+        issue_a(blk * WF_BM, 0, 0);
+        load_w(wf0, std::integral_constant<int, 0>{});
+        load_w(wf0 + WF_WSTEP, std::integral_constant<int, 1>{});
+        load_w(wf0 + 2 * WF_WSTEP, std::integral_constant<int, 2>{});
+        load_w(wf0 + 3 * WF_WSTEP, std::integral_constant<int, 3>{});
+    }
+    for (; blk < nblk; blk += gridDim.x) {
+        const long long row0 = blk * WF_BM;
+        const long long next = blk + gridDim.x;
+        // ------------------------------------------------------------------ layer 1 ------------------------------------------
+        if (ng1 > 1) issue_a(row0, 1, 1);
+        {
+            const unsigned char* wn = a.nhidden > 1 ? (const unsigned char*)a.Wt[1] + (size_t)wave * 4096 : wf0;
             int slot = 0;
-            for (int ks = 0; ks < nk; ++ks) {
-                // tile ks has landed once every wave's share has: this wave's DMA instructions of it are older than those of tile
-                // ks + 1 (vmcnt retires in order), then the barrier.  The barrier also says every wave is through the MFMAs of
-                // step ks - 1, i.e. through its reads of slot (ks + 2) % 3, which the next request overwrites
-                if (ks + 1 < nk) { if (XB16) WF_WAIT_VM(5); else WF_WAIT_VM(6); } else WF_WAIT_VM(0);
+            for (int g = 0; g < ng1; ++g) {
+                // group g has landed once every wave's share has: this wave's DMA instructions of it are older than everything it
+                // has requested since (vmcnt retires in order) -- 20 instructions before groups 0 and 1 (16 weight fragments + one
+                // feature group), 36 in the steady state (two groups' weight fragments + one feature group), 32 before the last
+                // group (no feature group follows it).  The barrier also says every wave is through group g - 1, whose slot the
+                // next request overwrites.
+                if (ng1 < 3) WF_WAIT_VM(0);
+                else if (g < 2) WF_WAIT_VM(20);
+                else if (g + 1 < ng1) WF_WAIT_VM(36);
+                else WF_WAIT_VM(32);
                 __builtin_amdgcn_s_barrier();
-                // The two waves of a SIMD (w and w + 4) run the same program in lockstep after every barrier: both would sit in the
-                // DMA-issue phase together (the matrix pipe idle), then contend for the matrix pipe together.  Waves 4..7 therefore
-                // request the next tile in the MIDDLE of their MFMAs: while one wave of the SIMD issues its DMA, the other computes.
-                const bool late = wave >= 4;
-                if (!late && ks + 2 < nk) issue(ks + 2, slot == 0 ? 2 : slot - 1);
-                const unsigned char* As = Ar + slot * A1_SLOT;
-                const unsigned char* Ws = Wr + slot * WF_W1_SLOT + w_ld_off;
-                bf16x8 fa[4];
-#pragma unroll
-                for (int rt = 0; rt < 4; ++rt) {
-                    if (XB16) {
-                        fa[rt] = *(const bf16x8*)(As + rt * 1024 + a16_ld_off);
-                    } else {
-                        const f32x4 lo = *(const f32x4*)(As + rt * 2048 + a32_ld_lo), hi = *(const f32x4*)(As + rt * 2048 + a32_ld_hi);
-                        fa[rt] = __builtin_convertvector(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), bf16x8);
-                    }
-                }
-#pragma unroll
-                for (int ct = 0; ct < 8; ++ct) {
-                    if (ct == 4 && late && ks + 2 < nk) issue(ks + 2, slot == 0 ? 2 : slot - 1);
-                    const bf16x8 fb = *(const bf16x8*)(Ws + (ct >> 2) * 16384 + (ct & 3) * 1024);
-#pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) {
-                        if (WF_ABLATE & 4) asm volatile("" :: "v"(fa[rt]), "v"(fb));
-                        else acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[rt], fb, acc[rt][ct], 0, 0, 0);
-                    }
-                }
+                if (g + 2 < ng1) issue_a(row0, g + 2, slot == 0 ? 2 : slot - 1);
+                asm volatile("" ::: "memory");
+                WF_LANE(ln);
+                const unsigned li_ = ln & 15, lq_ = ln >> 4;
+                const unsigned abx = (slot_off(slot) + li_ * 256u) | ((li_ ^ lq_) << 4);
+                group(std::integral_constant<int, 4096>{}, abx, g + 1 < ng1 ? wf0 + (size_t)(4 * g + 4) * WF_WSTEP : wn);
+                asm volatile("" ::: "memory");
                 slot = slot == 2 ? 0 : slot + 1;
             }
-            __syncthreads();                                 // every wave is through its last reads: the rings are dead
         }
-        // ------------------------------------------------------------------ hidden layers: epilogue, then the next K-loop from LDS
-        // epilogue of layer l: the outputs overwrite the rings / the previous activations in place.  Element (rt, ct = 4 h + c, r) is
-        // row 64 rg + 16 rt + 4 lq + r, column 256 h + 64 cg + 16 c + li; its 16-byte chunk index (column / 8) is XORed with
-        // row & 15 = 4 lq + r.
-        auto epilogue = [&](int l) {
-            const float* bias = a.bias[l];
-            const int Nl = a.N[l];
-            float bv[8];
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct) {                 // the eight bias loads together, from clamped addresses (no load behind a branch)
-                const int col = 256 * (ct >> 2) + 64 * cg + 16 * (ct & 3) + li;
-                bv[ct] = bias[col < Nl ? col : Nl - 1];
-            }
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct) {
-                const int col = 256 * (ct >> 2) + 64 * cg + 16 * (ct & 3) + li;
-                const bool live = col < Nl;                  // padded columns feed zeros into the next contraction
-                const unsigned cbase = (unsigned)((64 * rg + 4 * lq) * (WF_NP * 2) + ((col & 7) << 1));
-                const unsigned chunk = (unsigned)(col >> 3);
-#pragma unroll
-                for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = wf_act<ACT>(acc[rt][ct][r] + bv[ct]);
-                        v = live ? v : 0.f;
-                        const __bf16 h = (__bf16)v;
-                        *(u16*)(lds + cbase + (rt * 16 + r) * (WF_NP * 2) + ((chunk ^ (unsigned)(4 * lq + r)) << 4)) = __builtin_bit_cast(u16, h);
-                        acc[rt][ct][r] = 0.f;
-                    }
-            }
-            __syncthreads();
-        };
+        __syncthreads();                                     // every wave is through its last reads: the ring is dead
+        // the next block's first feature group, into the slot outside the activation image
+        if (next < nblk) issue_a(next * WF_BM, 0, 0);
         epilogue(0);
+        // ------------------------------------------------------------------ hidden layers l > 1: B operand from the activation image
         for (int l = 1; l < a.nhidden; ++l) {
-            // K-loop of layer l: contraction over the (padded) width of layer l - 1; the W tiles of the two column halves follow each
-            // other through ONE two-slot ring (step s: half s / nk, k-step s % nk), one tile ahead, across the half boundary
-            unsigned char* const Wr = lds + WF_ACT_BYTES;    // [2][256 cols][64 B]
-            const int nk = a.Kp[l] / 32;
-            const int Kp = a.Kp[l];
-            const int nsteps = 2 * nk;
-            // W: two column groups of 16 per wave and step (g = 2 wave + i)
-            const unsigned char* wb = (const unsigned char*)a.Wt[l] + (size_t)(32 * wave) * Kp * 2;        // uniform
-            const unsigned w_g_off = (unsigned)(((lane >> 2) * Kp + src_part) * 2);
-            const unsigned a_row_off = (unsigned)((64 * rg + li) * (WF_NP * 2));
-            auto issue = [&](int s2, int slot) {
-                if (WF_ABLATE & 8) return;
-                const int h = s2 >= nk ? 1 : 0, ks = s2 - h * nk;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    glds16(wb + (size_t)(256 * h + 16 * i) * Kp * 2 + (size_t)ks * 64 + w_g_off, Wr + slot * WF_W2_SLOT + (2 * wave + i) * 1024);
-            };
-            issue(0, 0);
-            int slot = 0, s2 = 0;
-            auto half = [&](auto H) {
-                constexpr int h = decltype(H)::value;
-                for (int ks = 0; ks < nk; ++ks, ++s2) {
-                    WF_WAIT_VM(0);                            // this wave's share of tile s2 (requested a whole step ago) has landed ...
-                    __builtin_amdgcn_s_barrier();             // ... and everybody's; everybody is through its reads of the other slot
-                    const bool late = wave >= 4;              // as in layer 1: the SIMD partners request their tiles at different points
-                    if (!late && s2 + 1 < nsteps) issue(s2 + 1, slot ^ 1);
-                    const unsigned ach = a_row_off + ((((unsigned)(ks * 4 + lq)) ^ (unsigned)li) << 4);       // row & 15 == li for every row tile
-                    const unsigned char* Ws = Wr + slot * WF_W2_SLOT + w_ld_off;
-                    bf16x8 fa[4];
-#pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) fa[rt] = *(const bf16x8*)(lds + ach + rt * (16 * WF_NP * 2));
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (c == 2 && late && s2 + 1 < nsteps) issue(s2 + 1, slot ^ 1);
-                        const bf16x8 fb = *(const bf16x8*)(Ws + c * 1024);
-#pragma unroll
-                        for (int rt = 0; rt < 4; ++rt) {
-                            if (WF_ABLATE & 4) asm volatile("" :: "v"(fa[rt]), "v"(fb));
-                            else acc[rt][4 * h + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[rt], fb, acc[rt][4 * h + c], 0, 0, 0);
-                        }
-                    }
-                    slot ^= 1;
-                }
-            };
-            half(std::integral_constant<int, 0>{});
-            half(std::integral_constant<int, 1>{});
+            const unsigned char* wl = (const unsigned char*)a.Wt[l] + (size_t)wave * 4096;
+            const unsigned char* wn = l + 1 < a.nhidden ? (const unsigned char*)a.Wt[l + 1] + (size_t)wave * 4096 : wf0;
+            const int ng = (a.Kp[l] + 127) >> 7;
+            for (int g = 0; g < ng; ++g) {
+                WF_LANE(ln);
+                const unsigned li_ = ln & 15, lq_ = ln >> 4;
+                const unsigned abx = (li_ * (unsigned)(WF_NP * 2) + (unsigned)g * 256u) | ((li_ ^ lq_) << 4);
+                group(std::integral_constant<int, 16 * WF_NP * 2>{}, abx, g + 1 < ng ? wl + (size_t)(4 * g + 4) * WF_WSTEP : wn);
+            }
             __syncthreads();                                 // every wave is through its reads of the activations
             epilogue(l);
         }
@@ -314,22 +317,22 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
                 }
             }
         }
-        __syncthreads();                                      // the next block's rings overwrite the activations
+        __syncthreads();                                      // the next block's ring slots 1, 2 overwrite the activations
     }
 }
 
 int isk_wide_fwd_ok(const WideFwdArgs& a) {
     if (a.nhidden < 1 || a.nhidden >= ISK_MAX_LAYERS || a.nout < 1 || a.nout > 16) return 0;
     for (int l = 0; l < a.nhidden; ++l)
-        if (a.N[l] < 1 || a.N[l] > WF_NP || a.Kp[l] % 32 || (l > 0 && a.Kp[l] > WF_NP)) return 0;
-    return a.Klast == a.N[a.nhidden - 1] && a.Fp == a.Kp[0];
+        if (a.N[l] < 1 || a.N[l] > WF_NP || a.Kp[l] % 32 || a.Kp[l] < 32 || (l > 0 && a.Kp[l] > WF_NP)) return 0;
+    return a.Klast == a.N[a.nhidden - 1] && a.Fp == a.Kp[0] && a.x_bf16;
 }
 
 int isk_launch_wide_fwd(const WideFwdArgs& a, hipStream_t st) {
     if (a.S <= 0) return 0;
     if (!isk_wide_fwd_ok(a)) return ISK_EUNSUPPORTED;
     const void* fn;
-#define WFPICK(A_) (a.x_bf16 ? (const void*)wide_fwd_bf16_kernel<A_, true> : (const void*)wide_fwd_bf16_kernel<A_, false>)
+#define WFPICK(A_) ((const void*)wide_fwd_bf16_kernel<A_>)
     switch (a.act) {
         case ISK_ACT_SIGMOID: fn = WFPICK(ISK_ACT_SIGMOID); break;
         case ISK_ACT_TANH: fn = WFPICK(ISK_ACT_TANH); break;

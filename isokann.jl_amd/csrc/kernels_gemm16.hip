@@ -294,7 +294,8 @@ void isk_launch_gather_images(const float* X, int ldx, const int* perm, int B, i
     hipLaunchKernelGGL(gather_images_kernel, grid, dim3(256), 0, st, X, ldx, perm, B, Bp, K, Kp, (u16*)xb, (u16*)xt, ldt);
 }
 
-// Wt_l[n][k] = bf16(W_l[n][k] * scale[k]) for every layer in one launch (forward B operands), W in Flux layout mem [k][n];
+// Wt_l[n][k] = bf16(W_l[n][k] * scale[k]) for every layer in one launch (forward B operands; and / or the same numbers in the
+// fragment-linear order Wf_l the fused wide forward streams), W in Flux layout mem [k][n];
 // scale = the LayerNorm scale for layer 0 (or nullptr).  32 x 32 tiles through LDS; columns k >= K are zero padding.
 __global__ __launch_bounds__(256) void wt_images_kernel(WtImagesArgs a) {
     __shared__ float tile[32][33];
@@ -324,10 +325,17 @@ __global__ __launch_bounds__(256) void wt_images_kernel(WtImagesArgs a) {
     }
     __syncthreads();
     u16* out = (u16*)a.Wt[l];
+    u16* frag = (u16*)a.Wf[l];
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {
         const int n = n0 + r, k = k0 + tx;
-        if (n < N && k < Kp) out[(long long)n * Kp + k] = to_bf16(tile[tx][r]);
+        if (n < N && k < Kp) {
+            const u16 h = to_bf16(tile[tx][r]);
+            if (out) out[(long long)n * Kp + k] = h;
+            // fragment-linear image of the fused wide forward (kernels_fwd_wide.hip): 16-column block n / 16 of 32, step k / 32; lane
+            // (n % 16) + 16 ((k % 32) / 8) holds features k % 8 of its 16 bytes
+            if (frag) frag[((((long long)(k >> 5) * 32 + (n >> 4)) * 64 + ((n & 15) + 16 * ((k & 31) >> 3))) << 3) + (k & 7)] = h;
+        }
     }
 }
 void isk_launch_wt_images(WtImagesArgs& a, hipStream_t st) {

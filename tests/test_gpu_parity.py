@@ -741,6 +741,38 @@ def test_wide_networks_layered_path(gpu_pkg, widths, ln, act, fmode):
     iso.close()
 
 
+@pytest.mark.own_fwd_mode
+@pytest.mark.parametrize("A,F,widths,ln,act,N,K", [
+    (20, 100, [100, 200, 64, 1], False, "sigmoid", 70, 3),        # one ring group of features (<= 128): every wait drains
+    (24, 130, [130, 176, 2], True, "tanh", 90, 5),                # two groups, the second 2 features long; ONE hidden layer; two outputs
+    (40, 300, [300, 200, 136, 1], True, "sigmoid", 1200, 28),     # 263 row blocks on 256 workgroups: the persistent loop's second
+                                                                  #   block (features and weights requested a layer early), a
+                                                                  #   half-filled last block, a short last feature group
+    (60, 700, [700, 512, 300, 500, 1], False, "relu", 150, 4),    # full-width layers, three hidden layers, steady-state ring
+])
+def test_wide_fused_bf16_forward_shapes(gpu_pkg, monkeypatch, A, F, widths, ln, act, N, K):
+    """the fused bf16 forward of wide networks (kernels_fwd_wide.hip; forward_mode 2 on a layered network with pair features):
+    chi and K chi against the fp64 oracle at bf16 accuracy, over the shapes its ring / weight-stream bookkeeping distinguishes"""
+    monkeypatch.delenv("ISK_FWD_MODE", raising=False)
+    pkg = gpu_pkg
+    xs, ys = O.synthetic_coords(A, N, K, seed=F)
+    pairs = O.random_pairs(A, F, seed=F + 1)
+    om = _rand_model(widths, seed=F + 2, ln=ln, act=act)
+    feat = O.FeaturesPairs(pairs)
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_mk_model(pkg, om), minibatch=0, forward_mode=2,
+                  featurize_every_iteration=True)
+    assert iso.get_option("layered") == 1
+    want_chi = om(feat(np.asarray(xs, np.float64)))
+    want_ks = O.expectation(om, feat(np.asarray(ys, np.float64)))
+    scale = max(1.0, np.abs(want_chi).max())
+    chi, ks = pkg.chis(iso), pkg.koopman(iso)
+    assert np.abs(chi - want_chi).max() <= 1e-2 * scale
+    assert np.abs(ks - want_ks).max() <= 1e-2 * scale
+    assert np.abs(chi - want_chi).max() > 1e-7 * scale            # really the bf16 path
+    np.testing.assert_array_equal(pkg.koopman(iso), ks)           # and deterministic
+    iso.close()
+
+
 # --------------------------------------------------------------- TransformPseudoInv (SURVEY 8f rank 4) ----
 @pytest.mark.parametrize("eigenvecs", [False, True])
 def test_pseudoinv_target_and_run_match_oracle(gpu_pkg, eigenvecs):
