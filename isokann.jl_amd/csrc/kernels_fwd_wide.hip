@@ -39,7 +39,7 @@ typedef unsigned short u16;
 #define WF_BM 128
 #define WF_NP 512
 #define WF_ACT_BYTES (WF_BM * WF_NP * 2)                 // 131072
-#define WF_A_SLOT (WF_BM * 256)                          // layer-1 ring slot: 128 rows x 128 bf16 features
+#define WF_A_SLOT (WF_BM * 256)                          // layer-1 feature slot: 128 rows x 128 bf16 features
 #define WF_LDS_BYTES (WF_ACT_BYTES + WF_A_SLOT)          // 163840
 #define WF_WSTEP (32 * 1024)                             // bytes of a layer's fragment-linear image per 32-feature step
 
@@ -69,20 +69,18 @@ __device__ __forceinline__ float wf_act_rt(int act, float z) {
     }
 }
 
-// One LDS-DMA wave-instruction: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to the contiguous KiB at LDS byte
-// address `dst` (lane L lands at dst + 16 L).  Issued as inline assembly ON PURPOSE: hipcc makes every LDS read that follows a
-// __builtin_amdgcn_global_load_lds wait for vmcnt(0) (it cannot know which bytes the DMA writes) -- i.e. for the tile requested
-// a moment ago, which serialises the whole pipeline.  Landing is synchronised by hand (WF_WAIT_VM + barrier below); the "memory"
-// clobber keeps the compiler from carrying LDS contents across the request.
-// (M0 carries the LDS address of an LDS-DMA; nothing else in this kernel uses it -- gfx950 DS instructions do not read M0.)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
-}
-#pragma clang diagnostic pop
+// Why the feature groups are staged through registers (global_load_dwordx4 -> 16 registers -> ds_write_b128) and not moved by
+// LDS-DMA, which the previous versions of this kernel used: hipcc's waitcnt insertion cannot mix the two kinds of request.
+//   * every LDS access it can see behind a __builtin_amdgcn_global_load_lds waits for that DMA (it cannot know which bytes it
+//     writes): the group requested a moment ago;
+//   * with LDS-DMA and ordinary loads in flight together it treats vmcnt as out of order (two event types on one counter) and
+//     waits for vmcnt(0) at every use of a loaded register;
+//   * an LDS-DMA hidden in inline assembly is missing from its arithmetic for the weight loads: the waits come out 4 short and
+//     force a feature group to have landed three steps after its request (measured: 21 % of the kernel);
+//   * hiding the weight loads as well (inline assembly + hand-written waits tied to the ring registers) made the register
+//     allocator spill 800 registers around the tied operands.
+// With plain loads only, every wait in the K-loops is the compiler's own and exact (vmcnt(12..16) / lgkmcnt(4..7) in the listing).
 
-#define WF_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 // diagnostic builds only (timing valid, results not): -DWF_ABLATE=bits -- 1: the feature groups re-read ONE group (cache
 // resident: no HBM stream), 2: every weight step re-reads the layer's first step, 4: no MFMAs (the fragment reads stay),
 // 8: no feature DMA at all, 16: no weight loads after a layer's first four steps
@@ -104,8 +102,8 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
     // whatever depends on the lane index is re-derived where it is used from a copy of it the compiler cannot see through
     // (WF_LANE): hoisted out of the loops, the per-instruction address registers were spilled (300 registers of scratch).
 #define WF_LANE(l_) unsigned l_ = (unsigned)lane; asm volatile("" : "+v"(l_))
-    // ring slot offsets: slot 0 behind the activation image, slots 1 and 2 over its first 64 KiB
-    auto slot_off = [](int s) -> unsigned { return s == 0 ? (unsigned)WF_ACT_BYTES : (unsigned)(s - 1) * WF_A_SLOT; };
+    // two feature slots: slot 0 (even groups) behind the activation image, slot 1 (odd groups) over its first 32 KiB
+    auto slot_off = [](int s) -> unsigned { return s == 0 ? (unsigned)WF_ACT_BYTES : 0u; };
 
     // the weight-fragment ring: set i holds step (4 g + i) of the running layer.  Every image is padded with zero steps to a
     // multiple of FOUR steps, and the stream of (layer, step) pairs a block consumes is continuous: the group that runs a layer's
@@ -119,14 +117,14 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) fw[i][c] = *(const __attribute__((address_space(1))) bf16x8*)(p + w_lane + c * 1024);
     };
-    // feature group g of block `row0` -> ring slot: instruction q moves rows 16 wave + 4 q + lq, physical piece li of a row holding
-    // logical piece li ^ (row & 15) = li ^ (4 q + lq); bytes past the (padded) row re-read its last 16 (their step is never run);
-    // rows past the end re-read the last row (never stored)
-    auto issue_a = [&](long long row0, int g, int slot) {
+    // feature group g of block `row0`: load q takes rows 16 wave + 4 q + lq, 16 bytes per lane -- physical piece li of a row holds
+    // logical piece li ^ (row & 15) = li ^ (4 q + lq), so the image is written linearly (lane L of load q at (16 wave + 4 q) * 256
+    // + 16 L) and read conflict-free.  Bytes past the (padded) row re-read its last 16 (their step multiplies zero weights); rows
+    // past the end re-read the last row (never stored).
+    auto load_a = [&](long long row0, int g, f32x4 (&stage)[4]) {
         if (WF_ABLATE & 8) return;
         const unsigned char* xb = (const unsigned char*)a.X + (size_t)row0 * kbytes1;            // uniform (Fp == Kp[0])
         asm volatile("" : "+s"(xb));
-        const unsigned dst = lds_base + slot_off(slot) + (16 * wave) * 256;
         const int gg = (WF_ABLATE & 1) ? 0 : g;
         const long long left = a.S - 1 - row0;
         const int rmax = left < WF_BM - 1 ? (int)left : WF_BM - 1;
@@ -138,51 +136,69 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
             r = r < rmax ? r : rmax;
             int kb = gg * 256 + ((li_ ^ (4 * q + lq_)) << 4);
             kb = kb < kbytes1 - 16 ? kb : kbytes1 - 16;
-            glds16(xb, (unsigned)(r * kbytes1 + kb), dst + q * 1024);
+            stage[q] = *(const __attribute__((address_space(1))) f32x4*)(xb + (unsigned)(r * kbytes1 + kb));
         }
     };
+    auto store_a = [&](int slot, const f32x4 (&stage)[4]) {
+        if (WF_ABLATE & 8) return;
+        WF_LANE(ln);
+        unsigned char* dst = lds + slot_off(slot) + (16 * wave) * 256 + ln * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f32x4*)(dst + q * 1024) = stage[q];
+    };
+    // raw barrier behind this wave's own LDS stores (a __syncthreads() would also drain vmcnt: the weight ring and the staged group)
+#define WF_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
     f32x4 acc[8][4];
+    // (cleared in front of every K-loop, not behind the epilogues: 128 registers of zeros carried across the last layer left no
+    // room for the staging registers of the next block's first feature group)
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt)
+        for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < 4; ++c) acc[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
 
     // A group of four 32-feature steps.  `abx` = LDS offset of this lane's row (li) of row tile 0 in the group's 256-byte run,
     // with the swizzle bits of step 0 merged in: piece (4 i + lq) ^ li = (4 i) ^ (lq ^ li), so step i is abx ^ 64 i; row tile rt
     // is rt * rstride further.  `wr` = the four steps that follow the ring's contents in the weight stream (this wave's 4 KiB of
-    // each).  The sample fragments of a step are read in two halves of four row tiles, each half one phase ahead of the sixteen
-    // MFMAs that use it (rows 0-63 of step i + 1 are requested before the MFMAs on rows 64-127 of step i): a wave's own LDS
-    // latency hides under its own MFMAs, whatever its SIMD partner is doing.  The scheduling barriers pin exactly this order.
+    // each).  The sample fragments are read in PAIRS of row tiles, double-buffered (2 x 2 x 4 registers: the budget has no room
+    // for a whole step's eight), each pair one phase ahead of the eight MFMAs that use it -- a wave's own LDS latency hides under
+    // its own MFMAs, whatever its SIMD partner is doing.  The scheduling barriers pin exactly this order.
     auto group = [&](auto RS, unsigned abx, const unsigned char* wr) {
         constexpr int rstride = decltype(RS)::value;
-        bf16x8 lo[4], hi[4];
-        auto rd4 = [&](unsigned base, bf16x8 (&f)[4]) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) f[t] = *(const bf16x8*)(lds + base + t * rstride);
+        bf16x8 pa[2], pb[2];
+        auto rd2 = [&](unsigned base, auto RT0, bf16x8 (&f)[2]) {
+            constexpr int rt0 = decltype(RT0)::value;
+            const unsigned b = rt0 < 4 ? base : base + 4u * rstride;      // (the immediate offset of a DS instruction is 16 bits)
+            f[0] = *(const bf16x8*)(lds + b + (rt0 & 3) * rstride);
+            f[1] = *(const bf16x8*)(lds + b + ((rt0 & 3) + 1) * rstride);
         };
-        auto mm16 = [&](bf16x8 (&f)[4], auto RT0, auto I) {
+        auto mm8 = [&](bf16x8 (&f)[2], auto RT0, auto I) {
             constexpr int rt0 = decltype(RT0)::value, i = decltype(I)::value;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (WF_ABLATE & 4) asm volatile("" :: "v"(f[t]), "v"(fw[i][c]));
                     else acc[rt0 + t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i][c], f[t], acc[rt0 + t][c], 0, 0, 0);
                 }
         };
-        rd4(abx, lo);
+#define WF_IC(n_) std::integral_constant<int, n_>{}
+#define WF_SB() __builtin_amdgcn_sched_barrier(0)
+        rd2(abx, WF_IC(0), pa);
 #define WF_STEP(I_)                                                                                                         \
-        rd4((abx ^ (64u * I_)) + 4u * rstride, hi);                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        mm16(lo, std::integral_constant<int, 0>{}, std::integral_constant<int, I_>{});                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        if (I_ < 3) rd4(abx ^ (64u * (I_ + 1)), lo);                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        mm16(hi, std::integral_constant<int, 4>{}, std::integral_constant<int, I_>{});                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        if (!(WF_ABLATE & 16)) load_w(wr + ((WF_ABLATE & 2) ? 0 : I_ * WF_WSTEP), std::integral_constant<int, I_>{});       \
-        __builtin_amdgcn_sched_barrier(0);
+        rd2(abx ^ (64u * I_), WF_IC(2), pb); WF_SB();                                                                       \
+        mm8(pa, WF_IC(0), WF_IC(I_)); WF_SB();                                                                              \
+        rd2(abx ^ (64u * I_), WF_IC(4), pa); WF_SB();                                                                       \
+        mm8(pb, WF_IC(2), WF_IC(I_)); WF_SB();                                                                              \
+        rd2(abx ^ (64u * I_), WF_IC(6), pb); WF_SB();                                                                       \
+        mm8(pa, WF_IC(4), WF_IC(I_)); WF_SB();                                                                              \
+        if (I_ < 3) rd2(abx ^ (64u * (I_ + 1)), WF_IC(0), pa);                                                              \
+        WF_SB();                                                                                                            \
+        mm8(pb, WF_IC(6), WF_IC(I_)); WF_SB();                                                                              \
+        if (!(WF_ABLATE & 16)) load_w(wr + ((WF_ABLATE & 2) ? 0 : I_ * WF_WSTEP), WF_IC(I_));                               \
+        WF_SB();
         WF_STEP(0) WF_STEP(1) WF_STEP(2) WF_STEP(3)
 #undef WF_STEP
     };
@@ -217,69 +233,76 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
                 }
                 const bf16x4 h = __builtin_convertvector(v, bf16x4);
                 *(u32x2*)(lds + off + rt * (16 * WF_NP * 2)) = __builtin_bit_cast(u32x2, h);
-                acc[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        __syncthreads();
+        WF_LDS_BARRIER();
     };
 
     const unsigned char* const wf0 = (const unsigned char*)a.Wt[0] + (size_t)wave * 4096;
     long long blk = blockIdx.x;
     if (blk < nblk) {
-        issue_a(blk * WF_BM, 0, 0);
+        f32x4 stage[4];
+        load_a(blk * WF_BM, 0, stage);
         load_w(wf0, std::integral_constant<int, 0>{});
         load_w(wf0 + WF_WSTEP, std::integral_constant<int, 1>{});
         load_w(wf0 + 2 * WF_WSTEP, std::integral_constant<int, 2>{});
         load_w(wf0 + 3 * WF_WSTEP, std::integral_constant<int, 3>{});
+        store_a(0, stage);
     }
     for (; blk < nblk; blk += gridDim.x) {
         const long long row0 = blk * WF_BM;
         const long long next = blk + gridDim.x;
         // ------------------------------------------------------------------ layer 1 ------------------------------------------
-        if (ng1 > 1) issue_a(row0, 1, 1);
         {
             const unsigned char* wn = a.nhidden > 1 ? (const unsigned char*)a.Wt[1] + (size_t)wave * 4096 : wf0;
-            int slot = 0;
-            for (int g = 0; g < ng1; ++g) {
-                // group g has landed once every wave's share has: this wave's DMA instructions of it are older than everything it
-                // has requested since (vmcnt retires in order) -- 20 instructions before groups 0 and 1 (16 weight fragments + one
-                // feature group), 36 in the steady state (two groups' weight fragments + one feature group), 32 before the last
-                // group (no feature group follows it).  The barrier also says every wave is through group g - 1, whose slot the
-                // next request overwrites.
-                if (ng1 < 3) WF_WAIT_VM(0);
-                else if (g < 2) WF_WAIT_VM(20);
-                else if (g + 1 < ng1) WF_WAIT_VM(36);
-                else WF_WAIT_VM(32);
-                __builtin_amdgcn_s_barrier();
-                if (g + 2 < ng1) issue_a(row0, g + 2, slot == 0 ? 2 : slot - 1);
-                asm volatile("" ::: "memory");
+            // Barrier before group g: every wave's share of group g is in LDS (stored at the end of group g - 1; group 0: a layer
+            // ago / above), and every wave is through group g - 1, whose slot this group's stores (of group g + 1) overwrite.
+            // The last group is peeled: inside the loop the feature loads are unconditional, so the compiler's vmcnt arithmetic
+            // for the weight ring is exact (a conditional request made it assume the smaller count -- its waits then forced the
+            // feature group to have landed three steps after it was requested)
+            zero_acc();
+            int g = 0;
+            for (; g + 1 < ng1; ++g) {
+                WF_LDS_BARRIER();
+                f32x4 stage[4];
+                load_a(row0, g + 1, stage);
                 WF_LANE(ln);
                 const unsigned li_ = ln & 15, lq_ = ln >> 4;
-                const unsigned abx = (slot_off(slot) + li_ * 256u) | ((li_ ^ lq_) << 4);
-                group(std::integral_constant<int, 4096>{}, abx, g + 1 < ng1 ? wf0 + (size_t)(4 * g + 4) * WF_WSTEP : wn);
-                asm volatile("" ::: "memory");
-                slot = slot == 2 ? 0 : slot + 1;
+                const unsigned abx = (slot_off(g & 1) + li_ * 256u) | ((li_ ^ lq_) << 4);
+                group(std::integral_constant<int, 4096>{}, abx, wf0 + (size_t)(4 * g + 4) * WF_WSTEP);
+                store_a((g + 1) & 1, stage);
+            }
+            {
+                WF_LDS_BARRIER();
+                WF_LANE(ln);
+                const unsigned li_ = ln & 15, lq_ = ln >> 4;
+                const unsigned abx = (slot_off(g & 1) + li_ * 256u) | ((li_ ^ lq_) << 4);
+                group(std::integral_constant<int, 4096>{}, abx, wn);
             }
         }
-        __syncthreads();                                     // every wave is through its last reads: the ring is dead
-        // the next block's first feature group, into the slot outside the activation image
-        if (next < nblk) issue_a(next * WF_BM, 0, 0);
+        WF_LDS_BARRIER();                                     // every wave is through its last reads: the ring is dead
         epilogue(0);
         // ------------------------------------------------------------------ hidden layers l > 1: B operand from the activation image
         for (int l = 1; l < a.nhidden; ++l) {
             const unsigned char* wl = (const unsigned char*)a.Wt[l] + (size_t)wave * 4096;
             const unsigned char* wn = l + 1 < a.nhidden ? (const unsigned char*)a.Wt[l + 1] + (size_t)wave * 4096 : wf0;
             const int ng = (a.Kp[l] + 127) >> 7;
+            zero_acc();
             for (int g = 0; g < ng; ++g) {
                 WF_LANE(ln);
                 const unsigned li_ = ln & 15, lq_ = ln >> 4;
                 const unsigned abx = (li_ * (unsigned)(WF_NP * 2) + (unsigned)g * 256u) | ((li_ ^ lq_) << 4);
                 group(std::integral_constant<int, 16 * WF_NP * 2>{}, abx, g + 1 < ng ? wl + (size_t)(4 * g + 4) * WF_WSTEP : wn);
             }
-            __syncthreads();                                 // every wave is through its reads of the activations
+            WF_LDS_BARRIER();                                 // every wave is through its reads of the activations
             epilogue(l);
         }
         // ------------------------------------------------------------------ last layer: nout <= 16 f32 dot products per row
+        // The next block's first feature group is requested in front of it and stored behind it, into the slot outside the
+        // activation image: here the accumulators are dead and the staging registers cost nothing (requested earlier they were
+        // spilled, i.e. waited for at once)
+        f32x4 nstage[4];                                      // (its own registers: nothing is carried here from the K-loops)
+        if (next < nblk) load_a(next * WF_BM, 0, nstage);
         {
             // four threads per row, each takes every fourth 16-byte chunk (8 hidden units) of the row: one ds_read_b128 and two
             // 16-byte weight loads per 8 multiply-adds (element by element this phase took as long as a whole hidden layer's epilogue)
@@ -317,7 +340,8 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
                 }
             }
         }
-        __syncthreads();                                      // the next block's ring slots 1, 2 overwrite the activations
+        if (next < nblk) store_a(0, nstage);
+        WF_LDS_BARRIER();                                      // the next block's feature slot 1 overwrites the activations
     }
 }
 
