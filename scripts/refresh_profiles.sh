@@ -35,3 +35,7 @@ d["mlp_fwd_traffic_bytes_per_launch"] = {"f16x2": d["mlp_fwd_traffic_bytes_per_l
 json.dump(d, open("gpurun_out/ref/${tag}_pmc_summary.json", "w"), indent=1)
 PY
 tail -3 gpurun_out/ref/pmc.txt
+# the same passes on the C5 shard's bf16 path (dominant kernel there: the fused wide forward)
+bash scripts/pmc.sh c5 --workload c5shard --forward-mode 2 --train-bf16 > gpurun_out/ref/pmc_c5.txt 2>&1 || true
+cp gpurun_out/pmc_summary_c5.json gpurun_out/ref/${tag}_pmc_summary_c5.json
+tail -2 gpurun_out/ref/pmc_c5.txt
