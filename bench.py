@@ -294,8 +294,18 @@ def main():
         # HBM bytes per launch of this kernel: NOT measured in this run (PMC counters need rocprofv3 passes of their own) -- the
         # figure of the committed counter summary of the same command, named in `traffic_source`
         traffic, traffic_source = None, None
+        try:
+            wide_fwd = bool(iso.get_option("wide_fwd"))
+        except Exception:
+            wide_fwd = False
         for pmf in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
             try:
+                if wide_fwd and args.workload == "c5shard" and world == 1 and not args.shard_of:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary_c5.json")))
+                    traffic = pm["mlp_fwd_traffic_bytes_per_launch"]
+                    traffic_source = ("profiles/r03_pmc_summary_c5.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this workload on its "
+                                      "bf16 path; not measured in this run)")
+                    break
                 pm = json.load(open(os.path.join(ROOT, "profiles", pmf)))
                 if args.workload == "c3" and not args.cached_features and world == 1 and not args.shard_of:
                     traffic = pm["mlp_fwd_traffic_bytes_per_launch"][{0: "f32", 1: "bf16x3", 2: "bf16", 3: "f16x2"}[args.forward_mode]]
@@ -330,8 +340,14 @@ def main():
                 nmma = 6 if args.forward_mode == 1 else 1
                 exec_flops = (N * K + (N if widths[-1] > 1 else 0)) * (nmma * l1 + (ffwd - 2 * widths[0] * widths[1]))
                 ach = exec_flops / (avg * 1e-3) / 1e12
+                if wide_fwd:
+                    # the fused wide forward runs EVERY layer on the bf16 pipe (hidden widths padded to 512, contractions to whole
+                    # groups of 128 features); priced in the algorithmic flops of the network
+                    exec_flops = fwd_flops
+                    ach = exec_flops / (avg * 1e-3) / 1e12
                 roof = {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": traffic,
-                        "kernel": f"mlp_fwd_bf16x3p_kernel<{nt1},8,{3 if args.forward_mode == 1 else 1},false>",
+                        "kernel": "wide_fwd_bf16_kernel<act>" if wide_fwd else
+                                  f"mlp_fwd_bf16x3p_kernel<{nt1},8,{3 if args.forward_mode == 1 else 1},false>",
                         "dtype": "bf16x3 split (3 bf16 planes per f32 operand, f32 accumulate)" if args.forward_mode == 1 else "bf16 operands, f32 accumulate",
                         "executed_flops_per_launch": exec_flops,
                         "algorithmic": {"flops_per_launch": fwd_flops, "tflops": alg_tf, "vs_f32_mfma_peak_157.3": alg_tf / 157.3}}
@@ -353,7 +369,7 @@ def main():
                                 "runs at 5.4 TB/s (DESIGN.md section 3)"}
             except Exception:
                 pass
-            roof.setdefault("algorithmic_bytes_per_launch", rows * fp * 4)
+            roof.setdefault("algorithmic_bytes_per_launch", rows * fp * (2 if wide_fwd else 4))    # (the fused wide forward reads bf16 rows)
             roof["traffic_source"] = traffic_source
             phases = {k: (v[0] / v[1] if v[1] else None) for k, v in tm.items()}
             per_it = {k: (v[0] / args.profile_steps if v[1] else None) for k, v in tm.items()}
@@ -374,6 +390,8 @@ def main():
                                           "us_per_step": 1e3 * tr_ms / max(1, nb_rows // bl), "TFLOP_per_s": tflops / (tr_ms * 1e-3) / 1e12,
                                           "frac_of_157.3_f32_mfma": tflops / (tr_ms * 1e-3) / 157.3e12,
                                           "allreduce_ms_per_epoch": per_it.get("allreduce")}
+                if args.train_bf16:             # the layered path's GEMMs then run on the bf16 pipe
+                    roof["training_chain"]["frac_of_2500_bf16_mfma"] = tflops / (tr_ms * 1e-3) / 2500e12
     if use_dp:
         dist.barrier()
 
@@ -391,7 +409,8 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": {0: "f32", 3: "f32 (Koopman forward GEMM as split-f16 x2 MFMA, f32 accumulate, f32-equivalent; training f32)",
                       1: "f32 (Koopman forward GEMM as split-bf16 x3 MFMA, f32 accumulate; training f32)",
-                      2: "bf16 (Koopman forward GEMM with bf16 operands, f32 accumulate: REDUCED precision, not the headline; training f32)"}[args.forward_mode],
+                      2: "bf16 (Koopman forward GEMM with bf16 operands, f32 accumulate: REDUCED precision, not the headline; training "
+                         + ("GEMMs with bf16 operands, f32 accumulate, f32 master weights)" if args.train_bf16 else "f32)")}[args.forward_mode],
             "data": "synthetic", "dp_replicas_consistent": dp_consistent,
             "config": {"workload": (("C4 = " if strong and args.workload == "c3" else "") + synth.WORKLOADS[args.workload]["label"]
                                     + (f" -- sharded data-parallel over {parts} GPUs (strong scaling)" if strong and not args.shard_of else "")

@@ -147,7 +147,8 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *   wide_fused          1        wide networks, plain-bf16 forward (forward_mode 2): one fused kernel, activations in LDS
  *   dp_force_coll       0        issue the native collectives on a one-rank communicator (tests)
  *   debug_feat_copy / debug_stamps / debug_rowmod   0   diagnostics
- * Read-only keys of isk_get_option: forward_mode (effective), layered, planes, nparams_engine. */
+ * Read-only keys of isk_get_option: forward_mode (effective), layered, planes, nparams_engine, wide_fwd (1 when the resident
+ * data set runs the fused bf16 forward of wide networks: layered network, forward_mode 2, pair features, option wide_fused). */
 int  isk_set_option(isk_engine* e, const char* key, int64_t value);
 int  isk_get_option(isk_engine* e, const char* key, int64_t* value);
 

@@ -74,5 +74,6 @@ extern "C" int isk_get_option(isk_engine* e, const char* key, int64_t* value) {
     if (!std::strcmp(key, "layered")) { *value = e->layered ? 1 : 0; return ISK_OK; }
     if (!std::strcmp(key, "planes")) { *value = e->planes ? 1 : 0; return ISK_OK; }
     if (!std::strcmp(key, "nparams_engine")) { *value = e->nparams; return ISK_OK; }
+    if (!std::strcmp(key, "wide_fwd")) { *value = e->xh16 ? 1 : 0; return ISK_OK; }              // resident data runs the fused wide forward
     return fail(ISK_EINVAL, std::string("unknown option: ") + key);
 }

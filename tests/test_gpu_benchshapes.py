@@ -225,6 +225,7 @@ def test_c5_network_bf16_path_within_1e2(gpu_pkg, train_bf16, monkeypatch):
     xs, ys, pairs, fx, fy, om = _c5_case(pkg, N, K, 17)
     iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_mk(pkg, om), opt=pkg.AdamRegularized(), minibatch=100,
                   featurize_every_iteration=True, forward_mode=2, options={"train_bf16": train_bf16})
+    assert iso.get_option("wide_fwd") == 1                                 # the fused wide forward is what runs
     want = om(fx)
     scale = max(1.0, np.abs(want).max())
     err = np.abs(pkg.chis(iso) - want).max()

@@ -761,7 +761,7 @@ def test_wide_fused_bf16_forward_shapes(gpu_pkg, monkeypatch, A, F, widths, ln, 
     feat = O.FeaturesPairs(pairs)
     iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_mk_model(pkg, om), minibatch=0, forward_mode=2,
                   featurize_every_iteration=True)
-    assert iso.get_option("layered") == 1
+    assert iso.get_option("layered") == 1 and iso.get_option("wide_fwd") == 1
     want_chi = om(feat(np.asarray(xs, np.float64)))
     want_ks = O.expectation(om, feat(np.asarray(ys, np.float64)))
     scale = max(1.0, np.abs(want_chi).max())
