@@ -83,7 +83,7 @@ __device__ __forceinline__ float wf_act_rt(int act, float z) {
 
 // diagnostic builds only (timing valid, results not): -DWF_ABLATE=bits -- 1: the feature groups re-read ONE group (cache
 // resident: no HBM stream), 2: every weight step re-reads the layer's first step, 4: no MFMAs (the fragment reads stay),
-// 8: no feature DMA at all, 16: no weight loads after a layer's first four steps
+// 8: no feature DMA at all, 16: no weight loads after a layer's first four steps, 32: no activation function (bias only)
 #ifndef WF_ABLATE
 #define WF_ABLATE 0
 #endif
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
             for (int r = 0; r < 4; ++r) {                    // the bias loads together, from clamped addresses (no load behind a branch)
                 const int col = 64 * wave + 16 * c + 4 * lq_ + r;
                 bv[c][r] = bias[col < Nl ? col : Nl - 1];
+                if (ACT == ISK_ACT_SIGMOID) bv[c][r] *= -1.44269504f;      // sigmoid(z + b) = 1 / (1 + 2^(z (-log2 e) + b (-log2 e))): one fma per element
             }
         const unsigned rowoff = (unsigned)(li_ * (WF_NP * 2)) + (unsigned)((lq_ & 1) << 3);
 #pragma unroll
@@ -228,8 +229,13 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
                 f32x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float z = wf_act<ACT>(acc[rt][c][r] + bv[c][r]);
-                    v[r] = (col0 + r < Nl) ? z : 0.f;        // padded columns feed zeros into the next contraction
+                    // (padded columns: the accumulator is exactly 0 -- zero weight rows -- so the value is act(bias), finite, and
+                    // the next layer's image has zero weights for it: no select needed)
+                    if (WF_ABLATE & 32) v[r] = acc[rt][c][r] + bv[c][r];
+                    else if (ACT == ISK_ACT_SIGMOID)
+                        v[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(acc[rt][c][r], -1.44269504f, bv[c][r])));
+                    else
+                        v[r] = wf_act<ACT>(acc[rt][c][r] + bv[c][r]);
                 }
                 const bf16x4 h = __builtin_convertvector(v, bf16x4);
                 *(u32x2*)(lds + off + rt * (16 * WF_NP * 2)) = __builtin_bit_cast(u32x2, h);
