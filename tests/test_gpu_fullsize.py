@@ -106,3 +106,52 @@ def test_c3_runs_are_bit_reproducible(gpu_pkg):
     assert np.all(np.isfinite(out[0][0]))
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.own_fwd_mode
+def test_c5_shard_full_size_bf16_path_properties(gpu_pkg, monkeypatch):
+    """One GPU's shard of C5 at full size (N = 12 500, K = 32, [2000,512,512,512,1], 400 000 Koopman rows = 3125 row blocks of the
+    fused wide forward on 256 workgroups: twelve to thirteen blocks per workgroup) on the bf16 path: oracle spot checks at the
+    path's stated 1e-2, and the size-independent properties of the path -- a row's result does not depend on where it sits
+    (a slice of the data gives bit-identical K chi), repeated evaluation is bit-identical, training lowers the loss"""
+    monkeypatch.delenv("ISK_FWD_MODE", raising=False)
+    pkg = gpu_pkg
+    synth = importlib.import_module("isokann_jl_amd.synth")
+    c = synth.WORKLOADS["c5shard"]
+    N, K = c["N"], c["K"]
+    xs, ys = synth.synthetic_coords(c["atoms"], N, K, seed=0)
+    pairs = synth.random_pairs(c["atoms"], c["feat"], seed=0)
+    model = pkg.densenet(c["widths"], layernorm=False, seed=3)
+    p0 = model.params.copy()
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), opt=pkg.AdamRegularized(), model=model, minibatch=1000,
+                  featurize_every_iteration=True, forward_mode=2, options={"train_bf16": 1})
+    assert iso.get_option("layered") == 1 and iso.get_option("wide_fwd") == 1
+    ks, chi = pkg.koopman(iso), pkg.chis(iso)
+    assert ks.shape == (1, N) and np.all(np.isfinite(ks)) and np.all(np.isfinite(chi))
+    np.testing.assert_array_equal(pkg.koopman(iso), ks)
+    # oracle on a sample of start points (each with its K propagated samples)
+    om = O.glorot_model(c["widths"], np.random.default_rng(0), layernorm=False)
+    om.set_flat(p0.astype(np.float64))
+    ofeat = O.FeaturesPairs(pairs)
+    idx = np.random.default_rng(1).choice(N, size=24, replace=False)
+    want_chi = om(ofeat(np.asarray(xs[:, idx], np.float64)))
+    want_ks = O.expectation(om, ofeat(np.asarray(ys[:, :, idx], np.float64)))
+    scale = max(1.0, np.abs(want_chi).max())
+    assert np.abs(chi[:, idx] - want_chi).max() <= 1e-2 * scale
+    assert np.abs(ks[:, idx] - want_ks).max() <= 1e-2 * scale
+    # slice invariance: start points 5003 .. 5702 on their own (other row blocks, another position inside a block)
+    a, b = 5003, 5703
+    m2 = pkg.densenet(c["widths"], layernorm=False, seed=3)
+    iso2 = pkg.Iso(pkg.SimulationData(xs[:, a:b], ys[:, :, a:b], pkg.FeaturesPairs(pairs)), opt=pkg.AdamRegularized(), model=m2,
+                   minibatch=100, featurize_every_iteration=True, forward_mode=2)
+    assert iso2.get_option("wide_fwd") == 1
+    np.testing.assert_array_equal(pkg.koopman(iso2), ks[:, a:b])
+    np.testing.assert_array_equal(pkg.chis(iso2), chi[:, a:b])
+    iso2.close()
+    # training at the benchmarked batch plan (12 steps of 1000 rows on the bf16 GEMMs)
+    pkg.run(iso, 3)
+    assert len(iso.losses) == 3 and np.all(np.isfinite(iso.losses))
+    assert np.abs(iso.model.get_params() - p0).max() > 0
+    assert np.all(np.isfinite(pkg.chis(iso)))
+    iso.close()
+
