@@ -229,21 +229,25 @@ int bf16_weight_images_alloc(isk_engine* e) {
 
 // the row-major images feed the training GEMMs (rebuilt every optimizer step), the fragment-linear ones the fused forward
 // (rebuilt once per forward after a parameter change)
-void bf16_weight_images_ensure(isk_engine* e, bool want_wt, bool want_wf) {
+static bool weight_image_args(isk_engine* e, bool want_wt, bool want_wf, WtImagesArgs& w) {
     auto& b = e->b16;
     want_wt = want_wt && b.wt_dirty && b.Wt[0];
     want_wf = want_wf && b.wf_dirty && b.Wf[0];
-    if (!want_wt && !want_wf) return;
-    WtImagesArgs w = {};
+    if (!want_wt && !want_wf) return false;
+    w = WtImagesArgs{};
     w.theta = e->d_theta; w.scale0 = e->cfg.layernorm ? e->d_theta + e->off_lns : nullptr; w.nlayers = e->L;
     for (int l = 0; l < e->L; ++l) {
         w.off_W[l] = e->off_W[l]; w.K[l] = e->cfg.widths[l]; w.N[l] = e->cfg.widths[l + 1]; w.Kp[l] = isk_pad32(w.K[l]);
         w.Wt[l] = want_wt ? b.Wt[l] : nullptr;
         w.Wf[l] = want_wf ? b.Wf[l] : nullptr;
     }
-    isk_launch_wt_images(w, e->stream);
     if (want_wt) b.wt_dirty = false;
     if (want_wf) b.wf_dirty = false;
+    return true;
+}
+void bf16_weight_images_ensure(isk_engine* e, bool want_wt, bool want_wf) {
+    WtImagesArgs w;
+    if (weight_image_args(e, want_wt, want_wf, w)) isk_launch_wt_images(w, e->stream);
 }
 
 __global__ void fill_u16_kernel(unsigned short* p, long long n, unsigned short v) {
@@ -285,8 +289,12 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
     const long long ldB = b.rows;                    // row length of the transposed images
     hipStream_t st = e->stream;
     const bool ln = e->cfg.layernorm != 0;
-    isk_launch_gather_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, st);
-    bf16_weight_images_ensure(e, true, false);
+    {
+        // the batch images and (behind an optimizer step: always) the row-major weight images, one launch
+        WtImagesArgs w;
+        if (weight_image_args(e, true, false, w)) isk_launch_prep_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, w, st);
+        else isk_launch_gather_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, st);
+    }
     bool ok = true;
     for (int l = 0; l < L && ok; ++l) {
         const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];

@@ -223,6 +223,9 @@ struct WtImagesArgs {
     int first_block[ISK_MAX_LAYERS];             // filled by the launcher
 };
 void isk_launch_wt_images(WtImagesArgs& a, hipStream_t st);
+// isk_launch_gather_images + isk_launch_wt_images as ONE launch (the head of an optimizer step of the bf16 layered path)
+void isk_launch_prep_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
+                            WtImagesArgs& w, hipStream_t st);
 void isk_launch_loss_delta16(const float* z, int ld, const float* target, const float* lossw, const int* perm, int B, int Bp, int nout,
                              float inv_div, int lastact, void* d16, int ld16, void* dt16, long long ldt, float* loss_slot,
                              const int* rank_err, hipStream_t st);

@@ -252,11 +252,18 @@ int isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st) {
 // batch rows (gathered by perm) -> xb [Bp][Kp] bf16 (A operand of the first layer's forward) and xt [K + 1 (+pad)][Bp] bf16 (its
 // transposed image with the row of ones behind the K features: the first layer's dW + db operand).  One 32 x 32 tile per
 // workgroup through LDS; rows >= B and columns >= K are written as zeros (they are contraction padding).
-__global__ __launch_bounds__(256) void gather_images_kernel(const float* __restrict__ X, int ldx, const int* __restrict__ perm, int B, int Bp,
-                                                            int K, int Kp, u16* __restrict__ xb, u16* __restrict__ xt, long long ldt) {
-    __shared__ float tile[32][33];
-    ISK_LATENCY_CHAIN_PRIO();
-    const int b0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+struct GatherArgs {
+    const float* X; int ldx; const int* perm; int B, Bp, K, Kp; u16* xb; u16* xt; long long ldt;
+    int gx;                                                            // tiles along the batch rows (linear block index = bx + gx * by)
+};
+__device__ __forceinline__ void gather_tile(const GatherArgs& g, const int bx, const int by, float (*tile)[33]) {
+    const float* __restrict__ X = g.X;
+    const int* __restrict__ perm = g.perm;
+    const int B = g.B, Bp = g.Bp, K = g.K, Kp = g.Kp, ldx = g.ldx;
+    u16* __restrict__ xb = g.xb;
+    u16* __restrict__ xt = g.xt;
+    const long long ldt = g.ldt;
+    const int b0 = bx * 32, k0 = by * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 8 row groups
     // the four rows of a thread: indices, then values, requested together from clamped addresses (no load behind a branch: each
     // would be a memory round trip of its own)
@@ -288,19 +295,28 @@ __global__ __launch_bounds__(256) void gather_images_kernel(const float* __restr
         if (k <= K && b < Bp) xt[(long long)k * ldt + b] = to_bf16(tile[tx][r]);
     }
 }
+__global__ __launch_bounds__(256) void gather_images_kernel(GatherArgs g) {
+    __shared__ float tile[32][33];
+    ISK_LATENCY_CHAIN_PRIO();
+    gather_tile(g, blockIdx.x % g.gx, blockIdx.x / g.gx, tile);
+}
+static GatherArgs gather_args(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt, int* nblocks) {
+    GatherArgs g = {X, ldx, perm, B, Bp, K, Kp, (u16*)xb, (u16*)xt, ldt, (Bp + 31) / 32};
+    *nblocks = g.gx * ((K + 1 + 31) / 32);                             // covers k = K (the ones row)
+    return g;
+}
 void isk_launch_gather_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
                               hipStream_t st) {
-    const dim3 grid((Bp + 31) / 32, (K + 1 + 31) / 32);              // covers k = K (the ones row)
-    hipLaunchKernelGGL(gather_images_kernel, grid, dim3(256), 0, st, X, ldx, perm, B, Bp, K, Kp, (u16*)xb, (u16*)xt, ldt);
+    int nb;
+    const GatherArgs g = gather_args(X, ldx, perm, B, Bp, K, Kp, xb, xt, ldt, &nb);
+    hipLaunchKernelGGL(gather_images_kernel, dim3(nb), dim3(256), 0, st, g);
 }
 
 // Wt_l[n][k] = bf16(W_l[n][k] * scale[k]) for every layer in one launch (forward B operands; and / or the same numbers in the
 // fragment-linear order Wf_l the fused wide forward streams), W in Flux layout mem [k][n];
 // scale = the LayerNorm scale for layer 0 (or nullptr).  32 x 32 tiles through LDS; columns k >= K are zero padding.
-__global__ __launch_bounds__(256) void wt_images_kernel(WtImagesArgs a) {
-    __shared__ float tile[32][33];
-    ISK_LATENCY_CHAIN_PRIO();
-    int l = 0, blk = blockIdx.x;
+__device__ __forceinline__ void wt_tile(const WtImagesArgs& a, int blk, float (*tile)[33]) {
+    int l = 0;
     while (l + 1 < a.nlayers && blk >= a.first_block[l + 1]) ++l;
     blk -= a.first_block[l];
     const int K = a.K[l], N = a.N[l], Kp = a.Kp[l];
@@ -338,10 +354,32 @@ __global__ __launch_bounds__(256) void wt_images_kernel(WtImagesArgs a) {
         }
     }
 }
+__global__ __launch_bounds__(256) void wt_images_kernel(WtImagesArgs a) {
+    __shared__ float tile[32][33];
+    ISK_LATENCY_CHAIN_PRIO();
+    wt_tile(a, blockIdx.x, tile);
+}
+// the two image jobs in front of an optimizer step's first product -- the batch rows (independent of the parameters) and the weight
+// images (behind the previous step's update) -- as ONE launch: a step is a chain of dependent launches, each worth ~5 us
+__global__ __launch_bounds__(256) void prep_images_kernel(GatherArgs g, WtImagesArgs w, int ngather) {
+    __shared__ float tile[32][33];
+    ISK_LATENCY_CHAIN_PRIO();
+    const int b = blockIdx.x;
+    if (b < ngather) gather_tile(g, b % g.gx, b / g.gx, tile);
+    else wt_tile(w, b - ngather, tile);
+}
 void isk_launch_wt_images(WtImagesArgs& a, hipStream_t st) {
     int total = 0;
     for (int l = 0; l < a.nlayers; ++l) { a.first_block[l] = total; total += ((a.Kp[l] + 31) / 32) * ((a.N[l] + 31) / 32); }
     hipLaunchKernelGGL(wt_images_kernel, dim3(total), dim3(256), 0, st, a);
+}
+void isk_launch_prep_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
+                            WtImagesArgs& w, hipStream_t st) {
+    int nb;
+    const GatherArgs g = gather_args(X, ldx, perm, B, Bp, K, Kp, xb, xt, ldt, &nb);
+    int total = 0;
+    for (int l = 0; l < w.nlayers; ++l) { w.first_block[l] = total; total += ((w.Kp[l] + 31) / 32) * ((w.N[l] + 31) / 32); }
+    hipLaunchKernelGGL(prep_images_kernel, dim3(nb + total), dim3(256), 0, st, g, w, nb);
 }
 
 // delta_L and the batch loss from the last layer's pre-activations (as loss_delta_kernel of kernels_layered.hip), plus the
