@@ -207,6 +207,7 @@ int  isk_launch_gemm16(const Gemm16Args& a, hipStream_t st);
 struct Gemm16Group {                             // several independent products as ONE launch (kernels_gemm16.hip)
     Gemm16Args g[ISK_G16_MAXGROUP];
     int n, gx[ISK_G16_MAXGROUP], first[ISK_G16_MAXGROUP];
+    int slow[ISK_G16_MAXGROUP];                  // member takes the elementwise operand path (ragged / unaligned shapes)
 };
 int  isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st);
 // gathered batch rows -> xb [Bp][Kp] bf16 and xt [K + 1][ldt] bf16 (row K = ones; columns [B, Bp) zeros)

@@ -202,7 +202,10 @@ __global__ __launch_bounds__(256) void gemm16_group_kernel(Gemm16Group g) {
     int p = 0, b = blockIdx.x;
     while (p + 1 < g.n && b >= g.first[p + 1]) ++p;
     b -= g.first[p];
-    gemm16_tile<false>(g.g[p], b % g.gx[p], b / g.gx[p], red);
+    // (a member with a ragged shape -- the last layer's one-column products -- takes the elementwise operand path: the choice is
+    // uniform per workgroup)
+    if (g.slow[p]) gemm16_tile<true>(g.g[p], b % g.gx[p], b / g.gx[p], red);
+    else gemm16_tile<false>(g.g[p], b % g.gx[p], b / g.gx[p], red);
 }
 
 static bool g16_grid(const Gemm16Args& a, int* gx, int* gy, bool* slow) {
@@ -230,18 +233,13 @@ int isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st) {
     Gemm16Group g;
     g.n = n;
     int total = 0;
-    bool any_slow = false;
     for (int p = 0; p < n; ++p) {
         int gx, gy; bool slow;
         if (!g16_grid(list[p], &gx, &gy, &slow)) return ISK_EINVAL;
-        any_slow |= slow;
-        g.g[p] = list[p]; g.gx[p] = gx; g.first[p] = total;
+        g.g[p] = list[p]; g.gx[p] = gx; g.first[p] = total; g.slow[p] = slow ? 1 : 0;
         total += gx * gy;
     }
-    if (any_slow || n == 1) {                            // the rare ragged shapes: one launch per product
-        for (int p = 0; p < n; ++p) { const int r = isk_launch_gemm16(list[p], st); if (r) return r; }
-        return 0;
-    }
+    if (n == 1) return isk_launch_gemm16(list[0], st);
     void* args[] = {(void*)&g};
     return hipLaunchKernel((const void*)gemm16_group_kernel, dim3(total), dim3(256), args, 0, st) == hipSuccess ? 0 : ISK_EHIP;
 }
