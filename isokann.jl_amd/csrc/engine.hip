@@ -1026,6 +1026,10 @@ void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nsl
 // epoch it skips the refresh and folds once at the end.
 // publish: this is the epoch's LAST step -- it writes the result into mapped pinned host memory (a kernel ends only when its
 // stores are acknowledged: publishing from every step cost ~2 us per step, 0.2 ms per iteration at minibatch = 100)
+// layered path without LayerNorm: rocBLAS and the bf16 GEMMs read theta (or their own images of it), so the forward weight
+// images are folded once, behind the epoch's last step (every epoch driver asks here: the per-step fold is ~38 us at C5)
+bool epoch_lazy_fold(isk_engine* e) { return e->layered && !e->cfg.layernorm && (bf16_train_active(e) || blas_ready(e)); }
+
 void launch_opt(isk_engine* e, float gscale, bool fold, bool capturing, bool publish) {
     OptArgs a;
     a.theta = e->d_theta; a.grad = e->d_grad; a.m = e->d_m; a.v = e->d_v; a.n = e->nparams;
@@ -1047,6 +1051,7 @@ void launch_opt(isk_engine* e, float gscale, bool fold, bool capturing, bool pub
     e->b16.wt_dirty = e->b16.wf_dirty = true;
     if (e->native) { e->wt_dirty = true; e->w16_dirty = true; }      // the training steps read theta; forwards re-fold on demand
     else if (fold) launch_fold(e);
+    else e->wt_dirty = true;                     // a forward folds on demand (ensure_folded)
 }
 
 static int upload_target(isk_engine* e, const float* target) {
@@ -1179,9 +1184,7 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
     e->loss_acc_zeroed = false;
     {
         ScopedTimer t(e, ISK_T_TRAIN);
-        // layered path without LayerNorm: rocBLAS and the bf16 GEMMs read theta (or their own images of it), so the forward
-        // weight images are folded once, behind the epoch's last step
-        const bool lazy_fold = e->layered && !e->cfg.layernorm && (bf16_train_active(e) || blas_ready(e));
+        const bool lazy_fold = epoch_lazy_fold(e);
         if (!train_epoch_graph(e, bs, nb)) {
             for (long long b = 0; b < nb; ++b) {
                 launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, pick_slabs((int)bs));

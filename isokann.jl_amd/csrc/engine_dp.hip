@@ -144,7 +144,7 @@ extern "C" int isk_dp_local_grads(isk_engine* e, int32_t first, int32_t nidx, in
 
 extern "C" int isk_dp_apply(isk_engine* e) {
     if (!e || e->N == 0) return fail(ISK_ESTATE, "no data");
-    launch_opt(e, 1.0f);
+    launch_opt(e, 1.0f, !epoch_lazy_fold(e));     // (the host-driven loop has no "last step": the next forward folds on demand)
     return ISK_OK;
 }
 

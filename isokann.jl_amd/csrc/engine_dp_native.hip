@@ -274,6 +274,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
             e->loss_acc_zeroed = false;
             {
                 ScopedTimer t(e, ISK_T_TRAIN);
+                const bool lazy_fold = epoch_lazy_fold(e);
                 for (int b = 0; b < nbatches; ++b) {
                     ++step_no;
                     if (e->opt.debug_inject_rank_error > 0 && step_no == e->opt.debug_inject_rank_error)
@@ -285,7 +286,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
                         // a collective this rank could not even enqueue: the peers are lost anyway, say why and stop
                         if (r != ncclSuccess) { (void)dp_clear_poison(e); return fail(ISK_EHIP, std::string("rccl: ") + g_rccl.GetErrorString(r)); }
                     }
-                    launch_opt(e, 1.0f, true, false, b == nbatches - 1);
+                    launch_opt(e, 1.0f, !lazy_fold || b == nbatches - 1, false, b == nbatches - 1);
                 }
             }
             double* acc = e->h_res;          // published by the last opt_step (mapped pinned memory)
