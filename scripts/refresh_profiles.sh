@@ -16,6 +16,8 @@ b c5shard --workload c5shard --no-cpu-baseline
 b c5shard_f32fwd --workload c5shard --forward-mode 0 --no-cpu-baseline
 b c5shard_bf16fwd --workload c5shard --forward-mode 2 --no-cpu-baseline
 b c5shard_bf16 --workload c5shard --forward-mode 2 --train-bf16 --no-cpu-baseline          # the arithmetic BASELINE names for C5: forward AND training GEMMs on bf16
+# the same through the native data-parallel driver with every collective on a one-rank communicator: what ONE of C5's 8 ranks runs
+ISK_DP_FORCE_COLL=1 b c5shard_bf16_dp1 --workload c5shard --forward-mode 2 --train-bf16 --force-dp --no-cpu-baseline
 b c3_bf16fwd --forward-mode 2 --no-cpu-baseline
 # one rank's share of the 8-way strong-scaled runs (C4: N = 1250, local batch 125; collectives on a one-rank communicator)
 b c4_shard_of_8 --shard-of 8 --no-cpu-baseline
