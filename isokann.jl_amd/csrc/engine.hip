@@ -770,6 +770,7 @@ extern "C" int isk_data_shape(isk_engine* e, int64_t* D, int64_t* K, int64_t* N)
 // fused networks: refresh the bf16 weight planes now (launch_forward would do it lazily, i.e. behind whatever the
 // stream is about to wait for)
 void fold_ahead(isk_engine* e) {
+    if (e->layered && e->xh16) { bf16_weight_images_ensure(e, false, true); return; }     // the fused wide forward's own images
     ensure_folded(e);
     const int planes = bf16_planes(e);
     if (e->layered || !(planes || e->planes) || !e->w16_dirty) return;
@@ -779,8 +780,8 @@ void fold_ahead(isk_engine* e) {
 }
 // the forward over feature rows: f32 MFMA or split-bf16 (cfg.forward_mode)
 int launch_forward(isk_engine* e, const MlpFwdArgs& f) {
+    if (e->layered && e->xh16) return forward_layered(e, f.X, f.S, f.out, nullptr, nullptr);     // fused wide kernel: no activation buffers, its own weight images
     ensure_folded(e);
-    if (e->layered && e->xh16) return forward_layered(e, f.X, f.S, f.out, nullptr, nullptr);     // fused wide kernel: no activation buffers
     if (e->layered) {
         float *a = e->d_actA, *b = e->d_actB;
         TmpBuf ta, tb;
@@ -1029,6 +1030,9 @@ void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nsl
 // layered path without LayerNorm: rocBLAS and the bf16 GEMMs read theta (or their own images of it), so the forward weight
 // images are folded once, behind the epoch's last step (every epoch driver asks here: the per-step fold is ~38 us at C5)
 bool epoch_lazy_fold(isk_engine* e) { return e->layered && !e->cfg.layernorm && (bf16_train_active(e) || blas_ready(e)); }
+// ... and not at all where nothing reads them: the fused wide forward streams its own fragment-linear images of theta and the bf16
+// GEMMs theirs (a forward of foreign rows through the generic layered kernels folds on demand: wt_dirty stays set)
+bool epoch_no_fold(isk_engine* e) { return epoch_lazy_fold(e) && e->xh16 && bf16_train_active(e); }
 
 void launch_opt(isk_engine* e, float gscale, bool fold, bool capturing, bool publish) {
     OptArgs a;
@@ -1188,7 +1192,7 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
         if (!train_epoch_graph(e, bs, nb)) {
             for (long long b = 0; b < nb; ++b) {
                 launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, pick_slabs((int)bs));
-                launch_opt(e, 1.0f, !lazy_fold || b == nb - 1, false, b == nb - 1);
+                launch_opt(e, 1.0f, !lazy_fold || (b == nb - 1 && !epoch_no_fold(e)), false, b == nb - 1);
             }
         }
     }

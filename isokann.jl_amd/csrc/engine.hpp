@@ -233,6 +233,7 @@ bool prepare_dev_bt(isk_engine* e);
 void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nslab = 1, bool step = true, bool capturing = false);
 void launch_opt(isk_engine* e, float gscale, bool fold = true, bool capturing = false, bool publish = true);
 bool epoch_lazy_fold(isk_engine* e);             // the forward weight images may wait for the epoch's last optimizer step
+bool epoch_no_fold(isk_engine* e);               // ... or for a forward that actually reads them
 int stage_perm_ahead(isk_engine* e, const int32_t* perm);
 void engine_options_init(isk_engine* e);                 // defaults, then ISK_<KEY> of the creating process
 // ---- engine_layered.hip ----------------------------------------------------------------

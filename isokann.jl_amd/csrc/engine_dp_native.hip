@@ -286,7 +286,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
                         // a collective this rank could not even enqueue: the peers are lost anyway, say why and stop
                         if (r != ncclSuccess) { (void)dp_clear_poison(e); return fail(ISK_EHIP, std::string("rccl: ") + g_rccl.GetErrorString(r)); }
                     }
-                    launch_opt(e, 1.0f, !lazy_fold || b == nbatches - 1, false, b == nbatches - 1);
+                    launch_opt(e, 1.0f, !lazy_fold || (b == nbatches - 1 && !epoch_no_fold(e)), false, b == nbatches - 1);
                 }
             }
             double* acc = e->h_res;          // published by the last opt_step (mapped pinned memory)
