@@ -31,9 +31,10 @@ def _problem(nout):
     A, F, N, K = 14, 40, 192, 3
     xs, ys = O.synthetic_coords(A, N, K, seed=90 + nout)
     pairs = O.random_pairs(A, F, seed=91)
-    widths = O.pairnet_widths(F, layers=3, nout=nout)
+    wide = bool(os.environ.get("ISK_TEST_WIDE"))          # a layered (wide) network on its bf16 path: see _mk_iso
+    widths = [F, 192, 64, nout] if wide else O.pairnet_widths(F, layers=3, nout=nout)
     rng = np.random.default_rng(92)
-    om = O.glorot_model(widths, rng, layernorm=True)
+    om = O.glorot_model(widths, rng, layernorm=not wide)
     for b in om.b:
         b[...] = 0.1 * rng.normal(size=b.shape)
     return xs, ys, pairs, widths, om.get_flat().astype(np.float32)
@@ -43,12 +44,15 @@ LR = 1e-2
 
 
 def _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, minibatch, every_iter=False, opt="adam"):
-    model = pkg.densenet(widths, layernorm=True)
+    wide = bool(os.environ.get("ISK_TEST_WIDE"))
+    model = pkg.densenet(widths, layernorm=not wide)
     model.params = theta
     tr = pkg.TransformShiftscale() if nout == 1 else pkg.TransformISA()
     popt = pkg.AdamRegularized(LR, 1e-3) if opt == "adam" else pkg.NesterovRegularized(LR, 1e-3)
+    # wide: first hidden width > 160 -> layered path; forward_mode 2 + train_bf16 = the fused bf16 forward and the bf16 training GEMMs
+    kw = dict(forward_mode=2, options={"train_bf16": 1}) if wide else {}
     return pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=model, opt=popt,
-                   target=tr, minibatch=minibatch, featurize_every_iteration=every_iter)
+                   target=tr, minibatch=minibatch, featurize_every_iteration=every_iter, **kw)
 
 
 def _worker(rank, world, port, nout, minibatch, niter, outdir, opt):

@@ -90,6 +90,15 @@ def test_native_driver_two_ranks_every_forward_mode(gpu_pkg, mock_lib, fwd_mode)
     test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, 3, 16, 1, True, "adam")
 
 
+def test_native_driver_two_ranks_wide_network_on_its_bf16_path(gpu_pkg, mock_lib, monkeypatch):
+    """C5's kind of network through the native driver: a layered network ([40,192,64,1], no LayerNorm) with the fused bf16 forward,
+    the featurizer writing bf16 rows inside every iteration and the bf16 training GEMMs (weight images rebuilt per step, f32
+    forward images not folded at all): two ranks through the mock RCCL against the single process on the full data"""
+    monkeypatch.setenv("ISK_TEST_WIDE", "1")
+    monkeypatch.delenv("ISK_FWD_MODE", raising=False)
+    test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, 1, 32, 2, True, "nesterov")
+
+
 @pytest.mark.parametrize("nout,minibatch,epochs,every_iter,opt", [(1, 64, 1, False, "adam"), (3, 64, 1, False, "adam"), (3, 0, 1, False, "adam"),
                                                                  (3, 48, 2, False, "adam"), (1, 16, 2, True, "adam"),
                                                                  (3, 48, 2, False, "nesterov"), (1, 16, 1, True, "nesterov")])
@@ -117,6 +126,8 @@ def test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, nout, m
         gperms.append(np.concatenate([head, np.setdiff1d(np.arange(N), head)]))
     mk = lambda: _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, gb if minibatch else 0, every_iter, opt=opt)      # noqa: E731
     ref = mk()
+    if os.environ.get("ISK_TEST_WIDE"):
+        assert ref.get_option("layered") == 1 and ref.get_option("wide_fwd") == 1 and ref.get_option("train_bf16") == 1
     pkg.run(ref, niter, epochs, perms=np.stack(gperms))
     np.testing.assert_allclose(r[0]["losses"], ref.losses, rtol=2e-4)
     want = ref.model.get_params()
