@@ -118,9 +118,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1000)
     ap.add_argument("--profile-steps", type=int, default=5)
-    ap.add_argument("--forward-mode", type=int, default=3, choices=[0, 1, 2, 3],
+    ap.add_argument("--forward-mode", type=int, default=None, choices=[0, 1, 2, 3],
                     help="0 = f32 MFMA forward, 1 = split-bf16 (bf16x3, f32-equivalent), 2 = plain bf16 operands (reduced precision), "
-                         "3 = split-f16 (f16x2, f32-equivalent; planes written by the featurizer)")
+                         "3 = split-f16 (f16x2, f32-equivalent; planes written by the featurizer).  Default: 3; for --workload c5shard 2 "
+                         "(BASELINE.json names the bf16 MFMA path for C5)")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel driver even with one rank (rehearsal)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="multi-GPU: strong = the workload's global N and global minibatch sharded over the ranks (C4); weak = a full "
@@ -128,8 +129,15 @@ def main():
     ap.add_argument("--shard-of", type=int, default=0, metavar="P",
                     help="one GPU: run ONE rank's share of the P-way strong-scaled run (N/P starts, local batch minibatch/P, collectives "
                          "on a one-rank communicator)")
-    ap.add_argument("--train-bf16", action="store_true", help="wide networks (c5shard): training GEMMs on bf16 operands, f32 accumulate")
+    ap.add_argument("--train-bf16", action=argparse.BooleanOptionalAction, default=None,
+                    help="wide networks (c5shard): training GEMMs on bf16 operands, f32 accumulate, f32 master weights.  Default: on for "
+                         "--workload c5shard on its bf16 path (forward mode 2), off otherwise")
     args = ap.parse_args()
+    # C5 is specified on the bf16 MFMA path (BASELINE.json configs[4]); every other workload on the f32-equivalent arithmetic
+    if args.forward_mode is None:
+        args.forward_mode = 2 if args.workload == "c5shard" else 3
+    if args.train_bf16 is None:
+        args.train_bf16 = args.workload == "c5shard" and args.forward_mode == 2
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -409,7 +417,9 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": {0: "f32", 3: "f32 (Koopman forward GEMM as split-f16 x2 MFMA, f32 accumulate, f32-equivalent; training f32)",
                       1: "f32 (Koopman forward GEMM as split-bf16 x3 MFMA, f32 accumulate; training f32)",
-                      2: "bf16 (Koopman forward GEMM with bf16 operands, f32 accumulate: REDUCED precision, not the headline; training "
+                      2: "bf16 (Koopman forward GEMM with bf16 operands, f32 accumulate: "
+                         + ("the arithmetic BASELINE.json names for C5, outputs ~1e-2 of f32; training " if args.workload == "c5shard"
+                            else "REDUCED precision, not the headline; training ")
                          + ("GEMMs with bf16 operands, f32 accumulate, f32 master weights)" if args.train_bf16 else "f32)")}[args.forward_mode],
             "data": "synthetic", "dp_replicas_consistent": dp_consistent,
             "config": {"workload": (("C4 = " if strong and args.workload == "c3" else "") + synth.WORKLOADS[args.workload]["label"]

@@ -12,9 +12,9 @@ b c3_cached --cached-features
 b c3_mb0 --minibatch 0
 b c3_mb100_nesterov --minibatch 100 --opt nesterov
 b c2 --workload c2
-b c5shard --workload c5shard --no-cpu-baseline
+b c5shard --workload c5shard --forward-mode 1 --no-cpu-baseline                               # split-bf16 forward (f32-equivalent), f32 training
 b c5shard_f32fwd --workload c5shard --forward-mode 0 --no-cpu-baseline
-b c5shard_bf16fwd --workload c5shard --forward-mode 2 --no-cpu-baseline
+b c5shard_bf16fwd --workload c5shard --forward-mode 2 --no-train-bf16 --no-cpu-baseline      # fused bf16 forward, f32 training (rocBLAS)
 b c5shard_bf16 --workload c5shard --forward-mode 2 --train-bf16 --no-cpu-baseline          # the arithmetic BASELINE names for C5: forward AND training GEMMs on bf16
 # the same through the native data-parallel driver with every collective on a one-rank communicator: what ONE of C5's 8 ranks runs
 ISK_DP_FORCE_COLL=1 b c5shard_bf16_dp1 --workload c5shard --forward-mode 2 --train-bf16 --force-dp --no-cpu-baseline
