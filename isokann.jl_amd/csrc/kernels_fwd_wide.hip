@@ -14,17 +14,20 @@
 //             is staged or re-read through LDS, and no barrier guards them: with the 64 x 128 wave tiles of the previous
 //             kernel the W fragments were two thirds of the LDS traffic (96 KiB read + 40 KiB written per 32-feature step
 //             against 1024 matrix-pipe clocks: the LDS port was as busy as the matrix pipe).
-//   layer 1   the feature rows (bf16, as the featurizer writes them for this path: FeatArgs.out_bf16) go global -> LDS by
-//             LDS-DMA, 128 rows x 128 features (32 KiB) per ring slot, three slots, two groups ahead, ONE barrier per 128
-//             features.  A DMA instruction moves 4 rows x 256 contiguous bytes; the 16-byte pieces of a row are XOR-swizzled
-//             with row & 15 through the SOURCE addresses, so the fragment reads are conflict-free.
+//   layer 1   the feature rows (bf16, as the featurizer writes them for this path: FeatArgs.out_bf16) in groups of 128
+//             features: 128 rows x 256 bytes = 32 KiB per slot, two slots, ONE group ahead, ONE raw barrier per group.  A
+//             thread requests its 4 x 16 bytes of group g + 1 with plain global_load_dwordx4 at the top of group g and
+//             stores them (ds_write_b128) at its end -- registers, not LDS-DMA: see the note in front of the kernel.  A load
+//             instruction covers 4 rows x 256 contiguous bytes; the 16-byte pieces of a row are XOR-swizzled with row & 15
+//             through the SOURCE addresses, so the image is written linearly and the fragment reads are conflict-free.
 //   layer l>1 B operand = the previous layer's activations, resident in LDS as bf16 [128][512] (16-byte chunks XORed with
 //             row & 15); NO barrier inside the K-loop (waves drift apart: one wave's LDS reads run under its SIMD partner's
 //             MFMAs); the outputs stay in registers until every wave has finished reading, then overwrite the activations.
 //   last      nout <= 16 outputs per row: plain f32 dot products against the f32 weights, four lanes per row.
-//   next block: its first feature group is requested into the ring slot that lies outside the activation image as soon as
-//             layer 1 is done, its first weight fragments before the last layer -- the block boundary exposes no round trip.
-// LDS: [activations 128 KiB | ring slot 0 32 KiB]; ring slots 1, 2 alias the first 64 KiB of the activation image (dead
+//   next block: its first feature group is requested in front of the last layer and stored behind it, into the slot that
+//             lies outside the activation image; its first weight fragments are requested by the last hidden layer's final
+//             steps (the weight stream is continuous) -- the block boundary exposes no round trip.
+// LDS: [activations 128 KiB | feature slot 0 32 KiB]; feature slot 1 aliases the first 32 KiB of the activation image (dead
 // while layer 1 runs).
 #include <type_traits>
 
@@ -34,7 +37,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short u16;
 
 #define WF_BM 128
 #define WF_NP 512
