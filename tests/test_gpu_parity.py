@@ -770,6 +770,13 @@ def test_wide_fused_bf16_forward_shapes(gpu_pkg, monkeypatch, A, F, widths, ln, 
     assert np.abs(ks - want_ks).max() <= 1e-2 * scale
     assert np.abs(chi - want_chi).max() > 1e-7 * scale            # really the bf16 path
     np.testing.assert_array_equal(pkg.koopman(iso), ks)           # and deterministic
+    # the evaluation callers on foreign rows take the same kernel: features handed over by the host (isk_forward: the engine's
+    # standardisation writes bf16 rows for them too) and coordinates (isk_chicoords)
+    n = min(N, 50)
+    fx32 = np.asarray(feat(np.asarray(xs[:, :n], np.float64)), np.float32)
+    assert np.abs(iso.model(fx32) - want_chi[:, :n]).max() <= 1e-2 * scale
+    sub = pkg.chicoords(iso, ys[:, :, :n])
+    assert np.abs(sub.mean(axis=1) - want_ks[:, :n]).max() <= 1e-2 * scale
     iso.close()
 
 
