@@ -350,6 +350,7 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
 void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float inv_div) {
     if (bf16_train_active(e) && launch_grads_layered_bf16(e, d_idx, B, inv_div)) return;
     if (launch_grads_layered_blas(e, d_idx, B, inv_div)) return;
+    ensure_folded(e);                // the in-house kernels read the f32 weight images (an epoch on the bf16 GEMMs leaves them unfolded)
     const int L = e->L;
     const long long Bpad = ((B + 15) / 16) * 16;
     const float* xs = e->d_xs32;

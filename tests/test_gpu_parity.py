@@ -780,6 +780,42 @@ def test_wide_fused_bf16_forward_shapes(gpu_pkg, monkeypatch, A, F, widths, ln, 
     iso.close()
 
 
+@pytest.mark.own_fwd_mode
+def test_wide_network_switching_the_training_arithmetic_mid_run(gpu_pkg, monkeypatch):
+    """An engine on the fused bf16 forward + bf16 training GEMMs does not fold the f32 weight images nobody reads; switching the
+    option back to the in-house f32 training kernels (which do read them) must see the CURRENT weights: gradients of the two
+    arithmetics on the same parameters agree at bf16 accuracy after the parameters have moved a long way"""
+    monkeypatch.delenv("ISK_FWD_MODE", raising=False)
+    pkg = gpu_pkg
+    A, F, N, K = 20, 100, 256, 3
+    xs, ys = O.synthetic_coords(A, N, K, seed=5)
+    pairs = O.random_pairs(A, F, seed=6)
+    om = _rand_model([F, 200, 64, 1], seed=7, ln=False)
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_mk_model(pkg, om), opt=pkg.AdamRegularized(5e-2, 1e-4),
+                  minibatch=64, forward_mode=2, featurize_every_iteration=True, options={"train_bf16": 1})
+    assert iso.get_option("wide_fwd") == 1
+    p0 = iso.model.get_params()
+    rng = np.random.default_rng(3)
+    tgt = np.asarray(rng.uniform(size=(1, N)), np.float32)
+    for _ in range(3):
+        pkg.train_batch(iso, tgt, perm=rng.permutation(N))
+    assert np.abs(iso.model.get_params() - p0).max() > 0.1            # 12 Adam steps at lr 5e-2
+    idx = rng.permutation(N)[:96]
+    g16, l16 = pkg.batch_grads(iso, tgt, idx)
+    iso.set_option("train_bf16", 0)
+    iso.set_option("layered_blas", 0)                                 # the in-house f32 kernels: they read the folded images
+    g32, l32 = pkg.batch_grads(iso, tgt, idx)
+    assert abs(l16 - l32) <= 2e-2 * abs(l32)
+    assert np.abs(g16 - g32).max() <= 3e-2 * np.abs(g32).max()
+    om2 = _rand_model([F, 200, 64, 1], seed=7, ln=False)
+    om2.set_flat(iso.model.get_params().astype(np.float64))
+    fx = O.FeaturesPairs(pairs)(np.asarray(xs, np.float64))
+    lo, go, _ = O.batch_loss_and_grads(om2, fx[:, idx], tgt[:, idx].astype(np.float64), np.ones(1))
+    gflat = np.concatenate([a.reshape(-1, order="F") for a in go])
+    np.testing.assert_allclose(g32, gflat, atol=5e-5 * np.abs(gflat).max(), rtol=2e-4)
+    iso.close()
+
+
 # --------------------------------------------------------------- TransformPseudoInv (SURVEY 8f rank 4) ----
 @pytest.mark.parametrize("eigenvecs", [False, True])
 def test_pseudoinv_target_and_run_match_oracle(gpu_pkg, eigenvecs):
