@@ -780,7 +780,10 @@ void fold_ahead(isk_engine* e) {
 }
 // the forward over feature rows: f32 MFMA or split-bf16 (cfg.forward_mode)
 int launch_forward(isk_engine* e, const MlpFwdArgs& f) {
-    if (e->layered && e->xh16) return forward_layered(e, f.X, f.S, f.out, nullptr, nullptr);     // fused wide kernel: no activation buffers, its own weight images
+    if (e->layered && e->xh16) {                 // fused wide kernel: no activation buffers, its own weight images of theta
+        if (e->cfg.layernorm) ensure_folded(e);  //   (with LayerNorm its first bias is the folded one)
+        return forward_layered(e, f.X, f.S, f.out, nullptr, nullptr);
+    }
     ensure_folded(e);
     if (e->layered) {
         float *a = e->d_actA, *b = e->d_actB;

@@ -141,6 +141,7 @@ extern "C" int isk_chicoords_pullback(isk_engine* e, const float* coords, int64_
     if (e->Fp > 2048 || D > 2048) return fail(ISK_EUNSUPPORTED, "pullback covers <= 2048 features / coordinates per sample");
     const int H1p = isk_pad16(e->cfg.widths[1]);
     const TrainShape ts = train_shape(e);
+    if (e->layered) ensure_folded(e);            // the layer-by-layer pullback reads the f32 weight images (forward and transposed)
     const int64_t CH = 16384;
     for (int64_t c0 = 0; c0 < ncols; c0 += CH) {
         const int64_t n = std::min<int64_t>(CH, ncols - c0);

@@ -800,6 +800,19 @@ def test_wide_network_switching_the_training_arithmetic_mid_run(gpu_pkg, monkeyp
     for _ in range(3):
         pkg.train_batch(iso, tgt, perm=rng.permutation(N))
     assert np.abs(iso.model.get_params() - p0).max() > 0.1            # 12 Adam steps at lr 5e-2
+    # d chi / d coords runs layer by layer on the f32 images as well
+    om_now = _rand_model([F, 200, 64, 1], seed=7, ln=False)
+    om_now.set_flat(iso.model.get_params().astype(np.float64))
+    cot = rng.normal(size=(1, 8))
+    got = pkg.chicoords_pullback(iso, xs[:, :8], cot)
+    import torch
+    x32 = np.asarray(xs[:, :8], np.float32).astype(np.float64)
+    want = np.zeros_like(x32)
+    for n in range(8):
+        xt = torch.tensor(x32[:, n], requires_grad=True)
+        (_torch_chi_of_coords(om_now, pairs, xt) * torch.tensor(cot[:, n])).sum().backward()
+        want[:, n] = xt.grad.numpy()
+    np.testing.assert_allclose(got, want, atol=5e-5 * np.abs(want).max(), rtol=5e-4)
     idx = rng.permutation(N)[:96]
     g16, l16 = pkg.batch_grads(iso, tgt, idx)
     iso.set_option("train_bf16", 0)
