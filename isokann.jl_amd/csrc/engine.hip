@@ -539,7 +539,7 @@ FeatArgs feat_args(const isk_engine* e) {
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
     a.bg_wg_per_cu = e->opt.feat_wg_per_cu; a.bg_wgs_total = e->opt.feat_bg_wgs; a.bg_pf = e->opt.feat_pf;
     a.dbg_copy = e->opt.debug_feat_copy;
-    a.out_bf16 = e->xh16;
+    a.out_bf16 = e->xh16; a.ld16 = isk_ld16(e->Fp);
     return a;
 }
 
@@ -553,7 +553,7 @@ static void featurize_rows(isk_engine* e, const float* in, long long S, float* x
     a.background = (st != nullptr) ? bg_wgs : 0;       // 1: the default throttle; > 1: that many workgroups in total
     a.planes = xscale != nullptr;
     if (a.planes) { a.xhat = xhat; a.row0 = row0; a.xscale = xscale + row0; }
-    else if (e->xh16) a.xhat = (float*)((unsigned short*)xhat + row0 * e->Fp);      // bf16 rows
+    else if (e->xh16) a.xhat = (float*)((unsigned short*)xhat + row0 * isk_ld16(e->Fp));      // bf16 rows
     else a.xhat = xhat + row0 * e->Fp;
     a.xhat32 = xs32; a.x32_first = x32_first;
     isk_launch_featurize(a, st ? st : e->stream);
@@ -837,7 +837,7 @@ int forward_resident(isk_engine* e, int which, bool ahead) {
     int tid = ISK_T_FWD_YS;
     if (which == 1) S = nys;
     if (which == 2) {
-        if (e->xh16) X = (const float*)((const unsigned short*)X + nys * e->Fp);      // bf16 rows
+        if (e->xh16) X = (const float*)((const unsigned short*)X + nys * isk_ld16(e->Fp));      // bf16 rows
         else if (!e->planes) X += nys * e->Fp;
         out += nys * e->nout; S = e->N; tid = ISK_T_FWD_XS;
     }

@@ -37,7 +37,7 @@ static int forward_cols(isk_engine* e, const float* host_in, int64_t rowlen, int
     a.D = (int)rowlen; a.F = e->F; a.Fp = e->Fp;
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps;
     a.background = 0;
-    a.planes = e->planes; a.xscale = (float*)xsc.p; a.out_bf16 = e->xh16;
+    a.planes = e->planes; a.xscale = (float*)xsc.p; a.out_bf16 = e->xh16; a.ld16 = isk_ld16(e->Fp);
     isk_launch_featurize(a, e->stream);
     MlpFwdArgs f = fwd_args(e, (const float*)xh.p, ncols, (float*)o.p);
     f.xscale = (const float*)xsc.p;
@@ -79,7 +79,7 @@ static int koopman_cols(isk_engine* e, const float* ys, int64_t D, int64_t K, in
     a.in = (const float*)in.p; a.pairs = is_coords ? e->d_pairs : nullptr; a.packed_pairs = is_coords ? e->d_packed : nullptr;
     a.xhat = (float*)xh.p; a.S = S; a.D = (int)D; a.F = e->F; a.Fp = e->Fp;
     a.normalize = e->cfg.layernorm; a.ln_mode = e->cfg.ln_mode; a.eps = e->cfg.ln_eps; a.background = 0;
-    a.planes = e->planes; a.xscale = (float*)xsc.p; a.out_bf16 = e->xh16;
+    a.planes = e->planes; a.xscale = (float*)xsc.p; a.out_bf16 = e->xh16; a.ld16 = isk_ld16(e->Fp);
     isk_launch_featurize(a, e->stream);
     MlpFwdArgs f = fwd_args(e, (const float*)xh.p, S, (float*)o.p);
     f.xscale = (const float*)xsc.p;

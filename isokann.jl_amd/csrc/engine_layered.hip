@@ -11,7 +11,7 @@ int bf16_planes(const isk_engine* e) { return e->cfg.forward_mode == 1 ? 3 : (e-
 static void wide_args_shape(const isk_engine* e, WideFwdArgs& a) {
     a.Fp = e->Fp; a.nhidden = e->L - 1;
     for (int l = 0; l + 1 < e->L; ++l) { a.N[l] = e->cfg.widths[l + 1]; a.Kp[l] = isk_pad32(e->cfg.widths[l]); }
-    a.Klast = e->cfg.widths[e->L - 1]; a.nout = e->nout; a.x_bf16 = 1;
+    a.Klast = e->cfg.widths[e->L - 1]; a.nout = e->nout; a.x_bf16 = 1; a.ldx = isk_ld16(e->Fp);
 }
 bool wide_forward_shape_ok(const isk_engine* e) {
     WideFwdArgs a = {};
@@ -24,7 +24,7 @@ bool wide_forward_shape_ok(const isk_engine* e) {
 // plain-bf16 forward (forward_mode 2) of a network whose hidden layers are <= 512 wide: ONE fused kernel, activations in LDS
 static int forward_wide_bf16(isk_engine* e, const float* X, long long S, float* out) {
     WideFwdArgs a = {};
-    a.X = X; a.x_bf16 = e->xh16; a.S = S; a.Fp = e->Fp; a.nhidden = e->L - 1;
+    a.X = X; a.x_bf16 = e->xh16; a.S = S; a.Fp = e->Fp; a.ldx = isk_ld16(e->Fp); a.nhidden = e->L - 1;
     for (int l = 0; l + 1 < e->L; ++l) {
         a.N[l] = e->cfg.widths[l + 1]; a.Kp[l] = isk_pad32(e->cfg.widths[l]); a.Wt[l] = e->b16.Wf[l];
         a.bias[l] = (l == 0 && e->cfg.layernorm) ? e->d_bias[0] : e->d_theta + e->off_b[l];

@@ -61,7 +61,8 @@ struct FeatArgs {
     float* stats;           // optional [S][2]: mean, 1/denominator of the LayerNorm standardisation
     // split-f16 output (forward_mode 3; register featurizer only, see isk_featurize_reg_ok): xhat rows are written as
     // [Fp/32 chunks][32 x f16 hi | 32 x f16 lo] of xhat * 2^s (same 4*Fp bytes per row), 2^-s goes to xscale[row]
-    int out_bf16;           // xhat rows are written as bf16 [S][Fp] (2 Fp bytes per row): the A operand of the fused wide forward
+    int out_bf16;           // xhat rows are written as bf16 [S][ld16] (Fp live elements per row): the A operand of the fused wide forward
+    int ld16;               //   row stride of those rows in elements (isk_ld16(Fp): whole 128-byte lines; 0 = Fp)
                             // (forward_mode 2 on the layered path); register featurizer only; not together with `planes`
     int planes;
     long long row0;         // planes only: `xhat` is the BASE of the plane buffer and local row s is global row row0 + s of its
@@ -142,9 +143,14 @@ void isk_launch_fold_f16(const float* Wt, void* out, int Kp, int nt, const unsig
 int  isk_bf16_chunks(int Kp);     // 32-feature chunks in the plane image (padded to the kernel's ring size)
 
 // ---------------------------------------------------------------- fused bf16 forward for wide networks (kernels_fwd_wide.hip) ----
+// row stride (elements) of the bf16 feature rows: every row starts on a 128-byte line, so a 256-byte run of a row is two whole
+// lines (at the plain stride of Fp = 2016 elements a run touched three: FETCH_SIZE was 1.33 x the algorithmic bytes)
+// ... but never a multiple of 1 KiB: at a power-of-two stride (4096 B for C5) the rows of a block alias onto the same HBM channels
+static inline int isk_ld16(int Fp) { int ld = (Fp + 63) & ~63; if (ld % 512 == 0) ld += 64; return ld; }
 struct WideFwdArgs {
-    const void* X; long long S; int Fp;           // [S][Fp] standardised feature rows (zero padded), bf16 as the featurizer
-    int x_bf16;                                   //   writes them for this path (FeatArgs.out_bf16; must be 1)
+    const void* X; long long S; int Fp;           // [S][ldx] standardised feature rows (Fp live elements, zero padded to a multiple of
+    int x_bf16;                                   //   32), bf16 as the featurizer writes them for this path (FeatArgs.out_bf16; must be 1)
+    int ldx;                                      //   row stride in elements (>= Fp; isk_ld16(Fp): rows start on 128-byte lines)
     int nhidden;                                  // hidden layers (all layers but the last), each of width <= 512
     int N[ISK_MAX_LAYERS], Kp[ISK_MAX_LAYERS];    // width and padded contraction (multiple of 32) per hidden layer
     const void* Wt[ISK_MAX_LAYERS];               // fragment-linear bf16 images (WtImagesArgs.Wf; columns >= N zero): isk_launch_wt_images

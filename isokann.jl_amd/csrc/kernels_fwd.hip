@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void featurize_reg_kernel(FeatArgs a, const un
             }
             if (lane == 0 && srow < a.S) a.xscale[srow] = inv;
         } else if (a.out_bf16) {                             // wave-uniform: bf16 rows (2 Fp bytes each) for the fused wide forward
-            const isk_i32x4 ro = row_rv(a.xhat, srow, a.Fp / 2, a.Fp / 2);
+            const isk_i32x4 ro = row_rv(a.xhat, srow, (a.ld16 ? a.ld16 : a.Fp) / 2, a.Fp / 2);
 #pragma unroll
             for (int pb = 0; pb < NPB; ++pb) {
                 const isk_bf16x2 h = __builtin_convertvector((isk_f32x2){tt[2 * pb] * rstd, tt[2 * pb + 1] * rstd}, isk_bf16x2);

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;
     const long long nblk = (a.S + WF_BM - 1) / WF_BM;
     const int ng1 = (a.Kp[0] + 127) >> 7;                                // ring groups of layer 1: 128 features (four steps) each
-    const int kbytes1 = a.Kp[0] * 2;
+    const int kbytes1 = a.Kp[0] * 2;                                     // live bytes of a feature row ...
+    const int xstride = a.ldx * 2;                                       // ... and its stride: rows start on 128-byte lines
     // Register budget (two waves per SIMD: 256): 128 accumulators + 64 weight-ring + 32 sample fragments leave ~30 for everything
     // else.  Addresses are therefore (uniform 64-bit base in SGPRs) + (one 32-bit lane offset) + (instruction immediate), and
     // whatever depends on the lane index is re-derived where it is used from a copy of it the compiler cannot see through
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
     // past the end re-read the last row (never stored).
     auto load_a = [&](long long row0, int g, f32x4 (&stage)[4]) {
         if (WF_ABLATE & 8) return;
-        const unsigned char* xb = (const unsigned char*)a.X + (size_t)row0 * kbytes1;            // uniform (Fp == Kp[0])
+        const unsigned char* xb = (const unsigned char*)a.X + (size_t)row0 * xstride;            // uniform
         asm volatile("" : "+s"(xb));
         const int gg = (WF_ABLATE & 1) ? 0 : g;
         const long long left = a.S - 1 - row0;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
             r = r < rmax ? r : rmax;
             int kb = gg * 256 + ((li_ ^ (4 * q + lq_)) << 4);
             kb = kb < kbytes1 - 16 ? kb : kbytes1 - 16;
-            stage[q] = *(const __attribute__((address_space(1))) f32x4*)(xb + (unsigned)(r * kbytes1 + kb));
+            stage[q] = *(const __attribute__((address_space(1))) f32x4*)(xb + (unsigned)(r * xstride + kb));
         }
     };
     auto store_a = [&](int slot, const f32x4 (&stage)[4]) {
@@ -357,7 +358,7 @@ int isk_wide_fwd_ok(const WideFwdArgs& a) {
     if (a.nhidden < 1 || a.nhidden >= ISK_MAX_LAYERS || a.nout < 1 || a.nout > 16) return 0;
     for (int l = 0; l < a.nhidden; ++l)
         if (a.N[l] < 1 || a.N[l] > WF_NP || a.Kp[l] % 32 || a.Kp[l] < 32 || (l > 0 && a.Kp[l] > WF_NP)) return 0;
-    return a.Klast == a.N[a.nhidden - 1] && a.Fp == a.Kp[0] && a.x_bf16;
+    return a.Klast == a.N[a.nhidden - 1] && a.Fp == a.Kp[0] && a.x_bf16 && a.ldx >= a.Kp[0] && a.ldx % 8 == 0;
 }
 
 int isk_launch_wide_fwd(const WideFwdArgs& a, hipStream_t st) {
