@@ -139,7 +139,8 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
             r = r < rmax ? r : rmax;
             int kb = gg * 256 + ((li_ ^ (4 * q + lq_)) << 4);
             kb = kb < kbytes1 - 16 ? kb : kbytes1 - 16;
-            stage[q] = *(const __attribute__((address_space(1))) f32x4*)(xb + (unsigned)(r * xstride + kb));
+            // (non-temporal: rows that are read once should not push the weight images out of the XCD's L2 -- A/B on one box: -1.5 %)
+            stage[q] = __builtin_nontemporal_load((const __attribute__((address_space(1))) f32x4*)(xb + (unsigned)(r * xstride + kb)));
         }
     };
     auto store_a = [&](int slot, const f32x4 (&stage)[4]) {
