@@ -78,14 +78,15 @@ __device__ __forceinline__ float wf_act_rt(int act, float z) {
 //   * with LDS-DMA and ordinary loads in flight together it treats vmcnt as out of order (two event types on one counter) and
 //     waits for vmcnt(0) at every use of a loaded register;
 //   * an LDS-DMA hidden in inline assembly is missing from its arithmetic for the weight loads: the waits come out 4 short and
-//     force a feature group to have landed three steps after its request (measured: 21 % of the kernel);
+//     force a feature group to have landed three steps after its request, whatever ring depth the code asks for;
 //   * hiding the weight loads as well (inline assembly + hand-written waits tied to the ring registers) made the register
 //     allocator spill 800 registers around the tied operands.
-// With plain loads only, every wait in the K-loops is the compiler's own and exact (vmcnt(12..16) / lgkmcnt(4..7) in the listing).
+// With plain loads only, every wait in the K-loops is the compiler's own and exact (vmcnt(16..19) with a feature group in flight,
+// vmcnt(12..15) without; lgkmcnt(3) for the fragment pairs).  The two builds run equally fast (A/B on one box).
 
 // diagnostic builds only (timing valid, results not): -DWF_ABLATE=bits -- 1: the feature groups re-read ONE group (cache
 // resident: no HBM stream), 2: every weight step re-reads the layer's first step, 4: no MFMAs (the fragment reads stay),
-// 8: no feature DMA at all, 16: no weight loads after a layer's first four steps, 32: no activation function (bias only)
+// 8: no feature loads at all, 16: no weight loads after a layer's first four steps, 32: no activation function (bias only)
 #ifndef WF_ABLATE
 #define WF_ABLATE 0
 #endif
@@ -95,13 +96,12 @@ __global__ __launch_bounds__(512) void wide_fwd_bf16_kernel(WideFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave-uniform: addresses built from it stay in SGPRs
-    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;
     const long long nblk = (a.S + WF_BM - 1) / WF_BM;
     const int ng1 = (a.Kp[0] + 127) >> 7;                                // ring groups of layer 1: 128 features (four steps) each
     const int kbytes1 = a.Kp[0] * 2;                                     // live bytes of a feature row ...
     const int xstride = a.ldx * 2;                                       // ... and its stride: rows start on 128-byte lines
-    // Register budget (two waves per SIMD: 256): 128 accumulators + 64 weight-ring + 32 sample fragments leave ~30 for everything
-    // else.  Addresses are therefore (uniform 64-bit base in SGPRs) + (one 32-bit lane offset) + (instruction immediate), and
+    // Register budget (two waves per SIMD: 256): 128 accumulators + 64 weight-ring + 16 sample-fragment + 16 feature-staging
+    // registers leave ~30 for everything else.  Addresses are therefore (uniform 64-bit base in SGPRs) + (one 32-bit lane offset) + (instruction immediate), and
     // whatever depends on the lane index is re-derived where it is used from a copy of it the compiler cannot see through
     // (WF_LANE): hoisted out of the loops, the per-instruction address registers were spilled (300 registers of scratch).
 #define WF_LANE(l_) unsigned l_ = (unsigned)lane; asm volatile("" : "+v"(l_))
