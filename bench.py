@@ -145,8 +145,6 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
-    if world > 1 or args.force_dp or args.shard_of > 0:
-        import torch  # noqa: F401  (before the engine library: torch's bundled ROCm libraries do not load behind the system's rocBLAS)
     ge.build()
     pkg = ge.load_package()
     if pkg.capi.device_count() <= local_rank:

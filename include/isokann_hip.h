@@ -139,6 +139,7 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *   feat_early_pct      0        share of the next iteration's rows featurized beside THIS forward (feat_early_wgs workgroups)
  *   train_graph         1        replay a training epoch as one hipGraph
  *   grad1_nw8           -1       layer-1 gradient kernel: 1 = 8-wave variant, 0 = 16-wave, -1 = 8-wave while the featurizer runs
+ *   tail_narrow         1        training: register-resident tail kernel where every tail layer is <= 16 wide (0: the generic LDS kernel)
  *   fwd_waves_per_simd  1        residency of the f32-MFMA forward kernel
  *   bf16_skew           1        split-bf16 forward: the second wave of a SIMD converts in the first half of a stage
  *   dense_groups        1        wide networks, bf16 forward: one grouped launch per layer
@@ -148,7 +149,8 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *   dp_force_coll       0        issue the native collectives on a one-rank communicator (tests)
  *   debug_feat_copy / debug_stamps / debug_rowmod   0   diagnostics
  * Read-only keys of isk_get_option: forward_mode (effective), layered, planes, nparams_engine, wide_fwd (1 when the resident
- * data set runs the fused bf16 forward of wide networks: layered network, forward_mode 2, pair features, option wide_fused). */
+ * data set runs the fused bf16 forward of wide networks: layered network, forward_mode 2, pair features, option wide_fused),
+ * layered_blas_active (1 once a rocBLAS handle exists, i.e. a wide network's f32 training GEMMs went to the library). */
 int  isk_set_option(isk_engine* e, const char* key, int64_t value);
 int  isk_get_option(isk_engine* e, const char* key, int64_t* value);
 
@@ -294,7 +296,8 @@ int  isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t local_batch, i
  *                                                  [i N/n, (i+1) N/n) of xs (D, N) and ys (D, K, N); N must be a multiple of n
  *   isk_dp_run_all(engines, n_eng, n, epochs, minibatch, perms, losses)   run!(iso, n, epochs) on the sharded data: one host
  *       thread per engine inside the call drives isk_dp_run (the step loop is launch-bound; the Julia host sees one blocking
- *       ccall).  minibatch keeps its meaning on the GLOBAL data (src/iso.jl:180; < 0: cfg.minibatch); perms: NULL, or one
+ *       ccall).  minibatch keeps its meaning on the GLOBAL data (src/iso.jl:180; < 0: cfg.minibatch) and must be a multiple of
+ *       n_eng (ISK_EINVAL otherwise: rounding it would change train_batch!'s batch size and step count); perms: NULL, or one
  *       (n*epochs, N/n) array of LOCAL shuffles per engine; losses[k] = train_batch!'s return value (src/iso.jl:193)
  *   isk_dp_destroy_all(engines, n) */
 int  isk_dp_create_all(const isk_config* cfg, const int32_t* devices, int32_t n, isk_engine** engines);

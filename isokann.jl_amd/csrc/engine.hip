@@ -85,6 +85,7 @@ static void free_data(isk_engine* e) {
     e->d_isa_work = nullptr;
     free_dev(e->d_actA); free_dev(e->d_actB); e->d_actA = e->d_actB = nullptr;
     free_dev(e->d_xb); e->d_xb = nullptr;
+    free_dev(e->dbg_st); free_dev(e->dbg_rows); e->dbg_st = nullptr; e->dbg_rows = nullptr;      // (dbg_rows is sized by the data)
     bf16_train_release(e);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_lz[l]); free_dev(e->d_la[l]); free_dev(e->d_ld[l]); e->d_lz[l] = e->d_la[l] = e->d_ld[l] = nullptr; }
     e->d_in_xs = e->d_in_ys = e->d_xhat = e->d_xhat_alt = e->d_out = e->d_ks = e->d_target = e->d_z1 = e->d_delta1 = e->d_part = nullptr;
@@ -176,6 +177,7 @@ TrainBuffers train_buffers(const isk_engine* e) {
     b.a1 = e->d_z1; b.delta1 = e->d_delta1; b.part = e->d_part; b.grad = e->d_grad;
     b.loss_acc = e->d_loss_acc; b.Fp = e->Fp;
     b.rank_err = e->d_rank_err;
+    b.tail_generic = e->opt.tail_narrow ? 0 : 1;
     return b;
 }
 
@@ -848,7 +850,7 @@ int forward_resident(isk_engine* e, int which, bool ahead) {
         if (e->planes) { f.xscale = e->d_xscale + (which == 2 ? nys : 0); f.x_row0 = which == 2 ? nys : 0; }   // unit-blocked rows: base + row index
         // diagnostic only (ISK_DEBUG_STAMPS=1 with a -DISK_STAMP build of the bf16x3 kernel): phase cycle sums
         const bool stamps = e->opt.debug_stamps != 0;
-        static unsigned long long* dbg_st = nullptr;
+        unsigned long long*& dbg_st = e->dbg_st;           // per engine: engines of one process sit on different devices
         if (stamps) {
             if (!dbg_st) (void)hipMalloc((void**)&dbg_st, (size_t)4096 * 12 * 8);
             (void)hipMemsetAsync(dbg_st, 0, (size_t)4096 * 12 * 8, e->stream);
@@ -856,7 +858,7 @@ int forward_resident(isk_engine* e, int which, bool ahead) {
         }
         // diagnostic only (ISK_DEBUG_ROWMOD=m): every row reads row (r mod m), i.e. a cache-resident sample stream
         const long long rowmod = e->opt.debug_rowmod;
-        static int* dbg_rows = nullptr;
+        int*& dbg_rows = e->dbg_rows;
         if (rowmod > 0) {
             if (!dbg_rows) {
                 std::vector<int> h(S);

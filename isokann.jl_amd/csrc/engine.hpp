@@ -127,6 +127,8 @@ struct isk_engine {
         const float* xs = nullptr;
     } tg[2];
     bool tg_disabled = false;
+    unsigned long long* dbg_st = nullptr;            // diagnostics of forward_resident (options debug_stamps / debug_rowmod)
+    int* dbg_rows = nullptr;
     hipEvent_t ev_loss = nullptr;        // recorded behind the epoch's loss read-back: the host waits for IT, not for the stream
     // data
     long long N = 0, K = 0, D = 0;

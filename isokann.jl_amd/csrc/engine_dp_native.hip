@@ -225,15 +225,16 @@ static int dp_clear_poison(isk_engine* e) {
 
 extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t local_batch, int32_t nbatches, int64_t global_batch,
                           const int32_t* perms, double* losses) {
-    CHK(need_data(e));
+    if (!e) return fail(ISK_EINVAL, "null engine");
     const bool coll = dp_collectives(e);
     // every argument check and allocation comes BEFORE the first collective, and its outcome is agreed on by all ranks: a rank
     // that simply returned here would leave the others blocked in an all-reduce
     int lst = ISK_OK;
     std::string lmsg;
     auto bad = [&](int code, const char* msg) { if (lst == ISK_OK) { lst = code; lmsg = msg; } };
+    if (need_data(e) != ISK_OK) { lst = ISK_ESTATE; lmsg = isk_last_error(); }          // a rank without data still joins the agreement
     if (n < 0 || epochs < 0) bad(ISK_EINVAL, "negative iteration count");
-    if (local_batch < 1 || nbatches < 1 || (long long)local_batch * nbatches > e->N || global_batch < local_batch)
+    if (lst == ISK_OK && (local_batch < 1 || nbatches < 1 || (long long)local_batch * nbatches > e->N || global_batch < local_batch))
         bad(ISK_EINVAL, "bad batch decomposition");
     if (perms && lst == ISK_OK)
         for (long long i = 0; i < (long long)n * epochs * e->N; ++i)
@@ -255,10 +256,22 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
         featurize_early_share(e, e->side_after_forward);
         const int tr = dp_target_native(e);
         e->side_after_forward = 0;
-        if (tr != ISK_OK) { (void)dp_clear_poison(e); return tr; }       // before this iteration's first gradient all-reduce on every rank alike
+        // A target that failed on THIS rank only (a HIP error in its forward, say) must not end the call here: the peers are on
+        // their way into the epoch's gradient all-reduces.  Raise the flag and keep issuing them; every rank returns at the
+        // epoch's end.  (With no epoch to carry the flag -- epochs == 0 -- there is nothing to keep in step: return.)
+        if (tr != ISK_OK) {
+            if (epochs == 0 || !coll) { (void)dp_clear_poison(e); return tr; }
+            dp_poison(e, tr, isk_last_error());
+        }
         // the shuffle order (drawn here from the engine's seeded generator when the host passes none: ~50 us of host
         // work) is staged while the forward runs
-        if (epochs > 0) CHK(stage_perm_ahead(e, perms ? perms + k * e->N : nullptr));
+        if (epochs > 0) {
+            const int sp = stage_perm_ahead(e, perms ? perms + k * e->N : nullptr);
+            if (sp != ISK_OK) {
+                if (!coll) { (void)dp_clear_poison(e); return sp; }
+                dp_poison(e, sp, isk_last_error());
+            }
+        }
         featurize_ys_beside_training(e, (long long)nbatches * epochs);
         for (int ep = 0; ep < epochs; ++ep) {
             if (ep == 0) {
@@ -297,7 +310,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
             // a rank flagged an error in one of this epoch's steps: the same verdict on every rank (the flag was all-reduced)
             if (e->dp_err != ISK_OK) return dp_clear_poison(e);
             if (acc[3] != 0.0) return fail(ISK_EPEER, "a peer rank reported an error inside the training epoch; no update was applied from that step on");
-            HIPCHK(hipGetLastError());
+            DPHIP(hipGetLastError());            // sticky error of this rank: carried by the NEXT epoch's flag slot (or returned below)
             int st = 0;
             std::memcpy(&st, acc + 2, sizeof(int));
             if (st) {   // the target's DomainError outranks the loss check; every rank sees the same status (same gathered data)
@@ -310,6 +323,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
         }
         if (epochs == 0) CHK(check_status(e));
     }
+    if (e->dp_err != ISK_OK) return dp_clear_poison(e);       // raised behind the last epoch's collectives: nobody is left waiting
     return ISK_OK;
 }
 
@@ -400,6 +414,9 @@ extern "C" int isk_dp_run_all(isk_engine** engines, int32_t n_engines, int32_t n
     long long bl, nb, gb;
     if (bs == Ng) { bl = Nl; nb = 1; gb = Ng; }
     else {
+        // train_batch!'s rule (src/iso.jl:180) fixes batch size and step count; a global batch that does not split evenly would
+        // silently become bl * n_engines rows and change both
+        if (bs % n_engines != 0) return fail(ISK_EINVAL, "the global minibatch must be a multiple of the engine count");
         bl = bs / n_engines;
         if (bl < 1) return fail(ISK_EINVAL, "global minibatch smaller than the number of engines");
         nb = Nl / bl; gb = bl * n_engines;

@@ -1,6 +1,7 @@
 // Layered (wide-network) path of the engine: networks whose layers do not fit the fused kernels (first hidden width > 160,
 // or a tail too wide for LDS -- e.g. C5's densenet [2000,512,512,512,1]) run layer by layer through HBM.
 #include <dlfcn.h>
+#include <mutex>
 #include "engine.hpp"
 
 // bf16 planes per f32 operand of the layer-1 / dense-block forward GEMM: 0 = f32 MFMA, 3 = split-bf16, 1 = plain bf16
@@ -107,20 +108,35 @@ struct BlasApi {
     bool failed = false;
 };
 BlasApi g_blas;
+std::mutex g_blas_mu;                       // isk_dp_run_all drives one host thread per engine: the first epochs race to get here
 
+// The host process may carry a rocBLAS of its own (PyTorch bundles one; so does AMDGPU.jl's artifact tree), and two things must
+// not happen: (1) a second copy whose symbols land in the GLOBAL scope -- the host's ROCm libraries, loaded later, would bind
+// their rocblas_* / hipblaslt references to it and die in their initialisers (recorded: `import torch` behind the engine's first
+// wide-network step, Segmentation fault inside torch/__init__.py; reproducible without a GPU with
+// ctypes.CDLL("librocblas.so.5", RTLD_GLOBAL) followed by `import torch`); (2) a copy registered under the DEVELOPER name
+// "librocblas.so", which is the name the host's libraries ask for: the loader would hand them OUR copy instead of their bundled
+// one.  So: reuse whatever the process already has (RTLD_NOLOAD, as rccl_load does), otherwise load by the versioned soname
+// with RTLD_LOCAL.
 bool blas_load() {
+    std::lock_guard<std::mutex> lk(g_blas_mu);
     if (g_blas.lib) return true;
     if (g_blas.failed) return false;
-    void* h = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    void* h = nullptr;
+    static const char* const names[] = {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so.5", "/opt/rocm/lib/librocblas.so"};
+    for (int i = 0; i < 2 && !h; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+    for (int i = 0; i < 4 && !h; ++i) if (i != 1) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen(names[1], RTLD_NOW | RTLD_LOCAL);
+    BlasApi a;
     if (h) {
-        g_blas.create = (decltype(g_blas.create))dlsym(h, "rocblas_create_handle");
-        g_blas.destroy = (decltype(g_blas.destroy))dlsym(h, "rocblas_destroy_handle");
-        g_blas.set_stream = (decltype(g_blas.set_stream))dlsym(h, "rocblas_set_stream");
-        g_blas.sgemm = (decltype(g_blas.sgemm))dlsym(h, "rocblas_sgemm");
+        a.create = (decltype(a.create))dlsym(h, "rocblas_create_handle");
+        a.destroy = (decltype(a.destroy))dlsym(h, "rocblas_destroy_handle");
+        a.set_stream = (decltype(a.set_stream))dlsym(h, "rocblas_set_stream");
+        a.sgemm = (decltype(a.sgemm))dlsym(h, "rocblas_sgemm");
     }
-    if (!h || !g_blas.create || !g_blas.destroy || !g_blas.set_stream || !g_blas.sgemm) { g_blas.failed = true; return false; }
-    g_blas.lib = h;
+    if (!h || !a.create || !a.destroy || !a.set_stream || !a.sgemm) { g_blas.failed = true; return false; }
+    a.lib = h;
+    g_blas = a;
     return true;
 }
 }  // namespace

@@ -33,6 +33,7 @@ struct IskOptions {
     int fwd_waves_per_simd = 1;   // residency of the f32 forward kernel
     int dp_force_coll = 0;        // issue the native collectives on a one-rank communicator (tests)
     int wide_fused = 1;           // layered path, plain-bf16 forward: the fused wide kernel (0: layer by layer through HBM)
+    int tail_narrow = 1;          // fused path: register-resident train_tail for narrow tails (0: the generic LDS kernel)
     int train_bf16 = 0;           // layered path: training GEMMs with bf16 operands (f32 master weights, f32 accumulate): the C5
                                   // arithmetic of BASELINE.json; 0 = f32
     int debug_inject_rank_error = 0;   // tests: in the native data-parallel run this rank flags an error at its n-th optimizer step
@@ -321,6 +322,7 @@ struct TrainBuffers {
     float* grad;            // flat gradient [nparams] + [loss, nonfinite]
     double* loss_acc;       // [2]: epoch loss sum (double), collapsed flag (as double)
     int cot_mode;           // 1: `target` is a cotangent (coordinate pullback), see isk_launch_train_tail
+    int tail_generic;       // 1: always the generic train_tail_kernel (option tail_narrow = 0); 0: the register-resident kernel where the tail is narrow
     int Fp;
     const int* rank_err;    // optional device word: this rank's error flag.  The gradient kernel copies it (as a float) into
                             // grad[nparams + 1], the slot behind the batch loss, so the data-parallel all-reduce of [grad | loss |
@@ -340,6 +342,9 @@ void isk_launch_train_fwd1n(const TrainShape& s, const TrainBuffers& b, const in
 void isk_launch_gemm_rows(const float* X, int ldx, const float* Wt, const float* bias, int nt, const int* perm, int B, float* out,
                           hipStream_t st);
 void isk_launch_train_tail(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div, hipStream_t st);
+// kernels_train_tailn.hip: the same step for narrow tails (every tail layer <= 16 wide), one 16-sample unit in registers
+bool isk_train_tail_narrow_ok(const TrainShape& s);
+void isk_launch_train_tail_narrow(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div, hipStream_t st);
 // cotangent mode: b.target holds the cotangent [B][nout]; delta_L = cot .* act'(z_L), no loss, no weights
 void isk_launch_train_grad1n(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st);
 #define ISK_MAX_SLABS 8

@@ -683,6 +683,7 @@ static TailDesc tail_desc(const TrainShape& s, size_t* lds_bytes) {
 
 void isk_launch_train_tail(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div,
                            hipStream_t st) {
+    if (!b.tail_generic && isk_train_tail_narrow_ok(s)) { isk_launch_train_tail_narrow(s, b, perm, B, inv_div, st); return; }
     const int units = (B + 15) / 16;
     size_t lds;
     const TailDesc d = tail_desc(s, &lds);

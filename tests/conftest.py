@@ -45,10 +45,6 @@ def pkg():
 @pytest.fixture(scope="session")
 def gpu_pkg(pkg):
     """package with the HIP library loaded and a device present"""
-    # torch (its autograd is the independent cross-check of some tests, its process groups carry the data-parallel tests) brings
-    # its own copies of the ROCm libraries: imported AFTER the engine has dlopen()ed the system's rocBLAS it crashes in its
-    # initialisers, so it goes first -- whatever subset of the tests is selected
-    import torch  # noqa: F401
     lib = pkg.capi.load()          # raises loudly if the .so is missing
     n = pkg.capi.device_count()
     if n < 1:

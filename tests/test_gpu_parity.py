@@ -9,11 +9,14 @@ Tolerances (fp32 path vs the fp64 oracle), per BASELINE.json north_star / SURVEY
   losses        rel 1e-4
 """
 import os
+import sys
 
 import numpy as np
 import pytest
 
 from oracle import isokann_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fwd_mode")]
 
@@ -827,6 +830,44 @@ def test_wide_network_switching_the_training_arithmetic_mid_run(gpu_pkg, monkeyp
     gflat = np.concatenate([a.reshape(-1, order="F") for a in go])
     np.testing.assert_allclose(g32, gflat, atol=5e-5 * np.abs(gflat).max(), rtol=2e-4)
     iso.close()
+
+
+@pytest.mark.own_fwd_mode
+def test_torch_imports_behind_a_wide_network_step_on_rocblas(gpu_pkg):
+    """The engine loads the system's rocBLAS lazily for the f32 training GEMMs of a wide network (option layered_blas).  Loaded
+    RTLD_GLOBAL it made every later `import torch` in the process die in the initialisers of torch's bundled ROCm libraries
+    (round-3 crash record); blas_load() now reuses a copy the host already has or loads its own RTLD_LOCAL by soname.  A fresh
+    child process: engine first, one optimizer step on the rocBLAS path, THEN torch (and a matmul on it)."""
+    import subprocess
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+assert 'torch' not in sys.modules
+import numpy as np
+import __graft_entry__ as ge
+pkg = ge.load_package()
+from oracle import isokann_oracle as O
+A, F, N, K = 20, 100, 128, 3
+xs, ys = O.synthetic_coords(A, N, K, seed=5)
+pairs = O.random_pairs(A, F, seed=6)
+iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=pkg.densenet([F, 200, 64, 1], layernorm=False, seed=1),
+              opt=pkg.AdamRegularized(), minibatch=64, forward_mode=0, options={"layered_blas": 1, "train_bf16": 0})
+pkg.run(iso, 1, 1)
+assert iso.get_option("layered_blas_active") == 1, "the step did not run on rocBLAS"
+assert 'torch' not in sys.modules
+import torch
+a = torch.arange(6.0).reshape(2, 3)
+assert float((a @ a.T).sum()) == 5 + 14 + 14 + 50
+if torch.cuda.is_available():
+    b = a.cuda()
+    assert float((b @ b.T).sum().cpu()) == 83.0
+pkg.run(iso, 1, 1)
+print("OK", iso.losses)
+""" % ROOT
+    env = dict(os.environ)
+    env.pop("ISK_FWD_MODE", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
 
 
 # --------------------------------------------------------------- TransformPseudoInv (SURVEY 8f rank 4) ----
