@@ -139,6 +139,9 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *   feat_early_pct      0        share of the next iteration's rows featurized beside THIS forward (feat_early_wgs workgroups)
  *   train_graph         1        replay a training epoch as one hipGraph
  *   grad1_nw8           -1       layer-1 gradient kernel: 1 = 8-wave variant, 0 = 16-wave, -1 = 8-wave while the featurizer runs
+ *   train_persist       0        training on one GPU: 1 = an epoch as ONE persistent launch where the network allows it (narrow tail,
+ *                                sigmoid hidden layers, batches of at most 1024 rows).  Experimental: correct, and slower than the four
+ *                                launches per optimizer step it replaces
  *   tail_narrow         1        training: register-resident tail kernel where every tail layer is <= 16 wide (0: the generic LDS kernel)
  *   fwd_waves_per_simd  1        residency of the f32-MFMA forward kernel
  *   bf16_skew           1        split-bf16 forward: the second wave of a SIMD converts in the first half of a stage
@@ -150,7 +153,7 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *   debug_feat_copy / debug_stamps / debug_rowmod   0   diagnostics
  * Read-only keys of isk_get_option: forward_mode (effective), layered, planes, nparams_engine, wide_fwd (1 when the resident
  * data set runs the fused bf16 forward of wide networks: layered network, forward_mode 2, pair features, option wide_fused),
- * layered_blas_active (1 once a rocBLAS handle exists, i.e. a wide network's f32 training GEMMs went to the library). */
+ * train_persist_active (1 when the last epoch ran as one persistent launch), layered_blas_active (1 once a rocBLAS handle exists, i.e. a wide network's f32 training GEMMs went to the library). */
 int  isk_set_option(isk_engine* e, const char* key, int64_t value);
 int  isk_get_option(isk_engine* e, const char* key, int64_t* value);
 

@@ -329,6 +329,10 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     uint64_t sm = cfg->seed ^ 0x1234567887654321ull;
     for (int i = 0; i < 4; ++i) e->rng[i] = splitmix(sm);
     e->bt1 = cfg->beta1; e->bt2 = cfg->beta2;
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess) e->ncu = ncu;
+    }
 
 #define ALLOC(ptr, bytes)                                                          \
     do {                                                                           \
@@ -424,6 +428,7 @@ extern "C" void isk_destroy(isk_engine* e) {
     if (e->copy) (void)hipStreamSynchronize(e->copy);
     free_data(e);
     free_dev(e->d_theta); free_dev(e->d_grad); free_dev(e->d_m); free_dev(e->d_v); free_dev(e->d_bt);
+    free_dev(e->d_ep_zp); free_dev(e->d_ep_lnpart); free_dev(e->d_ep_cnt);
     free_dev(e->d_loss_acc); free_dev(e->d_mm); free_dev(e->d_lossw);
     free_dev(e->d_At); free_dev(e->d_rowperm); free_dev(e->d_pairs); free_dev(e->d_packed); free_dev(e->d_isa_work_dp);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_Wt[l]); free_dev(e->d_bias[l]); }
@@ -1092,6 +1097,77 @@ int stage_perm_ahead(isk_engine* e, const int32_t* perm) {
     return ISK_OK;
 }
 
+// The whole epoch as ONE persistent launch (kernels_train_epoch.hip): fused-path networks with a narrow tail on a single GPU.
+// false: not applicable here (or a launch failed once): the caller runs the launch chain.
+static bool train_epoch_persist(isk_engine* e, long long bs, long long nb) {
+    e->last_epoch_persist = false;
+    if (!e->opt.train_persist || e->tp_disabled || e->layered || !e->native || nb < 1 || e->ncu < 1) return false;
+    const TrainShape s = train_shape(e);
+    EpochPlan p;
+    if (!isk_train_epoch_plan(s, e->Fp, (int)bs, e->ncu, &p)) return false;
+    const int H1p = isk_pad16(e->cfg.widths[1]);
+    const size_t zp_floats = (size_t)p.KS * p.zrows * H1p, lp_floats = (size_t)p.KS * p.nt * 2 * p.cps * 16;
+    if (e->ep_zp_floats < zp_floats) {
+        (void)hipStreamSynchronize(e->stream);
+        free_dev(e->d_ep_zp); e->d_ep_zp = nullptr; e->ep_zp_floats = 0;
+        if (hipMalloc((void**)&e->d_ep_zp, zp_floats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); e->tp_disabled = true; return false; }
+        e->ep_zp_floats = zp_floats;
+    }
+    if (e->ep_lnpart_floats < lp_floats) {
+        (void)hipStreamSynchronize(e->stream);
+        free_dev(e->d_ep_lnpart); e->d_ep_lnpart = nullptr; e->ep_lnpart_floats = 0;
+        if (hipMalloc((void**)&e->d_ep_lnpart, lp_floats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); e->tp_disabled = true; return false; }
+        e->ep_lnpart_floats = lp_floats;
+    }
+    if (!e->d_ep_cnt && hipMalloc((void**)&e->d_ep_cnt, ISK_EP_CNT_WORDS * sizeof(unsigned)) != hipSuccess) {
+        (void)hipGetLastError(); e->tp_disabled = true; return false;
+    }
+    EpochArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.X = e->d_xs32; a.Fp = e->Fp; a.perm = e->d_perm; a.B = (int)bs; a.nb = (int)nb;
+    a.theta = e->d_theta; a.m = e->d_m; a.v = e->d_v;
+    a.off_lns = e->off_lns; a.off_lnb = e->off_lnb; a.off_W0 = e->off_W[0]; a.off_b0 = e->off_b[0];
+    a.ln = e->cfg.layernorm; a.nch = e->Fp / 16;
+    a.target = e->d_target; a.lossw = e->d_lossw; a.inv_div = 1.0f / (float)bs;
+    a.zp = e->d_ep_zp; a.delta1 = e->d_delta1; a.part = e->d_part; a.lnpart = e->d_ep_lnpart; a.cnt = e->d_ep_cnt;
+    a.opt_kind = e->cfg.opt_kind; a.lr = e->cfg.lr; a.reg = e->cfg.reg; a.beta1 = e->cfg.beta1; a.beta2 = e->cfg.beta2;
+    a.eps = e->cfg.opt_eps; a.rho = e->cfg.rho;
+    a.bt1 = e->bt1; a.bt2 = e->bt2;
+    a.loss_acc = e->d_loss_acc; a.host_pub = e->d_hres;
+    const bool stamps = e->opt.debug_stamps != 0;
+    if (stamps) {
+        if (!e->dbg_st) (void)hipMalloc((void**)&e->dbg_st, (size_t)4096 * 12 * 8);
+        (void)hipMemsetAsync(e->dbg_st, 0, 64 * 8, e->stream);
+        a.dbg = e->dbg_st;
+    }
+    if (isk_launch_train_epoch(s, p, a, e->stream) != 0) { (void)hipGetLastError(); e->tp_disabled = true; return false; }
+    // what launch_grads / launch_opt keep track of on the host
+    for (long long b = 0; b < nb; ++b) { e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2; }
+    e->bt_dev_valid = false;             // the device copy of beta^t did not take part
+    e->last_nslab = 1;
+    e->w16_dirty = true; e->wt_dirty = true;
+    e->b16.wt_dirty = e->b16.wf_dirty = true;
+    e->loss_acc_zeroed = false;
+    e->last_epoch_persist = true;
+    if (stamps) {
+        (void)hipStreamSynchronize(e->stream);
+        unsigned long long h[64];
+        (void)hipMemcpy(h, e->dbg_st, sizeof(h), hipMemcpyDeviceToHost);
+        static const char* nm[14] = {"step", "P1", "pubA", "waitA+C", "Kreduce", "tail", "pubB", "waitB", "P3", "loss+E1", "E2+pubSib", "E4", "E5", "E6+pubC"};
+        for (int g = 0; g < 2; ++g) {
+            fprintf(stderr, "[epoch stamps] wg %s:", g == 0 ? "0 (tail role)" : "G-1");
+            unsigned long long prev = h[32 * g];
+            for (int k = 1; k < 14; ++k) {
+                if (!h[32 * g + k]) continue;
+                fprintf(stderr, " %s %.2f", nm[k], (double)(h[32 * g + k] - prev) * 0.01);
+                prev = h[32 * g + k];
+            }
+            fprintf(stderr, " | total %.2f us\n", (double)(prev - h[32 * g]) * 0.01);
+        }
+    }
+    return true;
+}
+
 // The epoch's nb x 5 dependent launches as ONE hipGraph launch.  A dependent kernel launched from the host costs ~3.0 us
 // on this stack, the same chain replayed from a graph ~1.9 us (measured with a 50-kernel chain of empty kernels); the
 // training chain is nothing but such launches (50 per iteration at C3, 500 at the reference's default minibatch of 100).
@@ -1161,6 +1237,10 @@ static int finish_epoch(isk_engine* e, double* loss, int* status_word) {
     HIPCHK(hipGetLastError());
     const double* acc = e->h_res;
     if (status_word) std::memcpy(status_word, acc + 2, sizeof(int));
+    if (acc[1] == 2.0) {                                         // the persistent epoch kernel gave up on a hand-off (bounded spin)
+        e->tp_disabled = true;
+        return fail(ISK_EHIP, "the persistent training-epoch kernel timed out on an in-launch hand-off; parameters are undefined (option train_persist = 0 avoids it)");
+    }
     if (acc[1] != 0.0) return fail(ISK_ECOLLAPSED, isk_status_string(ISK_ECOLLAPSED));
     if (loss) *loss = acc[0] / (double)e->N;                     // src/iso.jl:193
     return ISK_OK;
@@ -1194,7 +1274,7 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
     {
         ScopedTimer t(e, ISK_T_TRAIN);
         const bool lazy_fold = epoch_lazy_fold(e);
-        if (!train_epoch_graph(e, bs, nb)) {
+        if (!train_epoch_persist(e, bs, nb) && !train_epoch_graph(e, bs, nb)) {
             for (long long b = 0; b < nb; ++b) {
                 launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, pick_slabs((int)bs));
                 launch_opt(e, 1.0f, !lazy_fold || (b == nb - 1 && !epoch_no_fold(e)), false, b == nb - 1);

@@ -127,6 +127,13 @@ struct isk_engine {
         const float* xs = nullptr;
     } tg[2];
     bool tg_disabled = false;
+    // the persistent epoch kernel (kernels_train_epoch.hip): hand-off buffers, sized for the batch plan they were allocated for
+    int ncu = 0;                         // compute units of the device (its grid must be co-resident)
+    float* d_ep_zp = nullptr; size_t ep_zp_floats = 0;
+    float* d_ep_lnpart = nullptr; size_t ep_lnpart_floats = 0;
+    unsigned* d_ep_cnt = nullptr;
+    bool tp_disabled = false;
+    bool last_epoch_persist = false;            // a launch failed or timed out: the four-kernel chain from then on
     unsigned long long* dbg_st = nullptr;            // diagnostics of forward_resident (options debug_stamps / debug_rowmod)
     int* dbg_rows = nullptr;
     hipEvent_t ev_loss = nullptr;        // recorded behind the epoch's loss read-back: the host waits for IT, not for the stream

@@ -33,6 +33,8 @@ struct IskOptions {
     int fwd_waves_per_simd = 1;   // residency of the f32 forward kernel
     int dp_force_coll = 0;        // issue the native collectives on a one-rank communicator (tests)
     int wide_fused = 1;           // layered path, plain-bf16 forward: the fused wide kernel (0: layer by layer through HBM)
+    int train_persist = 0;        // fused path, single GPU: a training epoch as ONE persistent launch (experimental: measured SLOWER
+                                  // than the four launches per optimizer step it replaces -- DESIGN.md section 6c; default off)
     int tail_narrow = 1;          // fused path: register-resident train_tail for narrow tails (0: the generic LDS kernel)
     int train_bf16 = 0;           // layered path: training GEMMs with bf16 operands (f32 master weights, f32 accumulate): the C5
                                   // arithmetic of BASELINE.json; 0 = f32
@@ -347,6 +349,45 @@ bool isk_train_tail_narrow_ok(const TrainShape& s);
 void isk_launch_train_tail_narrow(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div, hipStream_t st);
 // cotangent mode: b.target holds the cotangent [B][nout]; delta_L = cot .* act'(z_L), no loss, no weights
 void isk_launch_train_grad1n(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st);
+// ---------------------------------------------------------------- narrow tails (train_tailn.hpp) ----
+#define TN_MAXL 3                   /* tail layers of the register-resident tail */
+struct TailNLay {
+    int K, N, act;
+    long long gW, gb;               // offsets in theta (Flux layout W[n + k*N])
+    long long pW, pb;               // offsets in the per-unit partial vector
+};
+struct TailNDesc {
+    int L, H1, H1p, nt, nout, act0, lastact;
+    long long off_b0, PS;
+    TailNLay lay[TN_MAXL];
+};
+TailNDesc isk_tailn_desc(const TrainShape& s);
+// ---------------------------------------------------------------- persistent training epoch (kernels_train_epoch.hip) ----
+struct EpochPlan { int cps, KS, nt, G, U, zrows, nC, nS; size_t lds; };
+#define ISK_EP_CNT_WORDS 4096         /* one 128-byte line per counter */
+struct EpochArgs {
+    const float* X; int Fp; const int* perm; int B, nb;         // batch rows of step s: perm[s*B .. s*B + B)
+    float* theta; float* m; float* v;                            // engine (native) order
+    long long off_lns, off_lnb, off_W0, off_b0;
+    int ln;                                                      // leading LayerNorm
+    int nt, nch, cps, KS, U, G, zrows, nC, nS;
+    long long nparams;
+    TailNDesc d;
+    const float* target; const float* lossw; float inv_div;
+    float* zp;                                                   // [KS][zrows][H1p]  K-slice partials of z1
+    float* delta1;                                               // [zrows][H1p]      natural column order
+    float* part;                                                 // [U][PS]           per-unit partial sums of the small gradients, [0] loss
+    float* lnpart;                                               // [KS][nt][2][cps*16] LayerNorm-gradient shares of the tile owners
+    unsigned* cnt;                                               // [ISK_EP_CNT_WORDS] hand-off counters (zeroed by the launcher)
+    int opt_kind; float lr, reg, beta1, beta2, eps, rho;
+    double bt1, bt2;                                             // beta^t of the epoch's first step
+    int collapsed_in;
+    double* loss_acc; double* host_pub;
+    unsigned long long* dbg;                                     // diagnostics (option debug_stamps): [2][32] phase stamps of step 1, or nullptr
+};
+// false: the shape is not covered (the caller keeps the four-kernel chain).  ncu: compute units (the grid must be co-resident)
+bool isk_train_epoch_plan(const TrainShape& s, int Fp, int B, int ncu, EpochPlan* p);
+int  isk_launch_train_epoch(const TrainShape& s, const EpochPlan& p, EpochArgs a, hipStream_t st);
 #define ISK_MAX_SLABS 8
 int  isk_train_tail_nblocks(int B);
 long long isk_train_part_floats(const TrainShape& s, int maxB);
