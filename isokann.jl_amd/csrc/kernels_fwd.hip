@@ -766,34 +766,37 @@ __global__ __launch_bounds__(256) void kmean_kernel(KmeanArgs a) {
     const float* base = a.out_ys + n * (long long)a.K * a.nout;
     const float* w = a.w ? a.w + n * (long long)a.K : nullptr;
     const int tot = a.K * a.nout;
+    // The sums run in DOUBLE and are rounded to float once: K chi is what the ISA target amplifies (its simplex inverse has a condition
+    // number of a few hundred on villin-like data), and a float summation of K = 20 terms carries more rounding error than the
+    // K-mean leaves of the forward's own (averaged-out) error.
     if (a.nout <= 64 && (64 % a.nout) == 0) {
         // lane l always sees output index l % nout (stride 64 is a multiple of nout)
-        float s = 0.f;
-        for (int i = lane; i < tot; i += WAVE) s += w ? base[i] * w[i / a.nout] : base[i];
+        double s = 0.0;
+        for (int i = lane; i < tot; i += WAVE) s += w ? (double)base[i] * (double)w[i / a.nout] : (double)base[i];
         for (int o = 32; o >= a.nout; o >>= 1) s += __shfl_xor(s, o, WAVE);
-        if (lane < a.nout) a.ks[n * a.nout + lane] = s / (float)a.K;
+        if (lane < a.nout) a.ks[n * a.nout + lane] = (float)(s / (double)a.K);
     } else if (a.nout < 64) {
         // nout does not divide 64 (C3: nout = 3): the first W = 64 - 64 % nout lanes walk the K x nout block with stride W,
         // so a lane keeps one output index; the W / nout partial sums per output are combined through LDS
-        __shared__ float part[4][64];
+        __shared__ double part[4][64];
         const int wv = threadIdx.x >> 6;
         const int W = WAVE - WAVE % a.nout;
-        float s = 0.f;
+        double s = 0.0;
         if (lane < W)
-            for (int i = lane; i < tot; i += W) s += w ? base[i] * w[i / a.nout] : base[i];
+            for (int i = lane; i < tot; i += W) s += w ? (double)base[i] * (double)w[i / a.nout] : (double)base[i];
         part[wv][lane] = s;
         __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the wave's own LDS writes have landed
         __builtin_amdgcn_wave_barrier();
         if (lane < a.nout) {
-            float t = 0.f;
+            double t = 0.0;
             for (int j = lane; j < W; j += a.nout) t += part[wv][j];
-            a.ks[n * a.nout + lane] = t / (float)a.K;
+            a.ks[n * a.nout + lane] = (float)(t / (double)a.K);
         }
     } else {
         for (int o = lane; o < a.nout; o += WAVE) {
-            float s = 0.f;
-            for (int k = 0; k < a.K; ++k) s += w ? base[k * a.nout + o] * w[k] : base[k * a.nout + o];
-            a.ks[n * a.nout + o] = s / (float)a.K;
+            double s = 0.0;
+            for (int k = 0; k < a.K; ++k) s += w ? (double)base[k * a.nout + o] * (double)w[k] : (double)base[k * a.nout + o];
+            a.ks[n * a.nout + o] = (float)(s / (double)a.K);
         }
     }
 }

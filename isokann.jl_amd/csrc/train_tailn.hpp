@@ -35,7 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float tn_sigmoid(float z) {
     const float e = __expf(-fabsf(z));
-    const float r = __builtin_amdgcn_rcpf(1.0f + e);               // (1 ulp; an IEEE division is ten instructions per element)
+    const float r = 1.0f / (1.0f + e);                             // (IEEE division: the training path is held to the oracle at fp32 rounding)
     return z >= 0.f ? r : e * r;
 }
 // four values per call, called UNCONDITIONALLY (masks are applied to the results): a call under a lane mask costs a divergent
@@ -167,11 +167,12 @@ __device__ __forceinline__ float tailn_unit(const TailNDesc& d, const TailNIO& i
         }
 #pragma unroll
         for (int ti = 0; ti < TPW; ++ti) {
-            f32x4 z = zp[ti][0];
+            // (the K-slice partials are summed in double: one float rounding for the whole 1728-term product)
+            double z0 = zp[ti][0][0], z1d = zp[ti][0][1], z2 = zp[ti][0][2], z3 = zp[ti][0][3];
 #pragma unroll
             for (int ks = 1; ks < ISK_FWD1_MAXKS; ++ks)
-                if (ks < io.KS) z += zp[ti][ks];
-            zsum[ti] = z;
+                if (ks < io.KS) { z0 += (double)zp[ti][ks][0]; z1d += (double)zp[ti][ks][1]; z2 += (double)zp[ti][ks][2]; z3 += (double)zp[ti][ks][3]; }
+            zsum[ti] = (f32x4){(float)z0, (float)z1d, (float)z2, (float)z3};
         }
     } else {
 #pragma unroll

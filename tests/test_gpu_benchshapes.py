@@ -133,16 +133,25 @@ def test_c3_width_full_batch_chi_within_1e5(gpu_pkg, every_iter):
 
 @pytest.mark.parametrize("every_iter", [False, True])
 @pytest.mark.parametrize("name", ["full_adam", "full3_adam", "mb100_nesterov", "mb1000_adam"])
-def test_c3_subsample_runs_within_fp32_floor(gpu_pkg, name, every_iter):
+def test_c3_subsample_runs_within_fp32_floor(gpu_pkg, fwd_mode, name, every_iter):
     """C3 itself (TransformISA) at the plain initialisation, where the simplex inverse amplifies every rounding error of K chi
     ~250-fold (4 000-fold by the third minibatched iteration): 10 and 3 full-batch iterations, and 3 iterations with injected
     DataLoader orders at the reference default (minibatch 100, Nesterov) and at villin.jl's (minibatch 1000, Adam).  The CPU
     oracle evaluated in float32 ends up 8e-6 (3 iterations) .. 1.8e-5 (10) from its own fp64 run in chi -- at or beyond the
-    1e-5 gate before any GPU is involved -- so the HIP path is held to max(gate, 3 x that measured fp32 floor); measured on
-    MI355X: 1.3e-5 after 3 iterations, 3.5e-5 after 10 (1.6 .. 2 x the CPU float32 floor)"""
+    1e-5 gate before any GPU is involved.
+
+    Round 4 found where the HIP path's 1.6 .. 2 x of that floor came from: the K-mean.  A float summation of K = 20 outputs per
+    start point carries more rounding error than the mean leaves of the forward's own (averaged-out) error, and K chi is exactly
+    what the simplex inverse amplifies; summed in double and rounded once (kmean_kernel), the split-f16 forward -- the arithmetic
+    bench.py runs -- ends 2.6e-6 (10 iterations), 2.2e-6 (3) and 1.1e-6 (minibatch 1000) from the fp64 trajectories: inside the
+    literal 1e-5 gate and 4 .. 7 x BELOW the CPU float32 floor; the minibatch-100 case (kappa 4 344) ends inside the floor.  That
+    mode is therefore held to max(gate, 1 x floor).  The f32-MFMA and split-bf16 forwards keep their own accumulation error
+    (3.4e-5 after 10 iterations: a 432-step float fma chain per output, against 54 x 3 roundings of 32-deep exact products on the
+    f16 planes) and the round-3 bound of 3 x floor.  Table: profiles/r04_c3sub_error_table.md"""
     lerr, cerr, floor_l, floor_c = _c3sub_run(gpu_pkg, name, every_iter)
-    assert lerr <= max(1e-4, 3 * floor_l)
-    assert cerr <= max(1e-5, 3 * floor_c)
+    mult = 1 if fwd_mode == 3 else 3
+    assert lerr <= max(1e-4, mult * floor_l)
+    assert cerr <= max(1e-5, mult * floor_c)
 
 
 # ------------------------------------------------------------------ C3: the full-N ISA target -----
