@@ -182,6 +182,9 @@ def main():
                          "clock sampled meanwhile (0 = skip)")
     ap.add_argument("--no-f32-reference", action="store_true",
                     help="single GPU, f32-equivalent split forward: skip the strict-Float32 (forward mode 0) pass reported beside the headline")
+    ap.add_argument("--pullback", type=int, default=0, metavar="COLS",
+                    help="single GPU: also time the coordinate pullback d chi / d coords (isk_chicoords_pullback, the counterpart of the "
+                         "reference's sqpairdist_bwd_kernel!, src/utils/pairdists.jl:153-196) on COLS columns of xs; host buffers in and out")
     ap.add_argument("--no-sub-records", action="store_true", help="multi-GPU: skip the weak-scaling and full-batch sub-records")
     ap.add_argument("--train-bf16", action=argparse.BooleanOptionalAction, default=None,
                     help="wide networks (c5shard): training GEMMs on bf16 operands, f32 accumulate, f32 master weights.  Default: on for "
@@ -485,7 +488,7 @@ def main():
                        "forward_mode": {0: "f32", 1: "bf16x3", 2: "bf16", 3: "f16x2"}[args.forward_mode],
                        "parallelism": f"dp{world} over N" if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu,
-            "f32_reference": f32_reference, "sustained": sustained, "sub_records": sub_records,
+            "f32_reference": f32_reference, "sustained": sustained, "sub_records": sub_records, "pullback": pullback,
             "final_loss": iso.losses[-1],
         }
         return line
@@ -597,6 +600,23 @@ def main():
             arm("")
         except Exception as ex:      # noqa: BLE001
             f32_reference = {"error": str(ex)}
+
+    pullback = None
+    if world == 1 and not use_dp and args.pullback > 0:
+        try:
+            ncol = min(args.pullback, N)
+            xcols = np.asfortranarray(iso.data.coords[0][:, :ncol])
+            cot = np.asfortranarray(np.random.default_rng(0).normal(size=(widths[-1], ncol)).astype(np.float32))
+            pkg.chicoords_pullback(iso, xcols, cot)                       # warm-up (allocations, first launches)
+            reps, tp0 = 0, time.perf_counter()
+            while reps < 3 or time.perf_counter() - tp0 < 0.5:
+                g = pkg.chicoords_pullback(iso, xcols, cot)
+                reps += 1
+            dtp = (time.perf_counter() - tp0) / reps
+            pullback = {"columns": ncol, "ms_per_call": 1e3 * dtp, "columns_per_s": ncol / dtp, "finite": bool(np.all(np.isfinite(g))),
+                        "note": "isk_chicoords_pullback: coordinates and cotangents from host buffers, gradients back to the host (PCIe-inclusive)"}
+        except Exception as ex:      # noqa: BLE001
+            pullback = {"error": str(ex)}
 
     if rank == 0:
         cpu = None

@@ -173,6 +173,13 @@ int  isk_reset_opt_state(isk_engine* e);            /* Flux.setup(opt, model) */
  * identity.  Uploads, featurizes (pdist) and LayerNorm-standardises once. */
 int  isk_set_data(isk_engine* e, const float* xs, const float* ys, int64_t D, int64_t K, int64_t N);
 int  isk_set_data_dev(isk_engine* e, const float* xs_dev, const float* ys_dev, int64_t D, int64_t K, int64_t N);
+/* Data growth of adaptive sampling without re-uploading what is already resident: `iso.data = mergedata(iso.data, new)` of
+ * addcoords! (src/iso.jl:238, src/simulation.jl:162-185) and the `cutoff` window `iso.data = iso.data[end-cutoff+1:end]` of
+ * run_kde! (src/iso.jl:288-290).  Drops the first `drop_first` resident start points (with their K samples), then appends
+ * n_add new ones (xs (D, n_add), ys (D, K, n_add); NULL / 0: none).  Only the new columns cross PCIe; the resident ones move
+ * device-to-device.  Model, optimizer state and options stay; Koopman weights (isk_set_koopman_weights) are dropped as by
+ * isk_set_data.  ISK_ESTATE without resident data, ISK_EINVAL when nothing would be left or K / D differ. */
+int  isk_append_data(isk_engine* e, const float* xs, const float* ys, int64_t D, int64_t K, int64_t n_add, int64_t drop_first);
 int  isk_data_shape(isk_engine* e, int64_t* D, int64_t* K, int64_t* N);
 /* WeightedSamples (Girsanov reweighting), src/data.jl:187-215: expectation becomes sum_k w[k,n] f(y[k,n]) / K.
  * w is (1, K, N) column-major, i.e. [N][K]; NULL restores the plain K-mean. */

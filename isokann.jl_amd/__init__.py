@@ -15,6 +15,6 @@ from .api import (  # noqa: F401
     NesterovRegularized, OptSpec, SimulationData, TransformISA, TransformPseudoInv, TransformShiftscale, batch_grads, chicoords, chis,
     coords, densenet, featuredim, features, halfinds, identity, inputdim, isotarget, koopman, outputdim, pairnet,
     pairnet_widths, propcoords, propfeatures, run, train_batch, koopman_coords, chi_kchi, validationloss,
-    ValidationLossLogger, koopman_variance, lastcat, mergedata, set_data, save, load, chicoords_pullback, dchidx, data_from_trajectory, data_from_trajectories,
+    ValidationLossLogger, koopman_variance, lastcat, mergedata, set_data, append_data, save, load, chicoords_pullback, dchidx, data_from_trajectory, data_from_trajectories,
     WeightedSamples, set_koopman_weights, rates,
 )

@@ -656,10 +656,51 @@ def mergedata(d1: SimulationData, d2: SimulationData) -> SimulationData:
     return SimulationData(lastcat(d1.coords[0], d2.coords[0]), lastcat(d1.coords[1], d2.coords[1]), d1.featurizer)
 
 
+def _data_delta(old: SimulationData, new: SimulationData):
+    """(drop_first, n_add) when `new` is `old` minus its first start points plus appended ones -- what addcoords! and the cutoff
+    window of run_kde! produce (src/iso.jl:238,288-290) -- else None"""
+    (oxs, oys), (nxs, nys) = old.coords, new.coords
+    if oys.shape[:2] != nys.shape[:2] or oxs.shape[0] != nxs.shape[0]:
+        return None
+    no, nn = oxs.shape[1], nxs.shape[1]
+    if nn >= no and np.array_equal(nxs[:, :no], oxs) and np.array_equal(nys[:, :, :no], oys):
+        return 0, nn - no                                   # mergedata(old, extra)
+    if nn < no and np.array_equal(nxs, oxs[:, no - nn:]) and np.array_equal(nys, oys[:, :, no - nn:]):
+        return no - nn, 0                                   # old[end-cutoff+1:end]
+    return None
+
+
+def append_data(iso: Iso, xs_new=None, ys_new=None, drop_first: int = 0) -> Iso:
+    """addcoords! / the cutoff window (src/iso.jl:238,288-290) without re-uploading the resident start points: drop the first
+    `drop_first`, append the columns of xs_new (D, n), ys_new (D, K, n).  Only the new columns cross PCIe (isk_append_data)."""
+    oxs, oys = iso.data.coords
+    d, k, _ = oys.shape
+    n_add = 0 if xs_new is None else int(np.asarray(xs_new).shape[1])
+    if n_add:
+        xs_new = np.asfortranarray(np.asarray(xs_new, np.float32))
+        ys_new = np.asfortranarray(np.asarray(ys_new, np.float32))
+        if xs_new.shape[0] != d or ys_new.shape[:2] != (d, k) or ys_new.shape[2] != n_add:
+            raise ValueError("new samples must be xs (D, n), ys (D, K, n) with the D and K of the resident data")
+    capi.check(iso._lib.isk_append_data(iso._h, capi.ptr_f32(xs_new) if n_add else None, capi.ptr_f32(ys_new) if n_add else None,
+                                        d, k, n_add, int(drop_first)))
+    keep_x, keep_y = oxs[:, drop_first:], oys[:, :, drop_first:]
+    iso.data = SimulationData(lastcat(keep_x, xs_new) if n_add else keep_x, lastcat(keep_y, ys_new) if n_add else keep_y, iso.data.featurizer)
+    return iso
+
+
 def set_data(iso: Iso, data: SimulationData) -> Iso:
-    """`iso.data = newdata` (src/iso.jl:238,289): re-upload and re-featurize; model and optimizer state stay"""
+    """`iso.data = newdata` (src/iso.jl:238,289): model and optimizer state stay.  Data that only grew at the end or lost start
+    points at the front (addcoords!, the cutoff window) keep their resident part on the device (isk_append_data); anything else is
+    re-uploaded and re-featurized"""
     if featuredim(data) != iso.modelspec.widths[0]:
         raise ValueError("feature dimension of the new data does not match the model")
+    delta = _data_delta(iso.data, data) if iso.data is not None else None
+    if delta is not None:
+        drop, n_add = delta
+        no = iso.data.coords[0].shape[1]
+        append_data(iso, data.coords[0][:, no - drop:] if n_add else None, data.coords[1][:, :, no - drop:] if n_add else None, drop)
+        iso.data = data
+        return iso
     xs, ys = data.coords
     d, k, n = ys.shape
     capi.check(iso._lib.isk_set_data(iso._h, capi.ptr_f32(xs), capi.ptr_f32(ys), d, k, n))

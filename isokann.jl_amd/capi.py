@@ -86,6 +86,7 @@ PROTOTYPES = {
     "isk_reset_opt_state": (C.c_int, [_H]),
     "isk_set_data": (C.c_int, [_H, _f32p, _f32p, C.c_int64, C.c_int64, C.c_int64]),
     "isk_set_data_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
+    "isk_append_data": (C.c_int, [_H, _f32p, _f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "isk_set_koopman_weights": (C.c_int, [_H, _f32p, C.c_int64, C.c_int64]),
     "isk_data_shape": (C.c_int, [_H, _i64p, _i64p, _i64p]),
     "isk_features": (C.c_int, [_H, _f32p, C.c_int64, C.c_int64, _f32p]),

@@ -753,6 +753,32 @@ extern "C" int isk_set_data_dev(isk_engine* e, const float* xs, const float* ys,
     return set_data_impl(e, xs, ys, D, K, N, hipMemcpyDeviceToDevice);
 }
 
+// addcoords! / the cutoff window of run_kde! (src/iso.jl:238,288-290): the resident start points stay on the device
+extern "C" int isk_append_data(isk_engine* e, const float* xs, const float* ys, int64_t D, int64_t K, int64_t n_add, int64_t drop_first) {
+    CHK(need_data(e));
+    if (n_add < 0 || drop_first < 0 || drop_first > e->N) return fail(ISK_EINVAL, "bad row counts");
+    if (n_add > 0 && (!xs || !ys)) return fail(ISK_EINVAL, "null argument");
+    if (D != e->D || K != e->K) return fail(ISK_EINVAL, "D and K of the new samples must match the resident data");
+    const int64_t keep = e->N - drop_first, Nn = keep + n_add;
+    if (Nn < 1) return fail(ISK_EINVAL, "no start point would be left");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->side) HIPCHK(hipStreamSynchronize(e->side));
+    TmpBuf txs, tys;
+    HIPCHK(hipMalloc(&txs.p, (size_t)Nn * D * sizeof(float)));
+    HIPCHK(hipMalloc(&tys.p, (size_t)Nn * K * D * sizeof(float)));
+    float* nxs = (float*)txs.p;
+    float* nys = (float*)tys.p;
+    // N is the slowest axis of xs (D, N) and ys (D, K, N): the kept start points are one contiguous run of each
+    HIPCHK(hipMemcpyAsync(nxs, e->d_in_xs + (size_t)drop_first * D, (size_t)keep * D * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(nys, e->d_in_ys + (size_t)drop_first * K * D, (size_t)keep * K * D * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    if (n_add > 0) {
+        HIPCHK(hipMemcpyAsync(nxs + (size_t)keep * D, xs, (size_t)n_add * D * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(nys + (size_t)keep * K * D, ys, (size_t)n_add * K * D * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return set_data_impl(e, nxs, nys, D, K, Nn, hipMemcpyDeviceToDevice);          // (frees the old buffers, re-featurizes on the device)
+}
+
 // WeightedSamples(values, weights) (src/data.jl:187-215): weights (1, K, N) column-major == [N][K]
 extern "C" int isk_set_koopman_weights(isk_engine* e, const float* w, int64_t K, int64_t N) {
     CHK(need_data(e));

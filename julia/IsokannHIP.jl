@@ -155,12 +155,49 @@ upload_data!(m::HipModel, data) = begin                # SimulationData(xs, ys; 
 end
 
 """
-    gpu(iso::Iso{<:Flux.Chain}; device=0, featurize_every_iteration=true, forward_mode=3) -> Iso{HipModel}
-
-`gpu(iso)` (src/iso.jl:256): the model, the optimizer state and the data move into an engine on `device`.  `data.coords`
-(not the cached features) is uploaded: the featurizer runs on the GPU inside every iteration.
+`iso.data = new` where `new` is the resident data minus its first start points and / or plus appended ones -- what addcoords!
+(src/iso.jl:238) and the cutoff window of run_kde! (src/iso.jl:288-290) produce: `(drop_first, n_add)`, else `nothing`.
+The comparison is a host memcmp of the coordinates (~10 ms at villin size against ~0.3 s for re-uploading them).
 """
-function gpu(iso::Iso{<:Flux.Chain}; device=0, featurize_every_iteration=true, forward_mode=3, seed=0)
+function data_delta(old, new)
+    (oxs, oys), (nxs, nys) = old.coords, new.coords
+    (size(oys)[1:2] == size(nys)[1:2] && size(oxs, 1) == size(nxs, 1)) || return nothing
+    no, nn = size(oxs, 2), size(nxs, 2)
+    nn >= no && view(nxs, :, 1:no) == oxs && view(nys, :, :, 1:no) == oys && return (0, nn - no)
+    nn < no && nxs == view(oxs, :, no-nn+1:no) && nys == view(oys, :, :, no-nn+1:no) && return (no - nn, 0)
+    nothing
+end
+
+"only the NEW columns cross PCIe; the resident start points move device-to-device (isk_append_data)"
+function append_data!(m::HipModel, old, new, drop::Integer, nadd::Integer)
+    D, K, _ = size(old.coords[2]); no = size(old.coords[1], 2)
+    xs = Float32.(new.coords[1][:, no-drop+1:end]); ys = Float32.(new.coords[2][:, :, no-drop+1:end])
+    check(ccall((:isk_append_data, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int64, Int64, Int64, Int64),
+                m.h, nadd > 0 ? pointer(xs) : Ptr{Float32}(C_NULL), nadd > 0 ? pointer(ys) : Ptr{Float32}(C_NULL), D, K, nadd, drop))
+end
+
+"""
+    HipEngine(; device=0, featurize_every_iteration=true, forward_mode=3, seed=0)
+
+Names this engine as the destination of `gpu`: `gpu(iso, HipEngine())`.  A TWO-argument method on purpose: the reference's
+own `gpu(iso::Iso)` (src/iso.jl:256, Flux.gpu -> CUDA) keeps its meaning for everybody who merely loads this extension, and so
+does `Iso(data; gpu=true)` (src/iso.jl:24,39).
+"""
+Base.@kwdef struct HipEngine
+    device::Int = 0
+    featurize_every_iteration::Bool = true
+    forward_mode::Int = 3
+    seed::Int = 0
+end
+
+"""
+    gpu(iso::Iso{<:Flux.Chain}, eng::HipEngine) -> Iso{HipModel}
+
+The role of `gpu(iso)` (src/iso.jl:256) for this engine: the model, the optimizer state and the data move into an engine on
+`eng.device`.  `data.coords` (not the cached features) is uploaded: the featurizer runs on the GPU inside every iteration.
+"""
+function gpu(iso::Iso{<:Flux.Chain}, eng::HipEngine)
+    (; device, featurize_every_iteration, forward_mode, seed) = eng
     rule = iso.opt isa HipOpt ? iso.opt.rule : optimiser_rule(iso.opt)
     cfg, keep = make_config(iso.data, iso.model, rule, iso.target, iso.minibatch; featurize_every_iteration, device, seed, forward_mode)
     h = Ref{Ptr{Cvoid}}(C_NULL)
@@ -177,14 +214,14 @@ end
 """
     HipIso(data; opt=NesterovRegularized(), model=defaultmodel(data), target=nothing, minibatch=100, kwargs...)
 
-`Iso(data; ...)` (src/iso.jl:17-43) with `gpu = this engine`.
+`Iso(data; ...)` (src/iso.jl:17-43) on this engine (`Iso(data; gpu=true)` itself keeps meaning Flux.gpu).
 """
 function HipIso(data; opt=ISOKANN.NesterovRegularized(), model=ISOKANN.defaultmodel(data), target=nothing, minibatch=100,
                 loggers=Any[], device=0, featurize_every_iteration=true, forward_mode=3, seed=0, kwargs...)
     t = something(target, default_target(model))
     host = Iso(; model, opt=Flux.setup(opt, model), data, target=t, loggers=Vector{Any}(loggers), minibatch, kwargs...)
     host.opt = HipOpt(opt)                                  # fresh state: nothing to push
-    gpu(host; device, featurize_every_iteration, forward_mode, seed)
+    gpu(host, HipEngine(; device, featurize_every_iteration, forward_mode, seed))
 end
 
 # ---- optimizer state <-> Optimisers state tree (Flux.setup order == trainables order) ----------------------------------
@@ -255,7 +292,7 @@ cpu(iso::Iso{<:HipModel}) = Iso(sync_to_host!(iso.model), pull_opt_state(iso.mod
 
 "save(path, iso) (src/iso.jl:405-408) goes through cpu(iso): what JLD2 serialises contains no Ptr{Cvoid}"
 save(path::String, iso::Iso{<:HipModel}) = save(path, cpu(iso))
-# load(path) returns the CPU Iso (src/iso.jl:417-420); `gpu(load(path))` puts it back on the engine.
+# load(path) returns the CPU Iso (src/iso.jl:417-420); `gpu(load(path), HipEngine())` puts it back on the engine.
 
 # ---------------------------------------------------------------------------------------------------------------------
 # the generic functions of the train step
@@ -315,11 +352,17 @@ function chicoords(iso::Iso{<:HipModel}, xs)                   # src/iso.jl:211
 end
 
 # `Iso` is a mutable struct: `iso.minibatch = mb` (src/iso.jl:10) and `iso.data = newdata` (src/iso.jl:238,289: adaptive
-# sampling re-slices / appends) are legal in the reference; forward both to the engine FIRST, the field follows on success
+# sampling appends start points and cuts a window off the front) are legal in the reference; forward both to the engine
+# FIRST, the field follows on success.  Data that only grew at the end / lost start points at the front keep their resident
+# part on the device (each run_kde! generation would otherwise re-upload the whole set: 1.5 GB at villin size)
 function Base.setproperty!(iso::Iso{<:HipModel}, f::Symbol, v)
     m = getfield(iso, :model)
     f === :minibatch && check(ccall((:isk_set_minibatch, LIB[]), Cint, (Ptr{Cvoid}, Int32), m.h, v))
-    f === :data && upload_data!(m, v)
+    if f === :data
+        old = getfield(iso, :data)
+        d = data_delta(old, v)
+        d === nothing ? upload_data!(m, v) : append_data!(m, old, v, d[1], d[2])
+    end
     setfield!(iso, f, convert(fieldtype(typeof(iso), f), v))
 end
 

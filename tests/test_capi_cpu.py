@@ -133,6 +133,137 @@ def test_config_struct_agrees_between_header_ctypes_and_julia_shim(pkg):
     assert called and called <= set(pkg.capi.PROTOTYPES), called - set(pkg.capi.PROTOTYPES)
 
 
+# ---- types across the three hand-written mirrors of the C ABI: the header, capi.py (ctypes) and julia/IsokannHIP.jl (which no
+# toolchain here can execute).  Every type is reduced to a kind: the width / signedness / pointee that the calling convention sees.
+_C_KINDS = [
+    (r"^(const\s+)?isk_engine\s*\*\s*\*$", "handle*"), (r"^(const\s+)?isk_engine\s*\*$", "handle"),
+    (r"^(const\s+)?isk_config\s*\*$", "config*"),
+    (r"^(const\s+)?int32_t\s*\*\s*const\s*\*$", "i32**"), (r"^(const\s+)?int32_t\s*\*$", "i32*"), (r"^(const\s+)?int64_t\s*\*$", "i64*"),
+    (r"^(const\s+)?float\s*\*$", "f32*"), (r"^(const\s+)?double\s*\*$", "f64*"), (r"^(const\s+)?uint8_t\s*\*$", "u8*"),
+    (r"^(const\s+)?char\s*\*$", "cstr"), (r"^(const\s+)?void\s*\*\s*\*$", "ptr*"), (r"^(const\s+)?void\s*\*$", "ptr"),
+    (r"^int32_t$", "i32"), (r"^int$", "i32"), (r"^int64_t$", "i64"), (r"^uint64_t$", "u64"), (r"^float$", "f32"), (r"^double$", "f64"),
+    (r"^void$", "void"),
+]
+
+
+def _c_kind(t):
+    t = re.sub(r"\s+", " ", t.strip())
+    for pat, kind in _C_KINDS:
+        if re.match(pat, t):
+            return kind
+    raise AssertionError("unmapped C type: %r" % t)
+
+
+def _header_prototypes(hdr):
+    """name -> (return kind, [argument kinds]) of every function declared in the header; an array parameter is a pointer"""
+    code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    out = {}
+    for m in re.finditer(r"^\s*((?:const\s+)?[A-Za-z_][A-Za-z0-9_]*(?:\s*\*)?)\s+(isk_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", code, flags=re.M | re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        kinds = []
+        for a in [x.strip() for x in args.replace("\n", " ").split(",")]:
+            if a in ("", "void"):
+                continue
+            am = re.match(r"^(.*?)([A-Za-z_][A-Za-z0-9_]*)?\s*(\[[^\]]*\])?$", a)
+            base, arr = am.group(1).strip(), am.group(3)
+            if not base:                                   # an unnamed parameter: the whole thing is the type
+                base = a
+            kinds.append(_c_kind(base + ("*" if arr else "")))
+        out[name] = (_c_kind(ret), kinds)
+    return out
+
+
+def _ctypes_kind(t):
+    if t is None:
+        return "void"
+    table = {C.c_int: "i32", C.c_int32: "i32", C.c_int64: "i64", C.c_uint64: "u64", C.c_float: "f32", C.c_double: "f64", C.c_char_p: "cstr",
+             C.c_void_p: "ptr"}
+    if t in table:
+        return table[t]
+    if hasattr(t, "_type_") and not isinstance(t._type_, str):                  # POINTER(x)
+        inner = t._type_
+        if inner is C.c_void_p:
+            return "ptr*"
+        if hasattr(inner, "_fields_"):
+            return "config*"
+        if hasattr(inner, "_type_") and not isinstance(inner._type_, str):    # POINTER(POINTER(c_int32))
+            return _ctypes_kind(inner)[:-1] + "**"
+        return {"i32": "i32*", "i64": "i64*", "f32": "f32*", "f64": "f64*", "u8": "u8*"}[
+            {C.c_int32: "i32", C.c_int: "i32", C.c_int64: "i64", C.c_float: "f32", C.c_double: "f64", C.c_uint8: "u8"}[inner]]
+    raise AssertionError("unmapped ctypes type: %r" % (t,))
+
+
+_JL_KINDS = {"Ptr{Cvoid}": "ptr", "Ref{Ptr{Cvoid}}": "ptr*", "Ptr{Ptr{Cvoid}}": "ptr*", "Ref{IskConfig}": "config*", "Ptr{Float32}": "f32*",
+             "Ptr{Float64}": "f64*", "Ref{Float64}": "f64*", "Ptr{Int32}": "i32*", "Ptr{Ptr{Int32}}": "i32**", "Ref{Int64}": "i64*",
+             "Ptr{Int64}": "i64*", "Int64": "i64", "Int32": "i32", "Cint": "i32", "Cstring": "cstr", "Float32": "f32", "Cvoid": "void"}
+
+
+def _same_kind(a, b):
+    """an opaque handle is a void pointer on the binding side, and so is a typed DEVICE pointer (ctypes passes raw addresses for the
+    `_dev` parameters); two TYPED pointers must agree in their pointee"""
+    norm = {"handle": "void*", "handle*": "void**", "ptr": "void*", "ptr*": "void**", "config*": "config*"}
+    a, b = norm.get(a, a), norm.get(b, b)
+    if a == b:
+        return True
+    level = lambda k: len(k) - len(k.rstrip("*"))
+    return (a.rstrip("*") == "void" or b.rstrip("*") == "void") and level(a) == level(b) and level(a) > 0
+
+
+def test_argument_types_agree_between_header_ctypes_and_julia_shim(pkg):
+    """the NAMES were checked above; this is the calling convention: field types of isk_config and the argument tuple of every
+    prototype, header vs capi.PROTOTYPES vs each `ccall` of julia/IsokannHIP.jl"""
+    hdr = open(os.path.join(ROOT, "include", "isokann_hip.h")).read()
+    protos = _header_prototypes(hdr)
+    assert set(protos) == set(pkg.capi.PROTOTYPES), set(protos) ^ set(pkg.capi.PROTOTYPES)
+    for name, (ret, args) in protos.items():
+        cres, cargs = pkg.capi.PROTOTYPES[name]
+        assert _same_kind(ret, _ctypes_kind(cres)), (name, ret, cres)
+        assert len(args) == len(cargs), (name, args, cargs)
+        for i, (h, c) in enumerate(zip(args, cargs)):
+            assert _same_kind(h, _ctypes_kind(c)), (name, i, h, c)
+    # isk_config: C field types vs ctypes vs Julia
+    start = hdr.index("typedef struct isk_config {") + len("typedef struct isk_config {")
+    body = re.sub(r"/\*.*?\*/", "", hdr[start:hdr.index("} isk_config;")], flags=re.S)
+    cfields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        tm = re.match(r"^((?:const\s+)?[A-Za-z_][A-Za-z0-9_]*\s*\*?)\s*(.*)$", decl)
+        for part in tm.group(2).split(","):
+            pm = re.match(r"^\s*(\*?)\s*([A-Za-z_][A-Za-z0-9_]*)\s*(\[[^\]]*\])?\s*$", part)
+            cfields.append((pm.group(2), _c_kind(tm.group(1) + pm.group(1)) + ("[]" if pm.group(3) else "")))
+    ct = []
+    for fname, ftype in pkg.capi.Config._fields_:
+        ct.append((fname, (_ctypes_kind(ftype._type_) + "[]") if hasattr(ftype, "_length_") else _ctypes_kind(ftype)))
+    assert cfields == ct, [x for x in zip(cfields, ct) if x[0] != x[1]]
+    jl = open(os.path.join(ROOT, "julia", "IsokannHIP.jl")).read()
+    sbody = jl[jl.index("struct IskConfig"):]
+    sbody = re.sub(r"#.*", "", sbody[:sbody.index("\nend")])
+    jf = re.findall(r"([A-Za-z_][A-Za-z0-9_]*)::((?:NTuple\{[^}]*\})|(?:[A-Za-z0-9]+(?:\{[A-Za-z0-9]+\})?))", sbody)
+    jl_field_kind = {"Int32": "i32", "UInt64": "u64", "Float32": "f32", "Ptr{Int32}": "i32*", "NTuple{MAXL + 1,Int32}": "i32[]"}
+    assert [(n, jl_field_kind[t]) for n, t in jf] == cfields
+    assert "const MAXL = %d" % pkg.capi.ISK_MAX_LAYERS in jl
+    # every ccall of the shim: return type and argument tuple against the header's prototype
+    calls = re.findall(r"ccall\(\((:isk_[a-z0-9_]+|f), LIB\[\]\),\s*([A-Za-z]+),\s*\(([^()]*(?:\{[^()]*\}[^()]*)*)\)", jl)
+    assert len(calls) >= 25
+    seen = set()
+    for sym, ret, tup in calls:
+        jargs = [t.strip() for t in re.split(r",\s*(?![^{]*\})", tup) if t.strip()]
+        names = [sym[1:]] if sym != "f" else ["isk_chis", "isk_koopman"]           # fetch(f, iso) is called with these two
+        for name in names:
+            hret, hargs = protos[name]
+            seen.add(name)
+            assert _same_kind(hret, _JL_KINDS[ret]), (name, hret, ret)
+            assert len(hargs) == len(jargs), (name, hargs, jargs)
+            for i, (h, j) in enumerate(zip(hargs, jargs)):
+                assert _same_kind(h, _JL_KINDS[j]), (name, i, h, j)
+    assert {"isk_create", "isk_set_data", "isk_append_data", "isk_run", "isk_dp_run_all", "isk_set_opt_state"} <= seen
+    # the engine must not take over the reference's one-argument gpu(iso) (src/iso.jl:256): opt-in through a second argument
+    assert re.search(r"^function gpu\(iso::Iso\{<:Flux\.Chain\}, eng::HipEngine\)", jl, flags=re.M)
+    assert not re.search(r"^(function )?gpu\(iso::Iso(\{[^}]*\})?\s*[;)]", jl, flags=re.M)
+
+
 def test_options_are_per_engine_and_validated(pkg):
     lib = pkg.capi.load()
     assert lib.isk_set_option(None, b"train_graph", 0) == pkg.capi.EINVAL

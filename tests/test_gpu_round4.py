@@ -1,0 +1,113 @@
+"""Round-4 additions at the boundary: data growth without re-upload (isk_append_data), the coordinate pullback at villin shape,
+and the documented shape limits as error codes."""
+import numpy as np
+import pytest
+
+from oracle import isokann_oracle as O
+from tests import benchshape_cases as bc
+
+pytestmark = [pytest.mark.gpu, pytest.mark.own_fwd_mode, pytest.mark.usefixtures("fwd_mode")]
+
+
+def _model(pkg, widths, seed, ln=True):
+    rng = np.random.default_rng(seed)
+    om = O.glorot_model(widths, rng, layernorm=ln)
+    for b in om.b:
+        b[...] = 0.1 * rng.normal(size=b.shape)
+    m = pkg.densenet(om.widths, layernorm=ln)
+    m.params = om.get_flat().astype(np.float32)
+    return om, m
+
+
+@pytest.mark.parametrize("every_iter", [False, True])
+def test_append_data_equals_a_full_upload(gpu_pkg, every_iter):
+    """addcoords! / the cutoff window of run_kde! (src/iso.jl:238,288-290; src/simulation.jl:162-185): `iso.data = ...` with data
+    that grew at the end and lost start points at the front keeps the resident part on the device (isk_append_data).  The engine
+    must then be in exactly the state a full isk_set_data of the same data leaves: chi, K chi and a training epoch bit for bit."""
+    pkg = gpu_pkg
+    A, F, K, nout = 18, 70, 4, 2
+    xs, ys = O.synthetic_coords(A, 300, K, seed=2)
+    pairs = O.random_pairs(A, F, seed=3)
+    om, _ = _model(pkg, [F, 20, 6, nout], seed=4)
+    mk = lambda x, y: pkg.SimulationData(x, y, pkg.FeaturesPairs(pairs))
+    kw = dict(opt=pkg.AdamRegularized(), minibatch=64, target=pkg.TransformISA(), featurize_every_iteration=every_iter)
+    grown = pkg.Iso(mk(xs[:, :200], ys[:, :, :200]), model=_model(pkg, [F, 20, 6, nout], seed=4)[1], **kw)
+    # (1) addcoords!: 60 new start points behind the resident 200
+    pkg.set_data(grown, mk(xs[:, :260], ys[:, :, :260]))
+    assert grown.data.coords[0].shape[1] == 260
+    # (2) the cutoff window: the last 180 of them ...   (3) ... and both at once through the explicit entry
+    pkg.set_data(grown, mk(xs[:, 80:260], ys[:, :, 80:260]))
+    pkg.append_data(grown, xs[:, 260:300], ys[:, :, 260:300], drop_first=20)
+    np.testing.assert_array_equal(grown.data.coords[0], np.asarray(xs[:, 100:300], np.float32))
+    full = pkg.Iso(mk(xs[:, 100:300], ys[:, :, 100:300]), model=_model(pkg, [F, 20, 6, nout], seed=4)[1], **kw)
+    np.testing.assert_array_equal(pkg.chis(grown), pkg.chis(full))
+    np.testing.assert_array_equal(pkg.koopman(grown), pkg.koopman(full))
+    perms = np.stack([np.random.default_rng(7).permutation(200) for _ in range(2)]).astype(np.int32)
+    pkg.run(grown, 2, 1, perms=perms)
+    pkg.run(full, 2, 1, perms=perms)
+    assert grown.losses == full.losses
+    np.testing.assert_array_equal(grown.model.get_params(), full.model.get_params())
+    # error codes: nothing left, mismatching K
+    with pytest.raises(pkg.capi.IskError) as ei:
+        pkg.append_data(grown, None, None, drop_first=200)
+    assert ei.value.status == pkg.capi.EINVAL
+    with pytest.raises(ValueError):
+        pkg.append_data(grown, xs[:, :5], ys[:, :3, :5])
+    grown.close(); full.close()
+
+
+def test_villin_shape_pullback_matches_torch_autograd(gpu_pkg):
+    """d chi / d coords (the counterpart of the reference's sqpairdist_bwd_kernel!, src/utils/pairdists.jl:153-196, through
+    LayerNorm and the MLP) at the VILLIN shape -- 591 atoms, the bench's 1700 pairs, [1700,142,12,3]+LN -- for eight columns
+    against torch's fp64 autograd of the same network on the float32 coordinates: 2e-5 of the largest gradient entry"""
+    import torch
+    pkg = gpu_pkg
+    A, F, nout, ncol = bc.C3_ATOMS, bc.C3_F, 3, 8
+    xs, ys = O.synthetic_coords(A, 32, 2, seed=5)
+    pairs = O.random_pairs(A, F, seed=0)
+    om, m = _model(pkg, [F, 142, 12, nout], seed=21)
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=m, target=pkg.TransformISA(), minibatch=0)
+    cot = np.random.default_rng(1).normal(size=(nout, ncol))
+    got = pkg.chicoords_pullback(iso, xs[:, :ncol], cot)
+    x32 = np.asarray(xs[:, :ncol], np.float32).astype(np.float64)
+    P = torch.tensor(np.asarray(pairs))
+    want = np.zeros_like(x32)
+    for n in range(ncol):
+        xt = torch.tensor(x32[:, n], requires_grad=True)
+        c = xt.reshape(-1, 3)
+        a = torch.sqrt(((c[P[:, 0]] - c[P[:, 1]]) ** 2).sum(dim=1))
+        mu = a.mean()
+        var = ((a - mu) ** 2).mean()
+        a = (a - mu) / torch.sqrt(var + om.ln_eps ** 2) * torch.tensor(om.ln_scale) + torch.tensor(om.ln_bias)
+        for W, b, act in zip(om.W, om.b, om.acts()):
+            z = torch.tensor(W) @ a + torch.tensor(b)
+            a = torch.sigmoid(z) if act == "sigmoid" else z
+        (a * torch.tensor(cot[:, n])).sum().backward()
+        want[:, n] = xt.grad.numpy()
+    scale = np.abs(want).max()
+    assert scale > 0
+    np.testing.assert_allclose(got, want, atol=2e-5 * scale, rtol=2e-4)
+    iso.close()
+
+
+def test_documented_shape_limits_are_error_codes(gpu_pkg):
+    """what the kernels do not cover is refused with ISK_EUNSUPPORTED at isk_create / at the call, never computed wrongly:
+    TransformISA beyond 8 outputs (the reference's fixperm takes any n, src/isotarget.jl:120-127: d! permutations), a layer wider
+    than 4096, the coordinate pullback beyond 2048 features (src/utils/pairdists.jl:153-196 has no such bound)"""
+    pkg = gpu_pkg
+    rng = np.random.default_rng(0)
+    xs, ys = rng.normal(size=(12, 40)), rng.normal(size=(12, 2, 40))
+    with pytest.raises(pkg.capi.IskError) as ei:
+        pkg.Iso(pkg.SimulationData(xs, ys, pkg.identity), model=pkg.densenet([12, 16, 9], layernorm=True), target=pkg.TransformISA(), minibatch=0)
+    assert ei.value.status == pkg.capi.EUNSUPPORTED
+    with pytest.raises(pkg.capi.IskError) as ei:
+        pkg.Iso(pkg.SimulationData(xs, ys, pkg.identity), model=pkg.densenet([12, 4100, 1], layernorm=False), minibatch=0)
+    assert ei.value.status == pkg.capi.EUNSUPPORTED
+    F = 2100
+    xw, yw = rng.normal(size=(F, 8)), rng.normal(size=(F, 2, 8))
+    iso = pkg.Iso(pkg.SimulationData(xw, yw, pkg.identity), model=pkg.densenet([F, 24, 4, 1], layernorm=True), minibatch=0)
+    assert np.all(np.isfinite(pkg.chis(iso)))                       # the forward itself covers this width
+    with pytest.raises(pkg.capi.IskError) as ei:
+        pkg.chicoords_pullback(iso, xw[:, :2], np.ones((1, 2)))
+    assert ei.value.status == pkg.capi.EUNSUPPORTED
+    iso.close()
