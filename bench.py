@@ -462,6 +462,8 @@ def main():
                                           "allreduce_ms_per_epoch": per_it.get("allreduce")}
                 if args.train_bf16:             # the layered path's GEMMs then run on the bf16 pipe
                     roof["training_chain"]["frac_of_2500_bf16_mfma"] = tflops / (tr_ms * 1e-3) / 2500e12
+    pullback = None                      # (filled in further down; build_line may be called before that by the watchdog's headline)
+
     def build_line(cpu, f32_reference, sustained, sub_records):
         # Koopman samples of the problem the ranks solve TOGETHER per step: the global N in strong scaling, world * N in weak;
         # a --shard-of rehearsal reports its own shard only (one rank of P: not a whole-job number)
@@ -601,7 +603,6 @@ def main():
         except Exception as ex:      # noqa: BLE001
             f32_reference = {"error": str(ex)}
 
-    pullback = None
     if world == 1 and not use_dp and args.pullback > 0:
         try:
             ncol = min(args.pullback, N)

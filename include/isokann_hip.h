@@ -146,7 +146,8 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *   fwd_waves_per_simd  1        residency of the f32-MFMA forward kernel
  *   bf16_skew           1        split-bf16 forward: the second wave of a SIMD converts in the first half of a stage
  *   dense_groups        1        wide networks, bf16 forward: one grouped launch per layer
- *   layered_blas        1        wide networks, f32 training: rocBLAS sgemm for the plain layer GEMMs (0: in-house kernels)
+ *   layered_blas        0        wide networks, f32 training: 1 = rocBLAS sgemm for the plain layer GEMMs; 0 = the in-house MFMA kernels
+ *                                in Float32 arithmetic (fused epilogues, grouped launches: the faster path, and no vendor BLAS)
  *   train_bf16          0        wide networks: training GEMMs on bf16 operands (f32 master weights, f32 accumulate)
  *   wide_fused          1        wide networks, plain-bf16 forward (forward_mode 2): one fused kernel, activations in LDS
  *   dp_force_coll       0        issue the native collectives on a one-rank communicator (tests)

@@ -1065,10 +1065,10 @@ void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nsl
 // stores are acknowledged: publishing from every step cost ~2 us per step, 0.2 ms per iteration at minibatch = 100)
 // layered path without LayerNorm: rocBLAS and the bf16 GEMMs read theta (or their own images of it), so the forward weight
 // images are folded once, behind the epoch's last step (every epoch driver asks here: the per-step fold is ~38 us at C5)
-bool epoch_lazy_fold(isk_engine* e) { return e->layered && !e->cfg.layernorm && (bf16_train_active(e) || blas_ready(e)); }
+bool epoch_lazy_fold(isk_engine* e) { return e->layered && !e->cfg.layernorm && (bf16_train_active(e) || mfma32_train_active(e) || blas_ready(e)); }
 // ... and not at all where nothing reads them: the fused wide forward streams its own fragment-linear images of theta and the bf16
 // GEMMs theirs (a forward of foreign rows through the generic layered kernels folds on demand: wt_dirty stays set)
-bool epoch_no_fold(isk_engine* e) { return epoch_lazy_fold(e) && e->xh16 && bf16_train_active(e); }
+bool epoch_no_fold(isk_engine* e) { return epoch_lazy_fold(e) && e->xh16 && (bf16_train_active(e) || mfma32_train_active(e)); }
 
 void launch_opt(isk_engine* e, float gscale, bool fold, bool capturing, bool publish) {
     OptArgs a;

@@ -96,6 +96,8 @@ struct isk_engine {
     // transposed) and of the weights, allocated on first use for the resident N
     struct Bf16Train {
         long long rows = 0;                           // Bp the buffers were sized for (0: not allocated)
+        int esz = 0;                                  // bytes per image element they were sized for: 2 (bf16) or 4 (Float32 arithmetic)
+        int wt_esz = 0;                               // element size of what the Wt images currently hold
         void *xb = nullptr, *xt = nullptr;            // [Bp][Fp], [F + 1][Bp]
         void* a16[ISK_MAX_LAYERS] = {nullptr};        // act_l          [Bp][pad32(N_l)]
         void* at16[ISK_MAX_LAYERS] = {nullptr};       // act_l'         [N_l + 1][Bp], row N_l = ones
@@ -250,6 +252,7 @@ int forward_layered(isk_engine* e, const float* X, long long S, float* out, floa
 void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float inv_div);
 void bf16_train_release(isk_engine* e);
 bool bf16_train_active(const isk_engine* e);
+bool mfma32_train_active(const isk_engine* e);   // layered f32 training on the in-house NT GEMMs in Float32 arithmetic (no rocBLAS)
 int bf16_weight_images_alloc(isk_engine* e);             // isk_create, layered engines: the [max(N, 512)][pad32 K] bf16 images W_l'
 void bf16_weight_images_ensure(isk_engine* e, bool want_wt, bool want_wf);           // refresh them if theta changed since they were built
 bool blas_ready(isk_engine* e);

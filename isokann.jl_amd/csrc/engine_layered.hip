@@ -215,6 +215,9 @@ static bool launch_grads_layered_blas(isk_engine* e, const int* d_idx, int B, fl
 // f32 accumulate, f32 master weights and optimizer.  kernels_gemm16.hip explains the operand images.
 // ---------------------------------------------------------------------------------------
 bool bf16_train_active(const isk_engine* e) { return e->layered && e->opt.train_bf16 != 0; }
+// ... and the same kernels in Float32 arithmetic (f32 fragments, v_mfma_f32_16x16x4_f32, f32 images): the DEFAULT of the layered
+// training path since round 4 -- option layered_blas = 1 selects rocBLAS sgemm instead
+bool mfma32_train_active(const isk_engine* e) { return e->layered && !e->opt.train_bf16 && !e->opt.layered_blas; }
 
 // the per-batch images (the weight images belong to the engine, not to the data)
 void bf16_train_release(isk_engine* e) {
@@ -225,12 +228,12 @@ void bf16_train_release(isk_engine* e) {
         free_dev(b.a16[l]); free_dev(b.at16[l]); free_dev(b.d16[l]); free_dev(b.dt16[l]);
         b.a16[l] = b.at16[l] = b.d16[l] = b.dt16[l] = nullptr;
     }
-    b.rows = 0;
+    b.rows = 0; b.esz = 0;
 }
 
 int bf16_weight_images_alloc(isk_engine* e) {
     for (int l = 0; l < e->L; ++l) {
-        const size_t bytes = (size_t)std::max(e->cfg.widths[l + 1], 512) * isk_pad32(e->cfg.widths[l]) * 2;    // rows >= N stay zero
+        const size_t bytes = (size_t)std::max(e->cfg.widths[l + 1], 512) * isk_pad32(e->cfg.widths[l]) * 4;    // rows >= N stay zero; sized for f32 elements
         if (hipMalloc(&e->b16.Wt[l], bytes) != hipSuccess) return ISK_ENOMEM;
         (void)hipMemset(e->b16.Wt[l], 0, bytes);
         if (l + 1 < e->L && e->cfg.widths[l + 1] <= 512) {           // hidden layer the fused wide forward can take: 512 (padded) columns
@@ -245,8 +248,9 @@ int bf16_weight_images_alloc(isk_engine* e) {
 
 // the row-major images feed the training GEMMs (rebuilt every optimizer step), the fragment-linear ones the fused forward
 // (rebuilt once per forward after a parameter change)
-static bool weight_image_args(isk_engine* e, bool want_wt, bool want_wf, WtImagesArgs& w) {
+static bool weight_image_args(isk_engine* e, bool want_wt, bool want_wf, WtImagesArgs& w, int wt_esz = 2) {
     auto& b = e->b16;
+    if (want_wt && b.wt_esz != wt_esz) b.wt_dirty = true;            // the images hold the other element type
     want_wt = want_wt && b.wt_dirty && b.Wt[0];
     want_wf = want_wf && b.wf_dirty && b.Wf[0];
     if (!want_wt && !want_wf) return false;
@@ -257,7 +261,8 @@ static bool weight_image_args(isk_engine* e, bool want_wt, bool want_wf, WtImage
         w.Wt[l] = want_wt ? b.Wt[l] : nullptr;
         w.Wf[l] = want_wf ? b.Wf[l] : nullptr;
     }
-    if (want_wt) b.wt_dirty = false;
+    w.wt_f32 = wt_esz == 4;
+    if (want_wt) { b.wt_dirty = false; b.wt_esz = wt_esz; }
     if (want_wf) b.wf_dirty = false;
     return true;
 }
@@ -269,38 +274,46 @@ void bf16_weight_images_ensure(isk_engine* e, bool want_wt, bool want_wf) {
 __global__ void fill_u16_kernel(unsigned short* p, long long n, unsigned short v) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = v;
 }
+__global__ void fill_f32_kernel(float* p, long long n, float v) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = v;
+}
 
-static bool bf16_train_ensure(isk_engine* e, long long Bp) {
+// esz: bytes per image element (2 = bf16, 4 = Float32 arithmetic)
+static bool bf16_train_ensure(isk_engine* e, long long Bp, int esz) {
     auto& b = e->b16;
-    if (b.rows >= Bp) return true;
+    if (b.rows >= Bp && b.esz == esz) return true;
     (void)hipStreamSynchronize(e->stream);
     bf16_train_release(e);
     const long long rows = isk_pad32((int)std::max<long long>(Bp, std::min<long long>(e->N, 4096)));     // usual batches without re-allocation
     const int L = e->L;
     bool ok = true;
     auto alloc = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; if (ok) (void)hipMemsetAsync(*p, 0, bytes, e->stream); };
-    alloc(&b.xb, (size_t)rows * e->Fp * 2);
-    alloc(&b.xt, (size_t)(e->F + 1) * rows * 2);
+    alloc(&b.xb, (size_t)rows * e->Fp * esz);
+    alloc(&b.xt, (size_t)(e->F + 1) * rows * esz);
     for (int l = 0; l < L && ok; ++l) {
         const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];
-        alloc(&b.a16[l], (size_t)rows * isk_pad32(N) * 2);
-        alloc(&b.at16[l], (size_t)(N + 1) * rows * 2);
-        alloc(&b.d16[l], (size_t)rows * isk_pad32(N) * 2);
-        alloc(&b.dt16[l], (size_t)N * rows * 2);
+        alloc(&b.a16[l], (size_t)rows * isk_pad32(N) * esz);
+        alloc(&b.at16[l], (size_t)(N + 1) * rows * esz);
+        alloc(&b.d16[l], (size_t)rows * isk_pad32(N) * esz);
+        alloc(&b.dt16[l], (size_t)N * rows * esz);
         (void)K;
-        if (ok) hipLaunchKernelGGL(fill_u16_kernel, dim3(64), dim3(256), 0, e->stream, (unsigned short*)b.at16[l] + (size_t)N * rows, rows,
-                                   (unsigned short)0x3F80);           // the row of ones (bf16 1.0) behind the N activation rows
+        // the row of ones behind the N activation rows
+        if (ok && esz == 2) hipLaunchKernelGGL(fill_u16_kernel, dim3(64), dim3(256), 0, e->stream, (unsigned short*)b.at16[l] + (size_t)N * rows, rows,
+                                               (unsigned short)0x3F80);
+        if (ok && esz == 4) hipLaunchKernelGGL(fill_f32_kernel, dim3(64), dim3(256), 0, e->stream, (float*)b.at16[l] + (size_t)N * rows, rows, 1.0f);
     }
     if (ok && e->cfg.layernorm) alloc((void**)&b.G0, (size_t)(e->F + 1) * e->cfg.widths[1] * sizeof(float));
     if (!ok) { bf16_train_release(e); return false; }
-    b.rows = rows;
+    b.rows = rows; b.esz = esz;
     return true;
 }
 
-static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, float inv_div) {
+// f32math: the same chain of fused products in Float32 arithmetic (f32 images, v_mfma_f32_16x16x4_f32)
+static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, float inv_div, const int f32math) {
     const int L = e->L;
     const int Bp = isk_pad32(B);
-    if (!bf16_train_ensure(e, Bp)) return false;
+    const int esz = f32math ? 4 : 2;
+    if (!bf16_train_ensure(e, Bp, esz)) return false;
     auto& b = e->b16;
     const long long ldB = b.rows;                    // row length of the transposed images
     hipStream_t st = e->stream;
@@ -308,15 +321,15 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
     {
         // the batch images and (behind an optimizer step: always) the row-major weight images, one launch
         WtImagesArgs w;
-        if (weight_image_args(e, true, false, w)) isk_launch_prep_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, w, st);
-        else isk_launch_gather_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, st);
+        if (weight_image_args(e, true, false, w, esz)) isk_launch_prep_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, f32math, w, st);
+        else isk_launch_gather_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, f32math, st);
     }
     bool ok = true;
     for (int l = 0; l < L && ok; ++l) {
         const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];
         Gemm16Args g = {};
-        g.A = l == 0 ? b.xb : b.a16[l - 1]; g.lda = l == 0 ? e->Fp : isk_pad32(K); g.a_f32 = 0;
-        g.B = b.Wt[l]; g.ldb = isk_pad32(K); g.b_f32 = 0;
+        g.A = l == 0 ? b.xb : b.a16[l - 1]; g.lda = l == 0 ? e->Fp : isk_pad32(K); g.a_f32 = f32math;
+        g.B = b.Wt[l]; g.ldb = isk_pad32(K); g.b_f32 = f32math; g.f32math = f32math;
         g.M = B; g.Nn = N; g.Kc = isk_pad32(K); g.kvalid = g.Kc;
         g.epi = ISK_G16_FWD;
         g.bias = (l == 0 && ln) ? e->d_bias[0] : e->d_theta + e->off_b[l];
@@ -329,14 +342,14 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
     // (the last layer + loss + both deltas as ONE "head" kernel was built and measured: 59 us against the 45 us of the four launches
     // it replaced -- eight rows per wave are eight dependent round trips; not kept)
     isk_launch_loss_delta16(e->d_lz[L - 1], isk_pad16(e->nout), e->d_target, e->d_lossw, d_idx, B, Bp, e->nout, inv_div, e->cfg.lastactivation,
-                            b.d16[L - 1], isk_pad32(e->nout), b.dt16[L - 1], ldB, e->d_grad + e->nparams, e->d_rank_err, st);
+                            b.d16[L - 1], isk_pad32(e->nout), b.dt16[L - 1], ldB, f32math, e->d_grad + e->nparams, e->d_rank_err, st);
     for (int l = L - 1; l >= 0 && ok; --l) {
         const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];
         const bool ln0 = l == 0 && ln;
         Gemm16Args pair[3] = {};
         Gemm16Args& g = pair[0];
-        g.A = l == 0 ? b.xt : b.at16[l - 1]; g.lda = ldB; g.a_f32 = 0;
-        g.B = b.dt16[l]; g.ldb = ldB; g.b_f32 = 0;
+        g.A = l == 0 ? b.xt : b.at16[l - 1]; g.lda = ldB; g.a_f32 = f32math;
+        g.B = b.dt16[l]; g.ldb = ldB; g.b_f32 = f32math; g.f32math = f32math;
         g.M = K + 1; g.Nn = N; g.Kc = Bp; g.kvalid = Bp;
         g.epi = ISK_G16_DW;
         g.gout = ln0 ? b.G0 : e->d_grad + e->off_W[l]; g.gld = N;           // row K lands on b_l: Flux keeps it right behind W_l
@@ -344,7 +357,7 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
         if (l > 0) {
             np = 2;
             Gemm16Args& x = pair[1];
-            x.A = b.d16[l]; x.lda = isk_pad32(N); x.a_f32 = 0;
+            x.A = b.d16[l]; x.lda = isk_pad32(N); x.a_f32 = f32math; x.f32math = f32math;
             x.B = e->d_theta + e->off_W[l]; x.ldb = N; x.b_f32 = 1;           // Flux (out, in) column-major == [k][n]: n contiguous
             x.M = B; x.Nn = K; x.Kc = isk_pad32(N); x.kvalid = N;
             x.epi = ISK_G16_DX;
@@ -364,7 +377,8 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
 
 // layered path: one optimizer step's gradient, layer by layer (see kernels_layered.hip)
 void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float inv_div) {
-    if (bf16_train_active(e) && launch_grads_layered_bf16(e, d_idx, B, inv_div)) return;
+    if (bf16_train_active(e) && launch_grads_layered_bf16(e, d_idx, B, inv_div, 0)) return;
+    if (mfma32_train_active(e) && launch_grads_layered_bf16(e, d_idx, B, inv_div, 1)) return;
     if (launch_grads_layered_blas(e, d_idx, B, inv_div)) return;
     ensure_folded(e);                // the in-house kernels read the f32 weight images (an epoch on the bf16 GEMMs leaves them unfolded)
     const int L = e->L;

@@ -27,7 +27,8 @@ struct IskOptions {
     int feat_bg_wgs = 0;          //                                        ... or in total (0 = per-CU rule)
     int feat_pf = 1;              // samples in flight per wave of the background featurizer
     int dense_groups = 1;         // layered bf16 forward: one grouped launch per layer
-    int layered_blas = 1;         // layered f32 training: rocBLAS sgemm for the plain GEMMs (0: in-house kernels)
+    int layered_blas = 0;         // layered f32 training: 1 = rocBLAS sgemm for the plain GEMMs; 0 (default since round 4) = the in-house
+                                  // NT kernels of kernels_gemm16.hip in Float32 arithmetic (no vendor BLAS on the default path)
     int train_graph = 1;          // replay the training epoch as one hipGraph
     int grad1_nw8 = -1;           // train_grad1n variant: 1 = 8 waves, 0 = 16 waves, -1 = 8 while the featurizer shares the CUs
     int fwd_waves_per_simd = 1;   // residency of the f32 forward kernel
@@ -210,6 +211,8 @@ struct Gemm16Args {
     void* ot16; int ldt;                         // optional TRANSPOSED bf16 image [Nn][ldt]: columns i in [M, ldt) are zeros
     // ISK_G16_DW: gout[i * gld + j] = C (f32)
     float* gout; long long gld;
+    int f32math;                                 // 1: Float32 arithmetic -- f32 fragments (a_f32 = b_f32 = 1), eight v_mfma_f32_16x16x4_f32 per
+                                                 // 32-deep step instead of one bf16 MFMA -- and the images o16 / ot16 are FLOAT arrays
 };
 int  isk_launch_gemm16(const Gemm16Args& a, hipStream_t st);
 #define ISK_G16_MAXGROUP 3
@@ -217,11 +220,13 @@ struct Gemm16Group {                             // several independent products
     Gemm16Args g[ISK_G16_MAXGROUP];
     int n, gx[ISK_G16_MAXGROUP], first[ISK_G16_MAXGROUP];
     int slow[ISK_G16_MAXGROUP];                  // member takes the elementwise operand path (ragged / unaligned shapes)
+    int f32[ISK_G16_MAXGROUP];                   // member runs in Float32 arithmetic
 };
 int  isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st);
 // gathered batch rows -> xb [Bp][Kp] bf16 and xt [K + 1][ldt] bf16 (row K = ones; columns [B, Bp) zeros)
+// img_f32: the images are FLOAT arrays (Float32 arithmetic of the training GEMMs) instead of bf16
 void isk_launch_gather_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
-                              hipStream_t st);
+                              int img_f32, hipStream_t st);
 struct WtImagesArgs {
     const float* theta; const float* scale0;     // scale0: LayerNorm scale folded into layer 0's image (or nullptr)
     int nlayers;
@@ -231,13 +236,14 @@ struct WtImagesArgs {
     void* Wf[ISK_MAX_LAYERS];                    // fragment-linear [pad128(K) / 32][32][64 lanes][8] bf16 of a layer <= 512 wide, zero
                                                  //   initialised by the owner (steps >= Kp / 32 are never written); nullptr: not wanted
     int first_block[ISK_MAX_LAYERS];             // filled by the launcher
+    int wt_f32;                                  // 1: the Wt images are FLOAT arrays (Float32 arithmetic of the training GEMMs)
 };
 void isk_launch_wt_images(WtImagesArgs& a, hipStream_t st);
 // isk_launch_gather_images + isk_launch_wt_images as ONE launch (the head of an optimizer step of the bf16 layered path)
 void isk_launch_prep_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
-                            WtImagesArgs& w, hipStream_t st);
+                            int img_f32, WtImagesArgs& w, hipStream_t st);
 void isk_launch_loss_delta16(const float* z, int ld, const float* target, const float* lossw, const int* perm, int B, int Bp, int nout,
-                             float inv_div, int lastact, void* d16, int ld16, void* dt16, long long ldt, float* loss_slot,
+                             float inv_div, int lastact, void* d16, int ld16, void* dt16, long long ldt, int img_f32, float* loss_slot,
                              const int* rank_err, hipStream_t st);
 
 // parameter "fold": flat Flux-order theta -> fragment-linear weights and folded bias

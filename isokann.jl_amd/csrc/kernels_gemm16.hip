@@ -14,6 +14,13 @@
 // ahead -- a 32 x 64 output tile per 256-thread workgroup whose four waves SPLIT K (256..504 workgroups for every product of
 // C5: the whole chip, 8..16 k-steps per wave), one LDS reduction, and fused epilogues (bias + activation + the bf16 / transposed
 // images the next products need), so that a layer is one launch forward and two backward.
+//
+// Float32 arithmetic (Gemm16Args.f32math; the default of the layered training path, option train_bf16 = 0): the same kernels with
+// f32 fragments -- a lane's eight consecutive contraction elements are eight registers -- and eight v_mfma_f32_16x16x4_f32 per
+// 32-deep step (step j contracts the elements 8 (lane / 16) + j: any bijection of the contraction index serves as long as both
+// operands use it), f32 images instead of bf16 ones.  Exact Float32 products and sums, i.e. what rocBLAS sgemm computed here
+// until round 3 -- with the fused epilogues and grouped launches of the bf16 path instead of a library call per product plus
+// elementwise kernels around it.
 #include <type_traits>
 
 #include "isk_internal.h"
@@ -51,6 +58,23 @@ __device__ __forceinline__ u16 to_bf16(float v) {
     return __builtin_bit_cast(u16, b);
 }
 
+__device__ __forceinline__ void st_img(void* img, long long idx, float v, int f32) {
+    if (f32) ((float*)img)[idx] = v; else ((u16*)img)[idx] = to_bf16(v);
+}
+// the Float32 fragment: eight consecutive contraction elements of one operand row (f32 in memory)
+template <bool SLOW>
+__device__ __forceinline__ f32x8 load_frag32(const void* base, long long off, int k0, int kmax) {
+    if (SLOW) {
+        f32x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (k0 + j < kmax) ? ((const float*)base)[off + j] : 0.f;
+        return r;
+    }
+    const f32x4* p = (const f32x4*)((const float*)base + off);
+    const f32x4 lo = p[0], hi = p[1];
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // 8 consecutive contraction elements of one operand row as an MFMA fragment; kmax: elements at k >= kmax read as 0 (only the
 // unaligned / ragged slow path passes kmax < the padded length)
 template <bool SLOW>
@@ -80,8 +104,9 @@ __device__ __forceinline__ bf16x8 load_frag(const void* base, const int F32, lon
 
 // one 32 x 64 output tile (bx, by) of problem `a`; the operand element types are wave-uniform run-time flags (a grouped launch
 // mixes products with bf16 and f32 operands)
-template <bool SLOW>
+template <bool SLOW, bool F32 = false>
 __device__ __forceinline__ void gemm16_tile(const Gemm16Args& a, const int bx, const int by, float (*red)[G16_TM][G16_LDR]) {
+    using frag_t = typename std::conditional<F32, f32x8, bf16x8>::type;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lq = lane >> 4;
     const int i0 = bx * G16_TM, j0 = by * G16_TN;
@@ -99,36 +124,66 @@ __device__ __forceinline__ void gemm16_tile(const Gemm16Args& a, const int bx, c
     const int nk = a.Kc / 32;
     // this wave's k-steps: wave, wave + 4, ...  Fragments are requested TWO steps ahead (three register sets, rotated statically):
     // the chain of a wave is 8..16 dependent memory round trips long, and beside the side-stream featurizer one of them is ~1 us
-    bf16x8 fa[3][2], fb[3][4];
+    // (Float32 arithmetic: two register sets, one step ahead -- a fragment is eight registers, and a step is 64 MFMAs of 32 cycles,
+    // which covers a round trip by itself)
+    constexpr int NSET = F32 ? 2 : 3;
+    frag_t fa[NSET][2], fb[NSET][4];
     auto loadset = [&](int ks, auto SLOT) {
         constexpr int sl = decltype(SLOT)::value;
         if (ks < nk) {
+            if constexpr (F32) {
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) fa[sl][rt] = load_frag<SLOW>(a.A, AF32, offA[rt] + ks * 32, ks * 32 + lq * 8, a.kvalid);
+                for (int rt = 0; rt < 2; ++rt) fa[sl][rt] = load_frag32<SLOW>(a.A, offA[rt] + ks * 32, ks * 32 + lq * 8, a.kvalid);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) fb[sl][ct] = load_frag<SLOW>(a.B, BF32, offB[ct] + ks * 32, ks * 32 + lq * 8, a.kvalid);
+                for (int ct = 0; ct < 4; ++ct) fb[sl][ct] = load_frag32<SLOW>(a.B, offB[ct] + ks * 32, ks * 32 + lq * 8, a.kvalid);
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) fa[sl][rt] = load_frag<SLOW>(a.A, AF32, offA[rt] + ks * 32, ks * 32 + lq * 8, a.kvalid);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) fb[sl][ct] = load_frag<SLOW>(a.B, BF32, offB[ct] + ks * 32, ks * 32 + lq * 8, a.kvalid);
+            }
         }
     };
     auto mma = [&](auto SLOT) {
         constexpr int sl = decltype(SLOT)::value;
+        if constexpr (F32) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[sl][rt], fb[sl][ct], acc[rt][ct], 0, 0, 0);
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][rt][j], fb[sl][ct][j], acc[rt][ct], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[sl][rt], fb[sl][ct], acc[rt][ct], 0, 0, 0);
+        }
     };
-    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
     int ks = wave;
     loadset(ks, S0{});
-    loadset(ks + 4, S1{});
-    for (; ks < nk; ks += 12) {
-        loadset(ks + 8, S2{});
-        mma(S0{});
-        if (ks + 4 >= nk) break;
-        loadset(ks + 12, S0{});
-        mma(S1{});
-        if (ks + 8 >= nk) break;
-        loadset(ks + 16, S1{});
-        mma(S2{});
+    if constexpr (F32) {
+        for (; ks < nk; ks += 8) {
+            loadset(ks + 4, S1{});
+            mma(S0{});
+            if (ks + 4 >= nk) break;
+            loadset(ks + 8, S0{});
+            mma(S1{});
+        }
+    } else {
+        loadset(ks + 4, S1{});
+        for (; ks < nk; ks += 12) {
+            loadset(ks + 8, std::integral_constant<int, NSET - 1>{});
+            mma(S0{});
+            if (ks + 4 >= nk) break;
+            loadset(ks + 12, S0{});
+            mma(S1{});
+            if (ks + 8 >= nk) break;
+            loadset(ks + 16, S1{});
+            mma(std::integral_constant<int, NSET - 1>{});
+        }
     }
     // C layout of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + r
 #pragma unroll
@@ -173,7 +228,7 @@ __device__ __forceinline__ void gemm16_tile(const Gemm16Args& a, const int bx, c
         } else {                                         // ISK_G16_DW: rows 0..K-1 are dW (Flux layout [k][n]), row K is db
             if (in) a.gout[(long long)i * a.gld + j] = v;
         }
-        if (a.o16 && i < a.M16 && j < a.ld16) ((u16*)a.o16)[(long long)i * a.ld16 + j] = to_bf16(o);
+        if (a.o16 && i < a.M16 && j < a.ld16) st_img(a.o16, (long long)i * a.ld16 + j, o, F32);
         if (want_t) red[0][row][col] = o;                // own element only: no other thread reads it before the barrier
     }
     if (!want_t) return;
@@ -183,15 +238,15 @@ __device__ __forceinline__ void gemm16_tile(const Gemm16Args& a, const int bx, c
     for (int p = 0; p < 8; ++p) {
         const int idx = tid + 256 * p, col = idx >> 5, row = idx & 31;
         const int i = i0 + row, j = j0 + col;
-        if (j < a.Nn && i < a.ldt) ((u16*)a.ot16)[(long long)j * a.ldt + i] = to_bf16(red[0][row][col]);
+        if (j < a.Nn && i < a.ldt) st_img(a.ot16, (long long)j * a.ldt + i, red[0][row][col], F32);
     }
 }
 
-template <bool SLOW>
+template <bool SLOW, bool F32>
 __global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args a) {
     __shared__ float red[4][G16_TM][G16_LDR];
     ISK_LATENCY_CHAIN_PRIO();
-    gemm16_tile<SLOW>(a, blockIdx.x, blockIdx.y, red);
+    gemm16_tile<SLOW, F32>(a, blockIdx.x, blockIdx.y, red);
 }
 
 // several INDEPENDENT products in one launch (dW_l beside dX_l: both need only delta_l): a step of the layered training path is a
@@ -207,6 +262,16 @@ __global__ __launch_bounds__(256) void gemm16_group_kernel(Gemm16Group g) {
     if (g.slow[p]) gemm16_tile<true>(g.g[p], b % g.gx[p], b / g.gx[p], red);
     else gemm16_tile<false>(g.g[p], b % g.gx[p], b / g.gx[p], red);
 }
+// the same for products in Float32 arithmetic (a kernel of its own: its fragments need twice the registers)
+__global__ __launch_bounds__(256) void gemm32_group_kernel(Gemm16Group g) {
+    __shared__ float red[4][G16_TM][G16_LDR];
+    ISK_LATENCY_CHAIN_PRIO();
+    int p = 0, b = blockIdx.x;
+    while (p + 1 < g.n && b >= g.first[p + 1]) ++p;
+    b -= g.first[p];
+    if (g.slow[p]) gemm16_tile<true, true>(g.g[p], b % g.gx[p], b / g.gx[p], red);
+    else gemm16_tile<false, true>(g.g[p], b % g.gx[p], b / g.gx[p], red);
+}
 
 static bool g16_grid(const Gemm16Args& a, int* gx, int* gy, bool* slow) {
     if (a.M < 1 || a.Nn < 1 || a.Kc < 32 || a.Kc % 32) return false;
@@ -214,6 +279,7 @@ static bool g16_grid(const Gemm16Args& a, int* gx, int* gy, bool* slow) {
     *gx = (rows + G16_TM - 1) / G16_TM; *gy = (a.Nn + G16_TN - 1) / G16_TN;
     // vector loads need 16-byte aligned rows; anything else (odd widths, a contraction that is not a multiple of 32) takes the
     // elementwise path
+    if (a.f32math && !(a.a_f32 && a.b_f32)) return false;               // Float32 arithmetic reads f32 operands
     const int ea = a.a_f32 ? 4 : 8, eb = a.b_f32 ? 4 : 8;
     const bool a_al = ((uintptr_t)a.A % 16 == 0) && (a.lda % ea == 0), b_al = ((uintptr_t)a.B % 16 == 0) && (a.ldb % eb == 0);
     *slow = !a_al || !b_al || a.kvalid < a.Kc;
@@ -224,7 +290,8 @@ int isk_launch_gemm16(const Gemm16Args& a, hipStream_t st) {
     int gx, gy; bool slow;
     if (!g16_grid(a, &gx, &gy, &slow)) return ISK_EINVAL;
     void* args[] = {(void*)&a};
-    const void* fn = slow ? (const void*)gemm16_kernel<true> : (const void*)gemm16_kernel<false>;
+    const void* fn = a.f32math ? (slow ? (const void*)gemm16_kernel<true, true> : (const void*)gemm16_kernel<false, true>)
+                               : (slow ? (const void*)gemm16_kernel<true, false> : (const void*)gemm16_kernel<false, false>);
     return hipLaunchKernel(fn, dim3(gx, gy), dim3(256), args, 0, st) == hipSuccess ? 0 : ISK_EHIP;
 }
 
@@ -236,12 +303,14 @@ int isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st) {
     for (int p = 0; p < n; ++p) {
         int gx, gy; bool slow;
         if (!g16_grid(list[p], &gx, &gy, &slow)) return ISK_EINVAL;
-        g.g[p] = list[p]; g.gx[p] = gx; g.first[p] = total; g.slow[p] = slow ? 1 : 0;
+        g.g[p] = list[p]; g.gx[p] = gx; g.first[p] = total; g.slow[p] = slow ? 1 : 0; g.f32[p] = list[p].f32math;
+        if (list[p].f32math != list[0].f32math) return ISK_EINVAL;     // one arithmetic per launch
         total += gx * gy;
     }
     if (n == 1) return isk_launch_gemm16(list[0], st);
     void* args[] = {(void*)&g};
-    return hipLaunchKernel((const void*)gemm16_group_kernel, dim3(total), dim3(256), args, 0, st) == hipSuccess ? 0 : ISK_EHIP;
+    const void* fn = list[0].f32math ? (const void*)gemm32_group_kernel : (const void*)gemm16_group_kernel;
+    return hipLaunchKernel(fn, dim3(total), dim3(256), args, 0, st) == hipSuccess ? 0 : ISK_EHIP;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -251,16 +320,18 @@ int isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st) {
 // transposed image with the row of ones behind the K features: the first layer's dW + db operand).  One 32 x 32 tile per
 // workgroup through LDS; rows >= B and columns >= K are written as zeros (they are contraction padding).
 struct GatherArgs {
-    const float* X; int ldx; const int* perm; int B, Bp, K, Kp; u16* xb; u16* xt; long long ldt;
+    const float* X; int ldx; const int* perm; int B, Bp, K, Kp; void* xb; void* xt; long long ldt;
     int gx;                                                            // tiles along the batch rows (linear block index = bx + gx * by)
+    int f32;                                                           // the images are float arrays (Float32 arithmetic)
 };
 __device__ __forceinline__ void gather_tile(const GatherArgs& g, const int bx, const int by, float (*tile)[33]) {
     const float* __restrict__ X = g.X;
     const int* __restrict__ perm = g.perm;
     const int B = g.B, Bp = g.Bp, K = g.K, Kp = g.Kp, ldx = g.ldx;
-    u16* __restrict__ xb = g.xb;
-    u16* __restrict__ xt = g.xt;
+    void* __restrict__ xb = g.xb;
+    void* __restrict__ xt = g.xt;
     const long long ldt = g.ldt;
+    const int f32 = g.f32;
     const int b0 = bx * 32, k0 = by * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 8 row groups
     // the four rows of a thread: indices, then values, requested together from clamped addresses (no load behind a branch: each
@@ -284,13 +355,13 @@ __device__ __forceinline__ void gather_tile(const GatherArgs& g, const int bx, c
         if (b < B && k < K) v = val[q];
         else if (b < B && k == K) v = 1.f;                            // the ones row of the transposed image
         tile[r][tx] = v;
-        if (b < Bp && k < Kp) xb[(long long)b * Kp + k] = to_bf16(k < K ? v : 0.f);
+        if (b < Bp && k < Kp) st_img(xb, (long long)b * Kp + k, k < K ? v : 0.f, f32);
     }
     __syncthreads();
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {
         const int k = k0 + r, b = b0 + tx;
-        if (k <= K && b < Bp) xt[(long long)k * ldt + b] = to_bf16(tile[tx][r]);
+        if (k <= K && b < Bp) st_img(xt, (long long)k * ldt + b, tile[tx][r], f32);
     }
 }
 __global__ __launch_bounds__(256) void gather_images_kernel(GatherArgs g) {
@@ -298,15 +369,16 @@ __global__ __launch_bounds__(256) void gather_images_kernel(GatherArgs g) {
     ISK_LATENCY_CHAIN_PRIO();
     gather_tile(g, blockIdx.x % g.gx, blockIdx.x / g.gx, tile);
 }
-static GatherArgs gather_args(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt, int* nblocks) {
-    GatherArgs g = {X, ldx, perm, B, Bp, K, Kp, (u16*)xb, (u16*)xt, ldt, (Bp + 31) / 32};
+static GatherArgs gather_args(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt, int f32,
+                              int* nblocks) {
+    GatherArgs g = {X, ldx, perm, B, Bp, K, Kp, xb, xt, ldt, (Bp + 31) / 32, f32};
     *nblocks = g.gx * ((K + 1 + 31) / 32);                             // covers k = K (the ones row)
     return g;
 }
 void isk_launch_gather_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
-                              hipStream_t st) {
+                              int img_f32, hipStream_t st) {
     int nb;
-    const GatherArgs g = gather_args(X, ldx, perm, B, Bp, K, Kp, xb, xt, ldt, &nb);
+    const GatherArgs g = gather_args(X, ldx, perm, B, Bp, K, Kp, xb, xt, ldt, img_f32, &nb);
     hipLaunchKernelGGL(gather_images_kernel, dim3(nb), dim3(256), 0, st, g);
 }
 
@@ -338,14 +410,14 @@ __device__ __forceinline__ void wt_tile(const WtImagesArgs& a, int blk, float (*
         tile[r][tx] = (k < K && n < N) ? wv[q] * sv[q] : 0.f;
     }
     __syncthreads();
-    u16* out = (u16*)a.Wt[l];
+    void* out = a.Wt[l];
     u16* frag = (u16*)a.Wf[l];
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {
         const int n = n0 + r, k = k0 + tx;
         if (n < N && k < Kp) {
             const u16 h = to_bf16(tile[tx][r]);
-            if (out) out[(long long)n * Kp + k] = h;
+            if (out) { if (a.wt_f32) ((float*)out)[(long long)n * Kp + k] = tile[tx][r]; else ((u16*)out)[(long long)n * Kp + k] = h; }
             // fragment-linear image of the fused wide forward (kernels_fwd_wide.hip): 16-column block n / 16 of 32, step k / 32; lane
             // (n % 16) + 16 ((k % 32) / 8) holds features k % 8 of its 16 bytes
             if (frag) frag[((((long long)(k >> 5) * 32 + (n >> 4)) * 64 + ((n & 15) + 16 * ((k & 31) >> 3))) << 3) + (k & 7)] = h;
@@ -372,9 +444,9 @@ void isk_launch_wt_images(WtImagesArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(wt_images_kernel, dim3(total), dim3(256), 0, st, a);
 }
 void isk_launch_prep_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
-                            WtImagesArgs& w, hipStream_t st) {
+                            int img_f32, WtImagesArgs& w, hipStream_t st) {
     int nb;
-    const GatherArgs g = gather_args(X, ldx, perm, B, Bp, K, Kp, xb, xt, ldt, &nb);
+    const GatherArgs g = gather_args(X, ldx, perm, B, Bp, K, Kp, xb, xt, ldt, img_f32, &nb);
     int total = 0;
     for (int l = 0; l < w.nlayers; ++l) { w.first_block[l] = total; total += ((w.Kp[l] + 31) / 32) * ((w.N[l] + 31) / 32); }
     hipLaunchKernelGGL(prep_images_kernel, dim3(nb + total), dim3(256), 0, st, g, w, nb);
@@ -384,8 +456,8 @@ void isk_launch_prep_images(const float* X, int ldx, const int* perm, int B, int
 // bf16 images of delta_L: d16 [Bp][ld16] (A operand of dX) and dt16 [nout][Bp] (B operand of dW + db)
 __global__ __launch_bounds__(1024) void loss_delta16_kernel(const float* __restrict__ z, int ld, const float* __restrict__ target,
                                                             const float* __restrict__ lossw, const int* __restrict__ perm, int B, int Bp,
-                                                            int nout, float inv_div, int lastact, u16* __restrict__ d16, int ld16,
-                                                            u16* __restrict__ dt16, long long ldt, float* __restrict__ loss_slot,
+                                                            int nout, float inv_div, int lastact, void* __restrict__ d16, int ld16,
+                                                            void* __restrict__ dt16, long long ldt, int img_f32, float* __restrict__ loss_slot,
                                                             const int* __restrict__ rank_err) {
     __shared__ float red[16];
     float ls = 0.f;
@@ -403,8 +475,8 @@ __global__ __launch_bounds__(1024) void loss_delta16_kernel(const float* __restr
             ls += r * r;
             d = 2.f * r * w * inv_div * g_dact(lastact, zz);
         }
-        d16[(long long)n * ld16 + o] = to_bf16(d);
-        dt16[(long long)o * ldt + n] = to_bf16(d);
+        st_img(d16, (long long)n * ld16 + o, d, img_f32);
+        st_img(dt16, (long long)o * ldt + n, d, img_f32);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o, 64);
@@ -418,9 +490,9 @@ __global__ __launch_bounds__(1024) void loss_delta16_kernel(const float* __restr
     }
 }
 void isk_launch_loss_delta16(const float* z, int ld, const float* target, const float* lossw, const int* perm, int B, int Bp, int nout,
-                             float inv_div, int lastact, void* d16, int ld16, void* dt16, long long ldt, float* loss_slot,
+                             float inv_div, int lastact, void* d16, int ld16, void* dt16, long long ldt, int img_f32, float* loss_slot,
                              const int* rank_err, hipStream_t st) {
     hipLaunchKernelGGL(loss_delta16_kernel, dim3(1), dim3(1024), 0, st, z, ld, target, lossw, perm, B, Bp, nout, inv_div, lastact,
-                       (u16*)d16, ld16, (u16*)dt16, ldt, loss_slot, rank_err);
+                       d16, ld16, dt16, ldt, img_f32, loss_slot, rank_err);
 }
 
