@@ -150,6 +150,8 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *                                in Float32 arithmetic (fused epilogues, grouped launches: the faster path, and no vendor BLAS)
  *   train_bf16          0        wide networks: training GEMMs on bf16 operands (f32 master weights, f32 accumulate)
  *   wide_fused          1        wide networks, plain-bf16 forward (forward_mode 2): one fused kernel, activations in LDS
+ *   dp_bucket           1        native data-parallel run of a wide network: the gradient all-reduce in two buckets -- the blocks of the
+ *                                layers >= 1 travel on a second stream while the first layer's backward products run (bit-identical results)
  *   dp_force_coll       0        issue the native collectives on a one-rank communicator (tests)
  *   debug_feat_copy / debug_stamps / debug_rowmod   0   diagnostics
  * Read-only keys of isk_get_option: forward_mode (effective), layered, planes, nparams_engine, wide_fwd (1 when the resident

@@ -429,6 +429,9 @@ extern "C" void isk_destroy(isk_engine* e) {
     free_data(e);
     free_dev(e->d_theta); free_dev(e->d_grad); free_dev(e->d_m); free_dev(e->d_v); free_dev(e->d_bt);
     free_dev(e->d_ep_zp); free_dev(e->d_ep_lnpart); free_dev(e->d_ep_cnt);
+    if (e->comm_stream) { (void)hipStreamSynchronize(e->comm_stream); (void)hipStreamDestroy(e->comm_stream); }
+    if (e->ev_b1_ready) (void)hipEventDestroy(e->ev_b1_ready);
+    if (e->ev_b1_done) (void)hipEventDestroy(e->ev_b1_done);
     free_dev(e->d_loss_acc); free_dev(e->d_mm); free_dev(e->d_lossw);
     free_dev(e->d_At); free_dev(e->d_rowperm); free_dev(e->d_pairs); free_dev(e->d_packed); free_dev(e->d_isa_work_dp);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_Wt[l]); free_dev(e->d_bias[l]); }

@@ -134,6 +134,13 @@ struct isk_engine {
     float* d_ep_zp = nullptr; size_t ep_zp_floats = 0;
     float* d_ep_lnpart = nullptr; size_t ep_lnpart_floats = 0;
     unsigned* d_ep_cnt = nullptr;
+    // bucketed gradient all-reduce of the layered path (engine_dp_native.hip): the blocks of layers >= 1 are reduced on a stream of
+    // their own while the first layer's backward products run
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_b1_ready = nullptr, ev_b1_done = nullptr;
+    void (*grad_hook)(isk_engine*) = nullptr;   // called by the layered backward once every block of layers >= 1 is enqueued
+    int bucket_issued = 0;                      // the hook ran in this step: the upper bucket is already on its way
+    int bucket_err = 0;                         // ncclResult of the hook's collective (0 = success)
     bool tp_disabled = false;
     bool last_epoch_persist = false;            // a launch failed or timed out: the four-kernel chain from then on
     unsigned long long* dbg_st = nullptr;            // diagnostics of forward_resident (options debug_stamps / debug_rowmod)

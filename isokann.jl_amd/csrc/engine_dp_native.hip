@@ -208,6 +208,26 @@ static void dp_poison(isk_engine* e, int code, const std::string& msg) {
     e->h_flag[0] = 1;
     (void)hipMemcpyAsync(e->d_rank_err, e->h_flag, sizeof(int), hipMemcpyHostToDevice, e->stream);
 }
+// the upper bucket of a wide network's gradient: [W_2 .. b_L | batch loss | rank-error flag], contiguous behind layer 1's block
+static void dp_bucket_hook(isk_engine* e) {
+    const size_t first = (size_t)e->off_W[1], count = (size_t)e->nparams + 2 - first;
+    (void)hipEventRecord(e->ev_b1_ready, e->stream);
+    (void)hipStreamWaitEvent(e->comm_stream, e->ev_b1_ready, 0);
+    e->bucket_err = (int)g_rccl.AllReduce(e->d_grad + first, e->d_grad + first, count, ncclFloat, ncclSum, e->comm, e->comm_stream);
+    (void)hipEventRecord(e->ev_b1_done, e->comm_stream);
+    e->bucket_issued = 1;
+}
+static bool dp_bucket_setup(isk_engine* e) {
+    if (e->comm_stream) return true;
+    if (hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_b1_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_b1_done, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
+
 #define DPHIP(expr)                                                                                \
     do {                                                                                           \
         hipError_t _e = (expr);                                                                    \
@@ -249,6 +269,9 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
     const int nslab = coll ? 1 : pick_slabs(local_batch);
     // [gradient slabs | batch loss | rank-error flag]
     const size_t red_count = (size_t)(nslab - 1) * (e->nparams + 2) + (size_t)e->nparams + 2;
+    // wide networks on the in-house GEMM chain: two buckets (option dp_bucket); every rank decides alike (same options, same shape)
+    const bool bucketed = coll && e->opt.dp_bucket && e->layered && e->L >= 2 && (bf16_train_active(e) || mfma32_train_active(e)) &&
+                          dp_bucket_setup(e);
     long long k = 0, step_no = 0;
     for (int it = 0; it < n; ++it) {
         if (e->cfg.featurize_every_iteration) featurize_resident(e);      // first: see isk_run
@@ -292,10 +315,18 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
                     ++step_no;
                     if (e->opt.debug_inject_rank_error > 0 && step_no == e->opt.debug_inject_rank_error)
                         dp_poison(e, ISK_EHIP, "injected rank error (option debug_inject_rank_error)");
+                    e->bucket_issued = 0; e->bucket_err = 0;
+                    e->grad_hook = bucketed ? dp_bucket_hook : nullptr;
                     launch_grads(e, e->d_perm + (long long)b * local_batch, local_batch, 1.0f / (float)global_batch, nslab);
+                    e->grad_hook = nullptr;
                     if (coll) {
                         ScopedTimer ta(e, ISK_T_ALLREDUCE);
-                        const ncclResult_t r = g_rccl.AllReduce(e->d_grad, e->d_grad, red_count, ncclFloat, ncclSum, e->comm, e->stream);
+                        // bucketed: the layers >= 1 (and the loss / flag slots) left from inside the backward on the second stream;
+                        // what remains is layer 1's block (with the LayerNorm blocks in front of it)
+                        const size_t cnt = e->bucket_issued ? (size_t)e->off_W[1] : red_count;
+                        ncclResult_t r = e->bucket_issued ? (ncclResult_t)e->bucket_err : ncclSuccess;
+                        if (r == ncclSuccess) r = g_rccl.AllReduce(e->d_grad, e->d_grad, cnt, ncclFloat, ncclSum, e->comm, e->stream);
+                        if (e->bucket_issued) DPHIP(hipStreamWaitEvent(e->stream, e->ev_b1_done, 0));
                         // a collective this rank could not even enqueue: the peers are lost anyway, say why and stop
                         if (r != ncclSuccess) { (void)dp_clear_poison(e); return fail(ISK_EHIP, std::string("rccl: ") + g_rccl.GetErrorString(r)); }
                     }

@@ -366,6 +366,9 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
         }
         // dW_l + db_l and delta_{l-1} both need only delta_l: one launch
         ok = isk_launch_gemm16_group(pair, np, st) == 0;
+        // every gradient block of the layers >= 1 is now enqueued (Flux order: they are one contiguous range behind layer 0's):
+        // the data-parallel driver sends them on their way while the first layer's products run
+        if (ok && l == 1 && e->grad_hook) e->grad_hook(e);
         if (ln0) {
             (void)hipMemcpyAsync(e->d_grad + e->off_b[0], b.G0 + (size_t)K * N, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st);
             isk_launch_ln_unfold(b.G0, b.G0 + (size_t)K * N, e->d_theta, e->off_W[0], e->off_lns, e->off_lnb, e->F, N, e->d_grad, st);

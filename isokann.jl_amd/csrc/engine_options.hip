@@ -25,6 +25,7 @@ const OptDesc kOptions[] = {
     {"grad1_nw8", &IskOptions::grad1_nw8, -1, 1},
     {"fwd_waves_per_simd", &IskOptions::fwd_waves_per_simd, 1, 4},
     {"dp_force_coll", &IskOptions::dp_force_coll, 0, 1},
+    {"dp_bucket", &IskOptions::dp_bucket, 0, 1},
     {"train_bf16", &IskOptions::train_bf16, 0, 1},
     {"tail_narrow", &IskOptions::tail_narrow, 0, 1},
     {"train_persist", &IskOptions::train_persist, 0, 1},

@@ -32,6 +32,8 @@ struct IskOptions {
     int train_graph = 1;          // replay the training epoch as one hipGraph
     int grad1_nw8 = -1;           // train_grad1n variant: 1 = 8 waves, 0 = 16 waves, -1 = 8 while the featurizer shares the CUs
     int fwd_waves_per_simd = 1;   // residency of the f32 forward kernel
+    int dp_bucket = 1;            // native data-parallel run, wide networks: all-reduce the gradient in two buckets, the layers >= 1 under
+                                  // the first layer's backward (0: one all-reduce behind the whole backward)
     int dp_force_coll = 0;        // issue the native collectives on a one-rank communicator (tests)
     int wide_fused = 1;           // layered path, plain-bf16 forward: the fused wide kernel (0: layer by layer through HBM)
     int train_persist = 0;        // fused path, single GPU: a training epoch as ONE persistent launch (experimental: measured SLOWER

@@ -50,7 +50,8 @@ def _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, minibatch, every_iter=False
     tr = pkg.TransformShiftscale() if nout == 1 else pkg.TransformISA()
     popt = pkg.AdamRegularized(LR, 1e-3) if opt == "adam" else pkg.NesterovRegularized(LR, 1e-3)
     # wide: first hidden width > 160 -> layered path; forward_mode 2 + train_bf16 = the fused bf16 forward and the bf16 training GEMMs
-    kw = dict(forward_mode=2, options={"train_bf16": 1}) if wide else {}
+    # (ISK_TRAIN_BF16=0: the same in-house GEMM chain in Float32 arithmetic)
+    kw = dict(forward_mode=2, options={"train_bf16": int(os.environ.get("ISK_TRAIN_BF16", "1"))}) if wide else {}
     return pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=model, opt=popt,
                    target=tr, minibatch=minibatch, featurize_every_iteration=every_iter, **kw)
 

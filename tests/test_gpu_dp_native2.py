@@ -87,16 +87,25 @@ def test_native_driver_two_ranks_every_forward_mode(gpu_pkg, mock_lib, fwd_mode)
     """what bench.py runs on a multi-GPU node -- ISA target, featurization inside every iteration, the side-stream featurizer
     beside the training steps and the collectives -- in the f32, split-bf16 and split-f16 (unit-blocked operand planes)
     forward modes (ISK_FWD_MODE is inherited by the ranks)"""
-    test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, 3, 16, 1, True, "adam")
+    _two_ranks_vs_single_process(gpu_pkg, mock_lib, 3, 16, 1, True, "adam")
 
 
-def test_native_driver_two_ranks_wide_network_on_its_bf16_path(gpu_pkg, mock_lib, monkeypatch):
+@pytest.mark.parametrize("train_bf16", [1, 0])
+def test_native_driver_two_ranks_wide_network_on_its_bf16_path(gpu_pkg, mock_lib, monkeypatch, train_bf16):
     """C5's kind of network through the native driver: a layered network ([40,192,64,1], no LayerNorm) with the fused bf16 forward,
-    the featurizer writing bf16 rows inside every iteration and the bf16 training GEMMs (weight images rebuilt per step, f32
-    forward images not folded at all): two ranks through the mock RCCL against the single process on the full data"""
+    the featurizer writing bf16 rows inside every iteration and the training GEMMs on the in-house NT kernels -- bf16 operands
+    (train_bf16 = 1) or Float32 arithmetic (0) --: two ranks through the mock RCCL against the single process on the full data.
+    The gradient travels in TWO buckets per optimizer step (option dp_bucket: the layers >= 1 on a second stream under the first
+    layer's backward); the same run with ONE all-reduce per step must leave bit-identical replicas."""
     monkeypatch.setenv("ISK_TEST_WIDE", "1")
+    monkeypatch.setenv("ISK_TRAIN_BF16", str(train_bf16))
     monkeypatch.delenv("ISK_FWD_MODE", raising=False)
-    test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, 1, 32, 2, True, "nesterov")
+    got = {}
+    for bucket in (1, 0):
+        monkeypatch.setenv("ISK_DP_BUCKET", str(bucket))
+        got[bucket] = _two_ranks_vs_single_process(gpu_pkg, mock_lib, 1, 32, 2, True, "nesterov", per_step=1 + bucket)
+    np.testing.assert_array_equal(got[1]["params"], got[0]["params"])
+    np.testing.assert_array_equal(got[1]["losses"], got[0]["losses"])
 
 
 @pytest.mark.parametrize("nout,minibatch,epochs,every_iter,opt", [(1, 64, 1, False, "adam"), (3, 64, 1, False, "adam"), (3, 0, 1, False, "adam"),
@@ -105,6 +114,10 @@ def test_native_driver_two_ranks_wide_network_on_its_bf16_path(gpu_pkg, mock_lib
 def test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, nout, minibatch, epochs, every_iter, opt):
     """every_iter: featurization inside every iteration, i.e. the side-stream featurizer beside the training steps and the
     collectives (what bench.py runs on a multi-GPU node); minibatch 16 gives the >= 4 optimizer steps that switch it on"""
+    _two_ranks_vs_single_process(gpu_pkg, mock_lib, nout, minibatch, epochs, every_iter, opt)
+
+
+def _two_ranks_vs_single_process(gpu_pkg, mock_lib, nout, minibatch, epochs, every_iter, opt, per_step=1):
     import torch.multiprocessing as mp
     pkg = gpu_pkg
     world, niter = 2, 3
@@ -117,7 +130,7 @@ def test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, nout, m
     bl, nb, gb = (int(v) for v in r[0]["plan"])
     # collectives per run: the up-front agreement (equal shards, argument / allocation status) once, per iteration 1
     # (shift-scale range) or 2 (ks, chi gathers), per optimizer step one [gradient | loss | flag] all-reduce
-    assert ncalls == 1 + niter * ((1 if nout == 1 else 2) + epochs * nb)
+    assert ncalls == 1 + niter * ((1 if nout == 1 else 2) + epochs * nb * per_step)
     xs, ys, pairs, widths, theta = _problem(nout)
     N = xs.shape[1]
     gperms = []
@@ -127,12 +140,14 @@ def test_native_driver_two_ranks_match_single_process(gpu_pkg, mock_lib, nout, m
     mk = lambda: _mk_iso(pkg, xs, ys, pairs, widths, theta, nout, gb if minibatch else 0, every_iter, opt=opt)      # noqa: E731
     ref = mk()
     if os.environ.get("ISK_TEST_WIDE"):
-        assert ref.get_option("layered") == 1 and ref.get_option("wide_fwd") == 1 and ref.get_option("train_bf16") == 1
+        assert ref.get_option("layered") == 1 and ref.get_option("wide_fwd") == 1
+        assert ref.get_option("train_bf16") == int(os.environ.get("ISK_TRAIN_BF16", "1"))
     pkg.run(ref, niter, epochs, perms=np.stack(gperms))
     np.testing.assert_allclose(r[0]["losses"], ref.losses, rtol=2e-4)
     want = ref.model.get_params()
     ref.close()
     assert_params_match(pkg, r[0]["params"], want, opt, mk, gperms[0][:gb if minibatch else N], LR, niter * epochs * nb)
+    return {"params": np.array(r[0]["params"]), "losses": np.array(r[0]["losses"])}
 
 
 def test_native_driver_rank_error_is_agreed_in_the_same_step(gpu_pkg, mock_lib):
