@@ -152,11 +152,13 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *   wide_fused          1        wide networks, plain-bf16 forward (forward_mode 2): one fused kernel, activations in LDS
  *   dp_bucket           1        native data-parallel run of a wide network: the gradient all-reduce in two buckets -- the blocks of the
  *                                layers >= 1 travel on a second stream while the first layer's backward products run (bit-identical results)
+ *   dp_peer_reduce      0        isk_dp_run_all (one process, several GPUs): 1 = the gradient is not all-reduced; every engine's optimizer
+ *                                step reads the other engines' gradient buffers over peer access and sums them in rank order
  *   dp_force_coll       0        issue the native collectives on a one-rank communicator (tests)
  *   debug_feat_copy / debug_stamps / debug_rowmod   0   diagnostics
  * Read-only keys of isk_get_option: forward_mode (effective), layered, planes, nparams_engine, wide_fwd (1 when the resident
  * data set runs the fused bf16 forward of wide networks: layered network, forward_mode 2, pair features, option wide_fused),
- * train_persist_active (1 when the last epoch ran as one persistent launch), layered_blas_active (1 once a rocBLAS handle exists, i.e. a wide network's f32 training GEMMs went to the library). */
+ * dp_peer_active (1 when the last isk_dp_run / isk_dp_run_all summed the gradients over peer access), train_persist_active (1 when the last epoch ran as one persistent launch), layered_blas_active (1 once a rocBLAS handle exists, i.e. a wide network's f32 training GEMMs went to the library). */
 int  isk_set_option(isk_engine* e, const char* key, int64_t value);
 int  isk_get_option(isk_engine* e, const char* key, int64_t* value);
 

@@ -427,9 +427,12 @@ extern "C" void isk_destroy(isk_engine* e) {
     if (e->side) (void)hipStreamSynchronize(e->side);
     if (e->copy) (void)hipStreamSynchronize(e->copy);
     free_data(e);
+    if (e->d_grad_base) e->d_grad = e->d_grad_base;                  // (the peer-reduce run alternates d_grad between two slabs of its allocation)
     free_dev(e->d_theta); free_dev(e->d_grad); free_dev(e->d_m); free_dev(e->d_v); free_dev(e->d_bt);
     free_dev(e->d_ep_zp); free_dev(e->d_ep_lnpart); free_dev(e->d_ep_cnt);
     if (e->comm_stream) { (void)hipStreamSynchronize(e->comm_stream); (void)hipStreamDestroy(e->comm_stream); }
+    for (auto& ev : e->ev_grads) if (ev) (void)hipEventDestroy(ev);
+    if (e->grp && e->dp_rank == 0) delete e->grp;                    // the group object belongs to its first engine
     if (e->ev_b1_ready) (void)hipEventDestroy(e->ev_b1_ready);
     if (e->ev_b1_done) (void)hipEventDestroy(e->ev_b1_done);
     free_dev(e->d_loss_acc); free_dev(e->d_mm); free_dev(e->d_lossw);
@@ -1073,7 +1076,7 @@ bool epoch_lazy_fold(isk_engine* e) { return e->layered && !e->cfg.layernorm && 
 // GEMMs theirs (a forward of foreign rows through the generic layered kernels folds on demand: wt_dirty stays set)
 bool epoch_no_fold(isk_engine* e) { return epoch_lazy_fold(e) && e->xh16 && (bf16_train_active(e) || mfma32_train_active(e)); }
 
-void launch_opt(isk_engine* e, float gscale, bool fold, bool capturing, bool publish) {
+void launch_opt(isk_engine* e, float gscale, bool fold, bool capturing, bool publish, const OptPeers* peers) {
     OptArgs a;
     a.theta = e->d_theta; a.grad = e->d_grad; a.m = e->d_m; a.v = e->d_v; a.n = e->nparams;
     a.kind = e->cfg.opt_kind; a.lr = e->cfg.lr; a.reg = e->cfg.reg; a.beta1 = e->cfg.beta1; a.beta2 = e->cfg.beta2;
@@ -1087,7 +1090,8 @@ void launch_opt(isk_engine* e, float gscale, bool fold, bool capturing, bool pub
     a.host_pub = publish ? e->d_hres : nullptr;
     a.nslab = e->last_nslab;
     a.slab_prefix = e->off_b[0] + e->cfg.widths[1];          // [LN | W1 | b1]: the blocks train_grad1n writes per row slab
-    isk_launch_opt_step(a, e->stream);
+    if (peers) isk_launch_opt_step_peers(a, *peers, e->stream);
+    else isk_launch_opt_step(a, e->stream);
     e->loss_acc_zeroed = false;
     e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2;
     if (!dev) e->bt_dev_valid = false;           // this step advanced only the host copy

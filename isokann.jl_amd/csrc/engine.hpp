@@ -9,6 +9,8 @@
 #include <numeric>
 #include <string>
 #include <vector>
+#include <condition_variable>
+#include <mutex>
 
 #include <rccl/rccl.h>
 #include <rocblas/rocblas.h>
@@ -38,6 +40,29 @@ int isk_fail(int code, const std::string& msg);        // sets the thread-local 
 // engine
 // ---------------------------------------------------------------------------------------
 struct EventPair { hipEvent_t a, b; int id; };
+
+// the engines one host process drives together (isk_dp_create_all): what the option dp_peer_reduce needs beyond the communicator
+struct isk_engine;
+struct DpGroup {
+    std::vector<isk_engine*> eng;
+    // a reusable host barrier for the per-engine driver threads of isk_dp_run_all (an event must have been RECORDED by its
+    // owner's thread before another thread may make its stream wait for it)
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    long long generation = 0;
+    bool broken = false;               // a member left the run early: nobody waits any more
+    bool wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (broken) return false;
+        const long long gen = generation;
+        if (++arrived == (int)eng.size()) { arrived = 0; ++generation; cv.notify_all(); return true; }
+        cv.wait(lk, [&] { return generation != gen || broken; });
+        return !broken;
+    }
+    void leave() { std::lock_guard<std::mutex> lk(mu); broken = true; cv.notify_all(); }
+    void reset() { std::lock_guard<std::mutex> lk(mu); broken = false; arrived = 0; }
+};
 
 struct isk_engine {
     isk_config cfg;
@@ -169,6 +194,10 @@ struct isk_engine {
     // native data-parallel run (isk_dp_run): RCCL communicator + gathered ks / chi
     ncclComm_t comm = nullptr;
     int dp_rank = 0, dp_world = 1;
+    DpGroup* grp = nullptr;              // set by isk_dp_create_all (shared by the group; engine 0 owns it)
+    bool last_run_peer = false;          // the last isk_dp_run summed the replicas' gradients over peer access (no all-reduce)
+    float* d_grad_base = nullptr;        // d_grad alternates between two slabs of its allocation in the peer-reduce run
+    hipEvent_t ev_grads[2] = {nullptr, nullptr};   // recorded behind the gradient kernels of an optimizer step (by step parity)
     int dp_err = ISK_OK;             // native run: this rank's first failure inside the step loop (dp_poison) ...
     std::string dp_errmsg;           // ... and its message; reported when the epoch's collectives are through
     int* h_flag = nullptr;           // pinned staging word for d_rank_err
@@ -249,7 +278,7 @@ int compute_target(isk_engine* e, bool check, bool ahead = false);
 int pick_slabs(int B);
 bool prepare_dev_bt(isk_engine* e);
 void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nslab = 1, bool step = true, bool capturing = false);
-void launch_opt(isk_engine* e, float gscale, bool fold = true, bool capturing = false, bool publish = true);
+void launch_opt(isk_engine* e, float gscale, bool fold = true, bool capturing = false, bool publish = true, const OptPeers* peers = nullptr);
 bool epoch_lazy_fold(isk_engine* e);             // the forward weight images may wait for the epoch's last optimizer step
 bool epoch_no_fold(isk_engine* e);               // ... or for a forward that actually reads them
 int stage_perm_ahead(isk_engine* e, const int32_t* perm);

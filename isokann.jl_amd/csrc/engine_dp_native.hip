@@ -270,7 +270,16 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
     // [gradient slabs | batch loss | rank-error flag]
     const size_t red_count = (size_t)(nslab - 1) * (e->nparams + 2) + (size_t)e->nparams + 2;
     // wide networks on the in-house GEMM chain: two buckets (option dp_bucket); every rank decides alike (same options, same shape)
-    const bool bucketed = coll && e->opt.dp_bucket && e->layered && e->L >= 2 && (bf16_train_active(e) || mfma32_train_active(e)) &&
+    // single-process group with peer access: no gradient all-reduce at all (option dp_peer_reduce, the same on every engine)
+    const bool peer_mode = coll && e->opt.dp_peer_reduce && e->grp && (int)e->grp->eng.size() == e->dp_world && e->dp_world > 1 && e->d_grad_base;
+    e->last_run_peer = peer_mode;
+    // every exit: d_grad points at the allocation's base again (the other entry points index its slabs from there), and a replica
+    // that leaves a peer-reduce run early releases the group's host barrier instead of leaving the other driver threads in it
+    struct Leave {
+        isk_engine* e; bool peer; bool done;
+        ~Leave() { if (e->d_grad_base) e->d_grad = e->d_grad_base; if (peer && !done) e->grp->leave(); }
+    } leave_guard{e, peer_mode, false};
+    const bool bucketed = !peer_mode && coll && e->opt.dp_bucket && e->layered && e->L >= 2 && (bf16_train_active(e) || mfma32_train_active(e)) &&
                           dp_bucket_setup(e);
     long long k = 0, step_no = 0;
     for (int it = 0; it < n; ++it) {
@@ -317,8 +326,28 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
                         dp_poison(e, ISK_EHIP, "injected rank error (option debug_inject_rank_error)");
                     e->bucket_issued = 0; e->bucket_err = 0;
                     e->grad_hook = bucketed ? dp_bucket_hook : nullptr;
+                    if (peer_mode) e->d_grad = e->d_grad_base + (size_t)(step_no & 1) * (e->nparams + 2);     // this step's slab
                     launch_grads(e, e->d_perm + (long long)b * local_batch, local_batch, 1.0f / (float)global_batch, nslab);
                     e->grad_hook = nullptr;
+                    if (peer_mode) {
+                        // One cross-engine dependency per step: this engine's optimizer step reads every engine's gradient slab.  The
+                        // slab of step s is rewritten by step s + 2 only, which follows (on its own stream) that engine's step s + 1,
+                        // which waited for every engine's gradient of s + 1, i.e. for every engine's optimizer step of s: no second wait.
+                        ScopedTimer ta(e, ISK_T_ALLREDUCE);
+                        const int par = (int)(step_no & 1);
+                        DPHIP(hipEventRecord(e->ev_grads[par], e->stream));
+                        const bool all_here = e->grp->wait();              // every engine's event is recorded before anyone waits for it
+                        OptPeers pp;
+                        pp.n = e->dp_world;
+                        for (int r = 0; r < e->dp_world; ++r) {
+                            isk_engine* o = e->grp->eng[r];
+                            pp.g[r] = o->d_grad_base + (size_t)par * (o->nparams + 2);
+                            if (o != e && all_here) DPHIP(hipStreamWaitEvent(e->stream, o->ev_grads[par], 0));
+                        }
+                        if (!all_here) dp_poison(e, ISK_EPEER, "a replica of the group left the run");
+                        launch_opt(e, 1.0f, !lazy_fold || (b == nbatches - 1 && !epoch_no_fold(e)), false, b == nbatches - 1, &pp);
+                        continue;
+                    }
                     if (coll) {
                         ScopedTimer ta(e, ISK_T_ALLREDUCE);
                         // bucketed: the layers >= 1 (and the loss / flag slots) left from inside the backward on the second stream;
@@ -354,6 +383,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
         }
         if (epochs == 0) CHK(check_status(e));
     }
+    leave_guard.done = true;
     if (e->dp_err != ISK_OK) return dp_clear_poison(e);       // raised behind the last epoch's collectives: nobody is left waiting
     return ISK_OK;
 }
@@ -380,6 +410,30 @@ extern "C" int isk_dp_create_all(const isk_config* cfg, const int32_t* devices, 
         if (r != ncclSuccess) rc = fail(ISK_EHIP, std::string("rccl: ") + g_rccl.GetErrorString(r));
         else
             for (int i = 0; i < n; ++i) { engines[i]->comm = comms[i]; engines[i]->dp_rank = i; engines[i]->dp_world = n; }
+    }
+    if (rc == ISK_OK && n > 1 && n <= ISK_DP_MAXPEER) {
+        // what the option dp_peer_reduce needs: every engine can read every other engine's gradient buffer (peer access between
+        // distinct devices; engines on one device -- the test set-up -- share an address space anyway), and an event per step parity
+        DpGroup* g = new DpGroup();
+        g->eng.assign(engines, engines + n);
+        bool peers_ok = true;
+        for (int i = 0; i < n && peers_ok; ++i) {
+            if (hipSetDevice(devices[i]) != hipSuccess) { peers_ok = false; break; }
+            for (int j = 0; j < n; ++j) {
+                if (devices[j] == devices[i]) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess || !can) { peers_ok = false; break; }
+                const hipError_t pe = hipDeviceEnablePeerAccess(devices[j], 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { peers_ok = false; break; }
+                (void)hipGetLastError();
+            }
+            for (int k = 0; k < 2 && peers_ok; ++k)
+                if (hipEventCreateWithFlags(&engines[i]->ev_grads[k], hipEventDisableTiming) != hipSuccess) peers_ok = false;
+            engines[i]->d_grad_base = engines[i]->d_grad;
+        }
+        (void)hipGetLastError();
+        if (peers_ok) for (int i = 0; i < n; ++i) engines[i]->grp = g;
+        else delete g;                   // no peer access: the group keeps its RCCL all-reduce (dp_peer_reduce is then ignored)
     }
     if (rc != ISK_OK) {
         const std::string msg = isk_last_error();
@@ -452,6 +506,7 @@ extern "C" int isk_dp_run_all(isk_engine** engines, int32_t n_engines, int32_t n
         if (bl < 1) return fail(ISK_EINVAL, "global minibatch smaller than the number of engines");
         nb = Nl / bl; gb = bl * n_engines;
     }
+    if (engines[0]->grp) engines[0]->grp->reset();
     std::vector<std::vector<double>> ls(n_engines, std::vector<double>((size_t)std::max(1, n * epochs), 0.0));
     const int rc = for_each_engine(engines, n_engines, [&](int i) {
         return isk_dp_run(engines[i], n, epochs, (int32_t)bl, (int32_t)nb, gb, perms ? perms[i] : nullptr, ls[i].data());

@@ -26,6 +26,7 @@ const OptDesc kOptions[] = {
     {"fwd_waves_per_simd", &IskOptions::fwd_waves_per_simd, 1, 4},
     {"dp_force_coll", &IskOptions::dp_force_coll, 0, 1},
     {"dp_bucket", &IskOptions::dp_bucket, 0, 1},
+    {"dp_peer_reduce", &IskOptions::dp_peer_reduce, 0, 1},
     {"train_bf16", &IskOptions::train_bf16, 0, 1},
     {"tail_narrow", &IskOptions::tail_narrow, 0, 1},
     {"train_persist", &IskOptions::train_persist, 0, 1},
@@ -78,6 +79,7 @@ extern "C" int isk_get_option(isk_engine* e, const char* key, int64_t* value) {
     if (!std::strcmp(key, "planes")) { *value = e->planes ? 1 : 0; return ISK_OK; }
     if (!std::strcmp(key, "nparams_engine")) { *value = e->nparams; return ISK_OK; }
     if (!std::strcmp(key, "layered_blas_active")) { *value = e->blas ? 1 : 0; return ISK_OK; }   // a rocBLAS handle exists: f32 training GEMMs went to the library
+    if (!std::strcmp(key, "dp_peer_active")) { *value = e->last_run_peer ? 1 : 0; return ISK_OK; }           // the last data-parallel run read its peers' gradients directly
     if (!std::strcmp(key, "train_persist_active")) { *value = e->last_epoch_persist ? 1 : 0; return ISK_OK; }   // the last epoch ran as one persistent launch
     if (!std::strcmp(key, "wide_fwd")) { *value = e->xh16 ? 1 : 0; return ISK_OK; }              // resident data runs the fused wide forward
     return fail(ISK_EINVAL, std::string("unknown option: ") + key);

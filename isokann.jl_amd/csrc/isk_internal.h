@@ -32,6 +32,8 @@ struct IskOptions {
     int train_graph = 1;          // replay the training epoch as one hipGraph
     int grad1_nw8 = -1;           // train_grad1n variant: 1 = 8 waves, 0 = 16 waves, -1 = 8 while the featurizer shares the CUs
     int fwd_waves_per_simd = 1;   // residency of the f32 forward kernel
+    int dp_peer_reduce = 0;       // single-process multi-GPU group (isk_dp_run_all): 1 = no gradient all-reduce at all -- every replica's
+                                  // optimizer step reads the other replicas' gradient buffers directly (peer-mapped) and sums them
     int dp_bucket = 1;            // native data-parallel run, wide networks: all-reduce the gradient in two buckets, the layers >= 1 under
                                   // the first layer's backward (0: one all-reduce behind the whole backward)
     int dp_force_coll = 0;        // issue the native collectives on a one-rank communicator (tests)
@@ -416,6 +418,11 @@ struct OptArgs {            // kept within two 64-byte kernarg lines
     float gscale;           // gradient multiplier (1, or 1/global_batch in data-parallel mode)
 };
 void isk_launch_opt_step(const OptArgs& a, hipStream_t st);
+// the same step with the gradient summed over the replicas of a single-process data-parallel group: g[r] is rank r's
+// [gradient | loss | flag] buffer (peer-mapped device memory), summed in rank order -- the same bits on every replica
+#define ISK_DP_MAXPEER 16
+struct OptPeers { const float* g[ISK_DP_MAXPEER]; int n; };
+void isk_launch_opt_step_peers(const OptArgs& a, const OptPeers& p, hipStream_t st);
 
 // ---------------------------------------------------------------- coordinate pullback ----
 // grad[n] = (d chi / d coords_n)' * cot[n]  (Zygote pullback of chicoords; the counterpart of the reference's

@@ -926,13 +926,21 @@ void isk_launch_train_grad1n(const TrainShape& s, const TrainBuffers& b, const i
 // The batch loss sits in grad[n]; a non-finite loss (or an earlier one in this epoch) skips the
 // update, as the reference throws before update! (src/iso.jl:186-189).
 static_assert(sizeof(OptArgs) <= 128, "OptArgs: two kernarg cache lines");
-__global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
+template <bool PEERS>
+__device__ __forceinline__ void opt_step_body(const OptArgs& a, const OptPeers& pr) {
     double* const loss_acc = a.loss_acc;
     ISK_LATENCY_CHAIN_PRIO();
     KSTAMP(4);
     const float bc1 = a.bt ? (float)(1.0 - a.bt[0]) : a.bc1, bc2 = a.bt ? (float)(1.0 - a.bt[1]) : a.bc2;
-    const float lstep = a.grad[a.n];
-    const float peer = a.grad[a.n + 1];                  // data-parallel: number of ranks that flagged an error in this step (else 0)
+    // PEERS: element i of the step's gradient is the sum over the replicas' buffers, in rank order (loss and flag slots alike)
+    auto gsum = [&](long long i) -> float {
+        if (!PEERS) return a.grad[i];
+        float s0 = pr.g[0][i];
+        for (int r = 1; r < pr.n; ++r) s0 += pr.g[r][i];
+        return s0;
+    };
+    const float lstep = gsum(a.n);
+    const float peer = gsum(a.n + 1);                    // data-parallel: number of ranks that flagged an error in this step (else 0)
     const double collapsed = loss_acc[1];
     // this thread's (first) parameter: its operands are requested before the batch loss is looked at -- waiting for the loss
     // first put a second memory round trip in front of every update
@@ -940,8 +948,8 @@ __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
     const bool in0 = i0 < a.n;
     const long long ic = in0 ? i0 : 0;
     const float th0 = a.theta[ic];
-    float gs0 = a.grad[ic];
-    if (ic < a.slab_prefix)                              // [LN | W1 | b1] gradients arrive split over row slabs
+    float gs0 = gsum(ic);
+    if (!PEERS && ic < a.slab_prefix)                    // [LN | W1 | b1] gradients arrive split over row slabs
         for (int sl = 1; sl < a.nslab; ++sl) gs0 += a.grad[(long long)sl * (a.n + 2) + ic];
     const float m0 = a.m[ic];
     const float v0 = a.kind == ISK_OPT_ADAM ? a.v[ic] : 0.f;
@@ -979,18 +987,31 @@ __global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
     };
     if (in0) update(i0, th0, gs0, m0, v0);
     for (long long i = i0 + (long long)gridDim.x * 256; i < a.n; i += (long long)gridDim.x * 256) {
-        float gs = a.grad[i];
-        if (i < a.slab_prefix)                           // [LN | W1 | b1] gradients arrive split over row slabs
+        float gs = gsum(i);
+        if (!PEERS && i < a.slab_prefix)                 // [LN | W1 | b1] gradients arrive split over row slabs
             for (int sl = 1; sl < a.nslab; ++sl) gs += a.grad[(long long)sl * (a.n + 2) + i];
         update(i, a.theta[i], gs, a.m[i], a.kind == ISK_OPT_ADAM ? a.v[i] : 0.f);
     }
 }
+
+__global__ __launch_bounds__(256) void opt_step_kernel(OptArgs a) {
+    const OptPeers none = {};
+    opt_step_body<false>(a, none);
+}
+__global__ __launch_bounds__(256) void opt_step_peers_kernel(OptArgs a, OptPeers p) { opt_step_body<true>(a, p); }
 
 void isk_launch_opt_step(const OptArgs& a, hipStream_t st) {
     long long b = (a.n + 255) / 256;
     if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     hipLaunchKernelGGL(opt_step_kernel, dim3((unsigned)b), dim3(256), 0, st, a);
+}
+
+void isk_launch_opt_step_peers(const OptArgs& a, const OptPeers& p, hipStream_t st) {
+    long long b = (a.n + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    hipLaunchKernelGGL(opt_step_peers_kernel, dim3((unsigned)b), dim3(256), 0, st, a, p);
 }
 
 // ------------------------------------------------------------------ coordinate pullback ---

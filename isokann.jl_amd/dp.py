@@ -370,6 +370,12 @@ class IsoAll:
         for i in range(self._n) if rank is None else [rank]:
             capi.check(self._lib.isk_set_option(self._h[i], key.encode(), int(value)))
 
+    def get_option(self, key: str, rank: int = 0) -> int:
+        import ctypes as C
+        v = C.c_int64(0)
+        capi.check(self._lib.isk_get_option(self._h[rank], key.encode(), C.byref(v)))
+        return int(v.value)
+
     def run(self, n: int = 1, epochs: int = 1, perms=None):
         """run!(iso, n, epochs); perms: optional list (one per engine) of (n*epochs, N/n_engines) LOCAL shuffle orders"""
         losses = np.zeros(max(1, n * epochs), np.float64)

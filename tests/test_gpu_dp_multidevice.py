@@ -21,8 +21,9 @@ from tests.test_gpu_dp_native2 import mock_lib  # noqa: E402,F401  (fixture)
 pytestmark = pytest.mark.gpu
 
 
-def _child(_, mock, outdir, nout, minibatch, niter, n_eng, opt, inject):
+def _child(_, mock, outdir, nout, minibatch, niter, n_eng, opt, inject, peer=0):
     os.environ["ISK_RCCL_LIB"] = mock
+    os.environ["ISK_DP_PEER_REDUCE"] = str(peer)           # (the option's default for the engines this process creates)
     import importlib
     import __graft_entry__ as ge
     pkg = ge.load_package()
@@ -42,7 +43,7 @@ def _child(_, mock, outdir, nout, minibatch, niter, n_eng, opt, inject):
         grp.run(niter, 1, perms=perms)
     except pkg.IskError as ex:
         err = f"{ex.status}|{ex}"
-    out = dict(losses=np.asarray(grp.losses), chi=grp.chis(), err=err, perms=np.stack(perms), nl=nl)
+    out = dict(losses=np.asarray(grp.losses), chi=grp.chis(), err=err, perms=np.stack(perms), nl=nl, peer_active=grp.get_option("dp_peer_active"))
     for r in range(n_eng):
         out[f"params{r}"] = grp.get_params(r)
     if inject:
@@ -95,6 +96,32 @@ def test_one_process_rank_error_stops_every_engine_in_the_same_step(gpu_pkg, moc
     causes on the others), the replicas stay bit-identical, the group runs on afterwards"""
     pkg = gpu_pkg
     o = _run_child(mock_lib, 3, 32, 2, 2, "nesterov", 2)
+    err = str(o["err"])
+    assert err.startswith(f"{pkg.capi.EHIP}|") and "rank 1" in err and "injected rank error" in err, err
+    np.testing.assert_array_equal(o["params0"], o["params1"])
+    assert len(o["losses"]) == 0 and len(o["losses_again"]) == 1 and np.isfinite(o["losses_again"][0])
+
+
+@pytest.mark.parametrize("nout,minibatch,n_eng,opt", [(3, 64, 2, "adam"), (3, 48, 3, "nesterov"), (1, 0, 2, "nesterov")])
+def test_peer_reduce_equals_the_all_reduce_bit_for_bit(gpu_pkg, mock_lib, nout, minibatch, n_eng, opt):   # noqa: F811
+    """option dp_peer_reduce: no gradient all-reduce -- every engine's optimizer step reads the other engines' gradient slabs
+    directly (peer-mapped; here the engines share one device) and sums them in rank order.  The mock collective library reduces in
+    rank order too, so the two runs must agree in every bit: losses, parameters of every replica, chi."""
+    a = _run_child(mock_lib, nout, minibatch, 3, n_eng, opt, 0, 1)
+    b = _run_child(mock_lib, nout, minibatch, 3, n_eng, opt, 0, 0)
+    assert str(a["err"]) == "" and str(b["err"]) == ""
+    assert int(a["peer_active"]) == 1 and int(b["peer_active"]) == 0
+    np.testing.assert_array_equal(a["losses"], b["losses"])
+    for r in range(n_eng):
+        np.testing.assert_array_equal(a[f"params{r}"], b["params0"])
+    np.testing.assert_array_equal(a["chi"], b["chi"])
+
+
+def test_peer_reduce_rank_error_stops_every_engine_in_the_same_step(gpu_pkg, mock_lib):   # noqa: F811
+    """the error flag of a replica travels in the slot behind the batch loss of its gradient slab: the peer sum carries it to every
+    engine in the same step, exactly as the all-reduce does"""
+    pkg = gpu_pkg
+    o = _run_child(mock_lib, 3, 32, 2, 2, "nesterov", 2, 1)
     err = str(o["err"])
     assert err.startswith(f"{pkg.capi.EHIP}|") and "rank 1" in err and "injected rank error" in err, err
     np.testing.assert_array_equal(o["params0"], o["params1"])
