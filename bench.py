@@ -368,12 +368,13 @@ def main():
             wide_fwd = bool(iso.get_option("wide_fwd"))
         except Exception:
             wide_fwd = False
-        for pmf in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+        for pmf in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
             try:
                 if wide_fwd and args.workload == "c5shard" and world == 1 and not args.shard_of:
-                    pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary_c5.json")))
+                    c5f = "r04_pmc_summary_c5.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_summary_c5.json")) else "r03_pmc_summary_c5.json"
+                    pm = json.load(open(os.path.join(ROOT, "profiles", c5f)))
                     traffic = pm["mlp_fwd_traffic_bytes_per_launch"]
-                    traffic_source = ("profiles/r03_pmc_summary_c5.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this workload on its "
+                    traffic_source = ("profiles/" + c5f + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this workload on its "
                                       "bf16 path; not measured in this run)")
                     break
                 pm = json.load(open(os.path.join(ROOT, "profiles", pmf)))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # regenerate the committed evidence under profiles/ (run on the GPU box): scripts/refresh_profiles.sh r01
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 mkdir -p gpurun_out/ref
 b() { name=$1; shift; python3 bench.py "$@" 2> gpurun_out/ref/$name.err | tail -1 > gpurun_out/ref/${tag}_bench_$name.json; python3 -c "
 import json,sys; d=json.load(open('gpurun_out/ref/${tag}_bench_$name.json')); print('$name', round(d['ms_per_step'],3), 'ms', round(d['value']/1e6,1), 'M/s frac', round(d['roofline']['frac'],3))"; }
@@ -14,21 +14,34 @@ b c3_mb100_nesterov --minibatch 100 --opt nesterov
 b c2 --workload c2
 b c5shard --workload c5shard --forward-mode 1 --no-cpu-baseline                               # split-bf16 forward (f32-equivalent), f32 training
 b c5shard_f32fwd --workload c5shard --forward-mode 0 --no-cpu-baseline
-b c5shard_bf16fwd --workload c5shard --forward-mode 2 --no-train-bf16 --no-cpu-baseline      # fused bf16 forward, f32 training (rocBLAS)
+b c5shard_bf16fwd --workload c5shard --forward-mode 2 --no-train-bf16 --no-cpu-baseline      # fused bf16 forward, f32 training: the in-house NT GEMMs in Float32 arithmetic (default since round 4)
+ISK_LAYERED_BLAS=1 b c5shard_bf16fwd_rocblas --workload c5shard --forward-mode 2 --no-train-bf16 --no-cpu-baseline   # ... and through rocBLAS sgemm (option layered_blas = 1)
 b c5shard_bf16 --workload c5shard --forward-mode 2 --train-bf16 --no-cpu-baseline          # the arithmetic BASELINE names for C5: forward AND training GEMMs on bf16
 # the same through the native data-parallel driver with every collective on a one-rank communicator: what ONE of C5's 8 ranks runs
 ISK_DP_FORCE_COLL=1 b c5shard_bf16_dp1 --workload c5shard --forward-mode 2 --train-bf16 --force-dp --no-cpu-baseline
 b c3_bf16fwd --forward-mode 2 --no-cpu-baseline
+b c3_pullback --pullback 2048 --no-cpu-baseline                                          # + the coordinate pullback on 2048 columns (field "pullback")
+# the persistent training-epoch kernel (experimental option train_persist, default off): measured against the launch chain
+ISK_TRAIN_PERSIST=1 b c3_persist --no-cpu-baseline
+ISK_TRAIN_PERSIST=1 b c3_cached_persist --cached-features --no-cpu-baseline
+ISK_TRAIN_PERSIST=1 b c3_mb100_nesterov_persist --minibatch 100 --opt nesterov --no-cpu-baseline
+ISK_TAIL_NARROW=0 b c3_generic_tail --no-cpu-baseline                                    # round 3's train_tail kernel, for the A/B on this box
 # one rank's share of the 8-way strong-scaled runs (C4: N = 1250, local batch 125; collectives on a one-rank communicator)
 b c4_shard_of_8 --shard-of 8 --no-cpu-baseline
 b c4_shard_of_4 --shard-of 4 --no-cpu-baseline
 b c4_shard_of_2 --shard-of 2 --no-cpu-baseline
 bash scripts/prof_bench.sh c3stats > gpurun_out/ref/prof.txt 2>&1 || true
 cp gpurun_out/prof_c3stats/c3stats_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c3.csv
-ISK_TRAIN_GRAPH=0 bash scripts/prof_bench.sh c3mb100 --minibatch 100 --opt nesterov >> gpurun_out/ref/prof.txt 2>&1 || true      # (rocprofv3 segfaults on the 400-kernel graph replay: eager launches for this trace)
+# (round 3 traced this configuration with eager launches because rocprofv3 segfaulted on the 400-kernel graph replay; in round 4 the
+# same command runs through -- the trace is the product's graph path again; ISK_TRAIN_GRAPH=0 is the fallback if it does not)
+bash scripts/prof_bench.sh c3mb100 --minibatch 100 --opt nesterov >> gpurun_out/ref/prof.txt 2>&1 || ISK_TRAIN_GRAPH=0 bash scripts/prof_bench.sh c3mb100 --minibatch 100 --opt nesterov >> gpurun_out/ref/prof.txt 2>&1 || true
 cp gpurun_out/prof_c3mb100/c3mb100_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c3_mb100_nesterov.csv
 bash scripts/prof_bench.sh c5stats --workload c5shard --forward-mode 2 --train-bf16 >> gpurun_out/ref/prof.txt 2>&1 || true
 cp gpurun_out/prof_c5stats/c5stats_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c5shard.csv
+bash scripts/prof_bench.sh c5f32 --workload c5shard --forward-mode 2 --no-train-bf16 >> gpurun_out/ref/prof.txt 2>&1 || true
+cp gpurun_out/prof_c5f32/c5f32_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c5shard_f32train.csv
+bash scripts/prof_bench.sh c4s8 --shard-of 8 >> gpurun_out/ref/prof.txt 2>&1 || true
+cp gpurun_out/prof_c4s8/c4s8_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c4_shard_of_8.csv
 bash scripts/pmc.sh > gpurun_out/ref/pmc.txt 2>&1 || true
 python3 - <<PY
 import json
@@ -41,3 +54,9 @@ tail -3 gpurun_out/ref/pmc.txt
 bash scripts/pmc.sh c5 --workload c5shard --forward-mode 2 --train-bf16 > gpurun_out/ref/pmc_c5.txt 2>&1 || true
 cp gpurun_out/pmc_summary_c5.json gpurun_out/ref/${tag}_pmc_summary_c5.json
 tail -2 gpurun_out/ref/pmc_c5.txt
+# L2 read-request split (TCC_EA0_RDREQ by size, hit / miss) of the forward kernels
+bash scripts/pmc_tcc.sh c3 > gpurun_out/ref/tcc_c3.txt 2>&1 || true
+bash scripts/pmc_tcc.sh c5 --workload c5shard --forward-mode 2 --train-bf16 > gpurun_out/ref/tcc_c5.txt 2>&1 || true
+cp gpurun_out/pmc_tcc_c3.json gpurun_out/ref/${tag}_pmc_tcc_c3_raw.json 2>/dev/null || true
+cp gpurun_out/pmc_tcc_c5.json gpurun_out/ref/${tag}_pmc_tcc_c5_raw.json 2>/dev/null || true
+python3 scripts/c3sub_table.py > gpurun_out/ref/${tag}_c3sub_error_table.md 2> gpurun_out/ref/c3sub_table.err || true
