@@ -1,9 +1,9 @@
 #!/bin/bash
-# rocprofv3 kernel stats of a bench.py run: scripts/prof_bench.sh <tag> [bench args...]
+# rocprofv3 kernel stats of a bench.py run: scripts/prof_bench.sh <tag> [bench args...]   (PROF_STEPS / PROF_WARMUP: iterations traced)
 tag=$1; shift
 R=$(pwd); mkdir -p $R/gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -o $tag -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --sustained-s 0 --no-f32-reference "$@" > $R/gpurun_out/prof_$tag/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -o $tag -- python3 $R/bench.py --steps ${PROF_STEPS:-30} --warmup ${PROF_WARMUP:-5} --no-cpu-baseline --sustained-s 0 --no-f32-reference "$@" > $R/gpurun_out/prof_$tag/log.txt 2>&1
 cd $R
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'

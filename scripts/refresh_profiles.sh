@@ -1,10 +1,10 @@
 #!/bin/bash
 # regenerate the committed evidence under profiles/ (run on the GPU box): scripts/refresh_profiles.sh r01
-set -e
 tag=${1:-r04}
 mkdir -p gpurun_out/ref
 b() { name=$1; shift; python3 bench.py "$@" 2> gpurun_out/ref/$name.err | tail -1 > gpurun_out/ref/${tag}_bench_$name.json; python3 -c "
 import json,sys; d=json.load(open('gpurun_out/ref/${tag}_bench_$name.json')); print('$name', round(d['ms_per_step'],3), 'ms', round(d['value']/1e6,1), 'M/s frac', round(d['roofline']['frac'],3))"; }
+if [ -z "$SKIP_BENCH" ]; then
 b c3
 b c3_bf16x3fwd --forward-mode 1
 b c3_f32fwd --forward-mode 0
@@ -30,12 +30,17 @@ ISK_TAIL_NARROW=0 b c3_generic_tail --no-cpu-baseline                           
 b c4_shard_of_8 --shard-of 8 --no-cpu-baseline
 b c4_shard_of_4 --shard-of 4 --no-cpu-baseline
 b c4_shard_of_2 --shard-of 2 --no-cpu-baseline
+fi
 bash scripts/prof_bench.sh c3stats > gpurun_out/ref/prof.txt 2>&1 || true
 cp gpurun_out/prof_c3stats/c3stats_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c3.csv
-# (round 3 traced this configuration with eager launches because rocprofv3 segfaulted on the 400-kernel graph replay; in round 4 the
-# same command runs through -- the trace is the product's graph path again; ISK_TRAIN_GRAPH=0 is the fallback if it does not)
-bash scripts/prof_bench.sh c3mb100 --minibatch 100 --opt nesterov >> gpurun_out/ref/prof.txt 2>&1 || ISK_TRAIN_GRAPH=0 bash scripts/prof_bench.sh c3mb100 --minibatch 100 --opt nesterov >> gpurun_out/ref/prof.txt 2>&1 || true
-cp gpurun_out/prof_c3mb100/c3mb100_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c3_mb100_nesterov.csv
+# The epoch graph of this configuration has 400 kernel nodes.  rocprofv3 (ROCm 7.2) segfaults INSIDE its interception of
+# hipGraphLaunch once about 10 000 graph-launched kernels have been traced in one process (SIGSEGV at a page-aligned address,
+# frames in the tool library under train_epoch -> hipGraphLaunch; 12 iterations = 4 800 kernels trace fine, 35 = 14 000 crash;
+# without the profiler, and with the profiler on eager launches, any length runs): a capacity limit of the tool, not the engine's
+# capture.  So the graph path is traced over 12 iterations (round 3 traced eager launches instead).
+rm -rf gpurun_out/prof_c3mb100
+PROF_STEPS=10 PROF_WARMUP=2 bash scripts/prof_bench.sh c3mb100 --minibatch 100 --opt nesterov >> gpurun_out/ref/prof.txt 2>&1 || true
+cp gpurun_out/prof_c3mb100/c3mb100_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c3_mb100_nesterov.csv || true
 bash scripts/prof_bench.sh c5stats --workload c5shard --forward-mode 2 --train-bf16 >> gpurun_out/ref/prof.txt 2>&1 || true
 cp gpurun_out/prof_c5stats/c5stats_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c5shard.csv
 bash scripts/prof_bench.sh c5f32 --workload c5shard --forward-mode 2 --no-train-bf16 >> gpurun_out/ref/prof.txt 2>&1 || true
