@@ -142,6 +142,8 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *   train_persist       0        training on one GPU: 1 = an epoch as ONE persistent launch where the network allows it (narrow tail,
  *                                sigmoid hidden layers, batches of at most 1024 rows).  Experimental: correct, and slower than the four
  *                                launches per optimizer step it replaces
+ *   fuse_opt            1        training on one GPU with batches of at most 768 rows (one row slab): the optimizer step rides on the
+ *                                layer-1 gradient kernel -- three launches per optimizer step instead of four
  *   tail_narrow         1        training: register-resident tail kernel where every tail layer is <= 16 wide (0: the generic LDS kernel)
  *   fwd_waves_per_simd  1        residency of the f32-MFMA forward kernel
  *   bf16_skew           1        split-bf16 forward: the second wave of a SIMD converts in the first half of a stage

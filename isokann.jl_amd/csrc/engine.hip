@@ -1050,7 +1050,32 @@ static int grad1_flags(const isk_engine* e, int nslab) {
 
 // one optimizer step's gradient into d_grad (slab 0 .. nslab-1).  step: an optimizer step follows (launch_opt), so
 // train_tail hands the Adam bias corrections of this step over on the device
-void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nslab, bool step, bool capturing) {
+// the arguments of this step's optimizer kernel (opt_step, or train_grad1n carrying it)
+static OptArgs opt_args(isk_engine* e, float gscale, bool publish) {
+    OptArgs a;
+    a.theta = e->d_theta; a.grad = e->d_grad; a.m = e->d_m; a.v = e->d_v; a.n = e->nparams;
+    a.kind = e->cfg.opt_kind; a.lr = e->cfg.lr; a.reg = e->cfg.reg; a.beta1 = e->cfg.beta1; a.beta2 = e->cfg.beta2;
+    a.eps = e->cfg.opt_eps; a.rho = e->cfg.rho;
+    a.bc1 = (float)(1.0 - e->bt1); a.bc2 = (float)(1.0 - e->bt2);
+    // fused path: the bias corrections of this step were handed over on the device by train_tail (launch_grads)
+    const bool dev = !e->layered && e->bt_dev_valid;
+    a.bt = dev ? e->d_bt + 2 : nullptr;
+    a.gscale = gscale; a.loss_acc = e->d_loss_acc;
+    a.host_pub = publish ? e->d_hres : nullptr;
+    a.nslab = e->last_nslab;
+    a.slab_prefix = e->off_b[0] + e->cfg.widths[1];          // [LN | W1 | b1]: the blocks train_grad1n writes per row slab
+    return a;
+}
+
+// fuse_mode: 0 = the gradient goes to d_grad; 1 = the optimizer step rides on train_grad1n (the caller then runs launch_opt with
+// kernel_done = true for the host-side bookkeeping); 2 = the same, and it is the epoch's last step (publishes the result)
+bool can_fuse_opt(const isk_engine* e, int B, int nslab) {
+    if (!e->opt.fuse_opt || e->layered || !e->native) return false;
+    const bool nw8 = e->opt.grad1_nw8 >= 0 ? e->opt.grad1_nw8 != 0 : e->ys_ahead;
+    return isk_train_grad1n_can_fuse(train_shape(e), e->Fp, B, nslab, nw8 ? 1 : 0);
+}
+
+void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nslab, bool step, bool capturing, int fuse_mode) {
     if (e->layered) { launch_grads_layered(e, d_idx, B, inv_div); return; }
     const TrainShape s = train_shape(e);
     TrainBuffers b = train_buffers(e);
@@ -1060,8 +1085,13 @@ void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nsl
     if (step && (capturing ? e->bt_dev_valid : prepare_dev_bt(e))) b.bt = e->d_bt;
     isk_launch_train_fwd1n(s, b, d_idx, B, e->stream);
     isk_launch_train_tail(s, b, d_idx, B, inv_div, e->stream);
-    isk_launch_train_grad1n(s, b, d_idx, B, grad1_flags(e, nslab), e->stream);
     e->last_nslab = nslab;
+    if (fuse_mode) {
+        const OptArgs oa = opt_args(e, 1.0f, fuse_mode == 2);
+        isk_launch_train_grad1n(s, b, d_idx, B, grad1_flags(e, nslab), e->stream, &oa);
+    } else {
+        isk_launch_train_grad1n(s, b, d_idx, B, grad1_flags(e, nslab), e->stream);
+    }
 }
 
 // fold: refresh the weight images the forward / training kernels read.  The rocBLAS variant of the layered training
@@ -1076,22 +1106,14 @@ bool epoch_lazy_fold(isk_engine* e) { return e->layered && !e->cfg.layernorm && 
 // GEMMs theirs (a forward of foreign rows through the generic layered kernels folds on demand: wt_dirty stays set)
 bool epoch_no_fold(isk_engine* e) { return epoch_lazy_fold(e) && e->xh16 && (bf16_train_active(e) || mfma32_train_active(e)); }
 
-void launch_opt(isk_engine* e, float gscale, bool fold, bool capturing, bool publish, const OptPeers* peers) {
-    OptArgs a;
-    a.theta = e->d_theta; a.grad = e->d_grad; a.m = e->d_m; a.v = e->d_v; a.n = e->nparams;
-    a.kind = e->cfg.opt_kind; a.lr = e->cfg.lr; a.reg = e->cfg.reg; a.beta1 = e->cfg.beta1; a.beta2 = e->cfg.beta2;
-    a.eps = e->cfg.opt_eps; a.rho = e->cfg.rho;
-    a.bc1 = (float)(1.0 - e->bt1); a.bc2 = (float)(1.0 - e->bt2);
-    // fused path: the bias corrections of this step were handed over on the device by train_tail (launch_grads)
+void launch_opt(isk_engine* e, float gscale, bool fold, bool capturing, bool publish, const OptPeers* peers, bool kernel_done) {
     const bool dev = !e->layered && e->bt_dev_valid;
     (void)capturing;
-    a.bt = dev ? e->d_bt + 2 : nullptr;
-    a.gscale = gscale; a.loss_acc = e->d_loss_acc;
-    a.host_pub = publish ? e->d_hres : nullptr;
-    a.nslab = e->last_nslab;
-    a.slab_prefix = e->off_b[0] + e->cfg.widths[1];          // [LN | W1 | b1]: the blocks train_grad1n writes per row slab
-    if (peers) isk_launch_opt_step_peers(a, *peers, e->stream);
-    else isk_launch_opt_step(a, e->stream);
+    if (!kernel_done) {                          // (kernel_done: train_grad1n carried the step -- launch_grads with fuse_mode)
+        const OptArgs a = opt_args(e, gscale, publish);
+        if (peers) isk_launch_opt_step_peers(a, *peers, e->stream);
+        else isk_launch_opt_step(a, e->stream);
+    }
     e->loss_acc_zeroed = false;
     e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2;
     if (!dev) e->bt_dev_valid = false;           // this step advanced only the host copy
@@ -1220,7 +1242,8 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
     if (!tg) {                                           // a free slot, else the one that does not belong to the other live buffer
         tg = !e->tg[0].exec ? &e->tg[0] : (!e->tg[1].exec ? &e->tg[1] : (e->tg[0].xs == e->d_xs32_alt ? &e->tg[1] : &e->tg[0]));
     }
-    if (!tg->exec || tg->bs != bs || tg->nb != nb || tg->flags != flags || tg->xs != xs_rows) {
+    const int flags_f = flags | (can_fuse_opt(e, (int)bs, nslab) ? 0x1000 : 0);        // (the fused step is part of what the graph was captured for)
+    if (!tg->exec || tg->bs != bs || tg->nb != nb || tg->flags != flags_f || tg->xs != xs_rows) {
         if (tg->exec) { (void)hipGraphExecDestroy(tg->exec); tg->exec = nullptr; }
         const double s1 = e->bt1, s2 = e->bt2;
         if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
@@ -1228,9 +1251,10 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
             e->tg_disabled = true;
             return false;
         }
+        const bool fuse = can_fuse_opt(e, (int)bs, nslab);
         for (long long b = 0; b < nb; ++b) {
-            launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, nslab, true, true);
-            launch_opt(e, 1.0f, true, true, b == nb - 1);
+            launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, nslab, true, true, fuse ? (b == nb - 1 ? 2 : 1) : 0);
+            launch_opt(e, 1.0f, true, true, b == nb - 1, nullptr, fuse);
         }
         hipGraph_t g = nullptr;
         hipError_t r = hipStreamEndCapture(e->stream, &g);
@@ -1243,7 +1267,7 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
             e->tg_disabled = true;
             return false;
         }
-        tg->bs = bs; tg->nb = nb; tg->flags = flags; tg->xs = xs_rows;
+        tg->bs = bs; tg->nb = nb; tg->flags = flags_f; tg->xs = xs_rows;
     } else {
         // what the launch functions keep track of on the host
         for (long long b = 0; b < nb; ++b) { e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2; }
@@ -1308,9 +1332,11 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
         ScopedTimer t(e, ISK_T_TRAIN);
         const bool lazy_fold = epoch_lazy_fold(e);
         if (!train_epoch_persist(e, bs, nb) && !train_epoch_graph(e, bs, nb)) {
+            const int nsl = pick_slabs((int)bs);
+            const bool fuse = can_fuse_opt(e, (int)bs, nsl);
             for (long long b = 0; b < nb; ++b) {
-                launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, pick_slabs((int)bs));
-                launch_opt(e, 1.0f, !lazy_fold || (b == nb - 1 && !epoch_no_fold(e)), false, b == nb - 1);
+                launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, nsl, true, false, fuse ? (b == nb - 1 ? 2 : 1) : 0);
+                launch_opt(e, 1.0f, !lazy_fold || (b == nb - 1 && !epoch_no_fold(e)), false, b == nb - 1, nullptr, fuse);
             }
         }
     }

@@ -277,8 +277,10 @@ int check_status(isk_engine* e);
 int compute_target(isk_engine* e, bool check, bool ahead = false);
 int pick_slabs(int B);
 bool prepare_dev_bt(isk_engine* e);
-void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nslab = 1, bool step = true, bool capturing = false);
-void launch_opt(isk_engine* e, float gscale, bool fold = true, bool capturing = false, bool publish = true, const OptPeers* peers = nullptr);
+void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nslab = 1, bool step = true, bool capturing = false, int fuse_mode = 0);
+bool can_fuse_opt(const isk_engine* e, int B, int nslab);
+void launch_opt(isk_engine* e, float gscale, bool fold = true, bool capturing = false, bool publish = true, const OptPeers* peers = nullptr,
+                bool kernel_done = false);
 bool epoch_lazy_fold(isk_engine* e);             // the forward weight images may wait for the epoch's last optimizer step
 bool epoch_no_fold(isk_engine* e);               // ... or for a forward that actually reads them
 int stage_perm_ahead(isk_engine* e, const int32_t* perm);

@@ -29,6 +29,7 @@ const OptDesc kOptions[] = {
     {"dp_peer_reduce", &IskOptions::dp_peer_reduce, 0, 1},
     {"train_bf16", &IskOptions::train_bf16, 0, 1},
     {"tail_narrow", &IskOptions::tail_narrow, 0, 1},
+    {"fuse_opt", &IskOptions::fuse_opt, 0, 1},
     {"train_persist", &IskOptions::train_persist, 0, 1},
     {"wide_fused", &IskOptions::wide_fused, 0, 1},
     {"debug_inject_rank_error", &IskOptions::debug_inject_rank_error, 0, 1 << 30},

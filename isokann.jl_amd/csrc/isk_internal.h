@@ -40,6 +40,8 @@ struct IskOptions {
     int wide_fused = 1;           // layered path, plain-bf16 forward: the fused wide kernel (0: layer by layer through HBM)
     int train_persist = 0;        // fused path, single GPU: a training epoch as ONE persistent launch (experimental: measured SLOWER
                                   // than the four launches per optimizer step it replaces -- DESIGN.md section 6c; default off)
+    int fuse_opt = 1;             // training on one GPU, one row slab (batches <= 768 rows): the optimizer step rides on train_grad1n
+                                  // (three launches per step instead of four)
     int tail_narrow = 1;          // fused path: register-resident train_tail for narrow tails (0: the generic LDS kernel)
     int train_bf16 = 0;           // layered path: training GEMMs with bf16 operands (f32 master weights, f32 accumulate): the C5
                                   // arithmetic of BASELINE.json; 0 = f32
@@ -358,7 +360,10 @@ void isk_launch_train_tail(const TrainShape& s, const TrainBuffers& b, const int
 bool isk_train_tail_narrow_ok(const TrainShape& s);
 void isk_launch_train_tail_narrow(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div, hipStream_t st);
 // cotangent mode: b.target holds the cotangent [B][nout]; delta_L = cot .* act'(z_L), no loss, no weights
-void isk_launch_train_grad1n(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st);
+struct OptArgs;
+// fuse: the optimizer step rides on the kernel (see isk_train_grad1n_can_fuse); nullptr: the gradient goes to b.grad
+void isk_launch_train_grad1n(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st, const OptArgs* fuse = nullptr);
+bool isk_train_grad1n_can_fuse(const TrainShape& s, int Fp, int B, int nslab, int nw8);
 // ---------------------------------------------------------------- narrow tails (train_tailn.hpp) ----
 #define TN_MAXL 3                   /* tail layers of the register-resident tail */
 struct TailNLay {

@@ -716,14 +716,39 @@ __device__ __forceinline__ long long part_to_grad(const TrainShape& s, long long
     return -1;
 }
 
+
+// WeightDecay + Adam | Nesterov on one parameter (Optimisers.jl 0.4.7).  ONE definition for opt_step_kernel and for the kernels
+// that carry the step themselves, with every product / sum pinned (explicit fmaf, __fmul_rn): left to the compiler, which product
+// of `gs * gscale + reg * th` is contracted into the fma depends on the surrounding code, and the fused and unfused steps then
+// differ in the last bit of a third of the parameters.
+__device__ __forceinline__ void opt_rule(const OptArgs& a, float bc1, float bc2, float gs, float& th, float& mi, float& vi) {
+    const float g = fmaf(a.reg, th, __fmul_rn(gs, a.gscale));
+    float d;
+    if (a.kind == ISK_OPT_ADAM) {
+        const float m = fmaf(a.beta1, mi, __fmul_rn(1.f - a.beta1, g));
+        const float v = fmaf(a.beta2, vi, __fmul_rn(__fmul_rn(1.f - a.beta2, g), g));
+        mi = m; vi = v;
+        d = __fmul_rn(__fdiv_rn(__fdiv_rn(m, bc1), __fadd_rn(sqrtf(__fdiv_rn(v, bc2)), a.eps)), a.lr);
+    } else {
+        d = fmaf(-__fmul_rn(a.rho, a.rho), mi, __fmul_rn(__fmul_rn(1.f + a.rho, a.lr), g));
+        mi = fmaf(a.rho, mi, -__fmul_rn(a.lr, g));
+    }
+    th = __fsub_rn(th, d);
+}
+
 #ifdef ISK_TAIL_STAMP
 #define GSTAMP(k) do { if (blockIdx.x == 5 && blockIdx.y == 0 && threadIdx.x == 0) g_tail_stamps[8 + k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GSTAMP(k) do { } while (0)
 #endif
-template <int NT, int NW>
+// OPT (one row slab, one GPU): the optimizer step rides on this kernel -- the workgroup that produces a gradient element owns the
+// parameter.  Round 2 measured that fusion at -2 % (3.87 vs 3.96 ms per iteration at minibatch 100): its m / v loads sat at the END
+// of the kernel, a dependent round trip that cost what the saved launch was worth.  Here every optimizer operand -- theta, m, v of
+// the W1 share, of the LayerNorm / bias / tail-parameter elements this thread will update, the units' loss partials, the epoch's
+// collapse flag, Adam's bias corrections -- is requested at the kernel's start and arrives under the main loop.
+template <int NT, int NW, bool OPT = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(TrainShape s, TrainBuffers b, const int* __restrict__ perm,
-                                                              int B, int nparts) {
+                                                              int B, int nparts, OptArgs oa) {
     ISK_LATENCY_CHAIN_PRIO();
     KSTAMP(3);
     GSTAMP(0);
@@ -760,6 +785,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const int w = li + 16 * u; red_pv[u] = (w < nparts) ? b.part[(long long)w * PS + red_grp] : 0.f; }
     }
+    // ---- OPT: every operand of the optimizer step this thread will take, requested now
+    float o_th[NE], o_m[NE], o_v[NE];
+    float b1_grad = 0.f;
+    float ln_th = 0.f, ln_m = 0.f, ln_v = 0.f, b1_th = 0.f, b1_m = 0.f, b1_v = 0.f, sp_th = 0.f, sp_m = 0.f, sp_v = 0.f, lossp = 0.f;
+    long long sp_gi = -1;
+    float sp_racc = 0.f;
+    double o_coll = 0.0;
+    float bc1 = 1.f, bc2 = 1.f, o_peer = 0.f;
+    const bool adam = oa.kind == ISK_OPT_ADAM;
+    const long long wbase = s.off_W[0] + (long long)ft * NT * 256;
     GSTAMP(1);
     f32x4 acc[NT];
     float dsum[NT];
@@ -830,8 +865,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(
 #pragma unroll
             for (int sft = 8; sft > 0; sft >>= 1) racc += __shfl_xor(racc, sft, WAVE);
             const long long gi = part_to_grad(s, e);
-            if (li == 0 && gi >= 0) gout[gi] = racc;
-            if (e == 0 && li == 0) gout[s.nparams + 1] = b.rank_err ? (float)*b.rank_err : 0.f;     // behind the loss: this rank's error flag
+            if (OPT) {
+                // (the launcher guarantees one element per group: e == red_grp, operands prefetched.)  The tail parameter behind
+                // this element is updated by lane 0 of the group once the batch loss is known, below
+                sp_racc = racc;
+                if (e == 0 && li == 0) { gout[s.nparams] = racc; gout[s.nparams + 1] = o_peer; }
+            } else {
+                if (li == 0 && gi >= 0) gout[gi] = racc;
+                if (e == 0 && li == 0) gout[s.nparams + 1] = b.rank_err ? (float)*b.rank_err : 0.f;     // behind the loss: this rank's error flag
+            }
         }
     }
     GSTAMP(2);
@@ -846,19 +888,84 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(
     // what the epilogue needs from memory is requested here (the accumulators are parked, registers are free) and arrives
     // under the two barriers: this thread's share of W1 (fragment-linear: contiguous) and its feature's LayerNorm scale / bias
     float w1v[NE];
+    if (OPT) {
+        // every operand of the optimizer step this thread will take: requested HERE, where the accumulators are parked and registers
+        // are free -- the loads arrive under the two barriers of the reduction (held across the main loop they cost 264 bytes of
+        // scratch per lane)
+        if (ln && tid < 32) {
+            const long long gi = ((tid >> 4) ? s.off_lnb : s.off_lns) + ft * 16 + (tid & 15);
+            ln_th = oa.theta[gi]; ln_m = oa.m[gi]; ln_v = adam ? oa.v[gi] : 0.f;
+        }
+        if (ft == 0 && tid < H1) {
+            const long long gi = s.off_b[0] + tid;
+            b1_th = oa.theta[gi]; b1_m = oa.m[gi]; b1_v = adam ? oa.v[gi] : 0.f;
+        }
+        if (red_pre && red_grp != 0) {
+            sp_gi = part_to_grad(s, red_grp);
+            if (sp_gi >= 0) { sp_th = oa.theta[sp_gi]; sp_m = oa.m[sp_gi]; sp_v = adam ? oa.v[sp_gi] : 0.f; }
+        }
+        if (tid < 64) lossp = tid < nparts ? b.part[(long long)tid * PS] : 0.f;      // (one row slab: nparts <= 48 units)
+        o_coll = oa.loss_acc[1];
+        o_peer = b.rank_err ? (float)*b.rank_err : 0.f;
+        bc1 = oa.bt ? (float)(1.0 - oa.bt[0]) : oa.bc1;
+        bc2 = oa.bt ? (float)(1.0 - oa.bt[1]) : oa.bc2;
 #pragma unroll
-    for (int i = 0; i < NE; ++i) w1v[i] = (ln && tid + NTH * i < NT * 256) ? W1n[tid + NTH * i] : 0.f;
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + NTH * i;
+            const long long gi = wbase + (e < NT * 256 ? e : 0);
+            o_th[i] = oa.theta[gi]; o_m[i] = oa.m[gi]; o_v[i] = adam ? oa.v[gi] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) w1v[i] = OPT ? ((ln && tid + NTH * i < NT * 256) ? o_th[i] : 0.f) : ((ln && tid + NTH * i < NT * 256) ? W1n[tid + NTH * i] : 0.f);
+
     const float gk = ln ? b.theta[s.off_lns + k] : 1.f, bk = ln ? b.theta[s.off_lnb + k] : 0.f;   // LayerNorm blocks are padded to Fp
     __syncthreads();
+    if (OPT && tid < 64) {
+        // the batch loss, summed the same way by every workgroup (the same skip / apply decision everywhere); behind the first
+        // barrier: its load has had the barrier's wait to arrive
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lossp += __shfl_xor(lossp, o, WAVE);
+        if (tid == 0) psh[NW * 8] = lossp;
+    }
     if (tid < NT * 16) {                                               // D[o], o = 16 t + li = tid
         float d = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) d += Dred[w * NT * 16 + tid];
         Dsh[tid] = d;
-        if (ft == 0 && tid < H1) gout[s.off_b[0] + tid] = d;            // db1 == D (this slab's rows)
+        if (!OPT && ft == 0 && tid < H1) gout[s.off_b[0] + tid] = d;    // db1 == D (this slab's rows)
+        if (OPT) b1_grad = d;
     }
     __syncthreads();
     GSTAMP(3);
+    // OPT: the step's verdict (opt_step_kernel's): a non-finite batch loss -- or an earlier one in this epoch -- skips every update
+    const float lstep = OPT ? psh[NW * 8] : 0.f;
+    const bool bad = OPT && ((o_coll != 0.0) || !isfinite(lstep) || o_peer != 0.f);
+    if (OPT && ft == 0 && tid == 0) {
+        double* const loss_acc = oa.loss_acc;
+        double acc0 = loss_acc[0];
+        if (o_peer != 0.f) loss_acc[3] = (double)o_peer;
+        if (bad) loss_acc[1] = 1.0;
+        else { acc0 += (double)lstep; loss_acc[0] = acc0; }
+        if (oa.host_pub) {
+            oa.host_pub[0] = acc0;
+            oa.host_pub[1] = bad ? 1.0 : 0.0;
+            ((int*)(oa.host_pub + 2))[0] = ((const int*)(loss_acc + 2))[0];
+            oa.host_pub[3] = o_peer != 0.f ? (double)o_peer : loss_acc[3];
+            __threadfence_system();
+        }
+    }
+    if (OPT && !bad) {
+        if (ft == 0 && tid < H1) {                                      // layer-1 bias: gradient D
+            opt_rule(oa, bc1, bc2, b1_grad, b1_th, b1_m, b1_v);
+            const long long gi = s.off_b[0] + tid;
+            oa.theta[gi] = b1_th; oa.m[gi] = b1_m; if (adam) oa.v[gi] = b1_v;
+        }
+        if (sp_gi >= 0 && li == 0 && red_pre) {                         // this group's tail parameter
+            opt_rule(oa, bc1, bc2, sp_racc, sp_th, sp_m, sp_v);
+            oa.theta[sp_gi] = sp_th; oa.m[sp_gi] = sp_m; if (adam) oa.v[sp_gi] = sp_v;
+        }
+    }
     // Epilogue.  Thread tid keeps accumulator slot (lane' = (tid/4) % 64, r = tid % 4) for the tiles t = tid/256 + (NTH/256) i:
     // feature k = 16 ft + 4 (lane'/16) + r, output 16 t + lane'%16.  Element e = 256 t + 4 lane' + r of the workgroup's
     // contiguous share of the (fragment-linear) layer-1 gradient.
@@ -871,13 +978,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(
             float G = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) G += red[w * NT * 256 + e];
+            float gW = G;
             if (ln) {
                 const float Do = Dsh[(e >> 8) * 16 + lip];
-                gW1[e] = gk * G + bk * Do;
+                gW = fmaf(gk, G, __fmul_rn(bk, Do));        // (pinned: the same bits whether stored or consumed by the optimizer rule)
                 pg += w1v[i] * G;
                 pb += w1v[i] * Do;
-            } else {
-                gW1[e] = G;
+            }
+            if (!OPT) gW1[e] = gW;
+            else if (!bad) {
+                float th = o_th[i];
+                opt_rule(oa, bc1, bc2, gW, th, o_m[i], o_v[i]);
+                oa.theta[wbase + e] = th; oa.m[wbase + e] = o_m[i];
+                if (adam) oa.v[wbase + e] = o_v[i];
             }
         }
     }
@@ -894,29 +1007,49 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 0) void train_grad1n_kernel(
 #pragma unroll
             for (int w = 0; w < NW; ++w)
                 if ((w & 3) == q) v += psh[(w * 2 + which) * 4 + r];
-            gout[(which ? s.off_lnb : s.off_lns) + ft * 16 + kl] = v;
+            if (!OPT) gout[(which ? s.off_lnb : s.off_lns) + ft * 16 + kl] = v;
+            else if (!bad) {
+                opt_rule(oa, bc1, bc2, v, ln_th, ln_m, ln_v);
+                const long long gi = (which ? s.off_lnb : s.off_lns) + ft * 16 + kl;
+                oa.theta[gi] = ln_th; oa.m[gi] = ln_m; if (adam) oa.v[gi] = ln_v;
+            }
         }
     }
     GSTAMP(4);
 }
 
 template <int NT, int NW>
-static void launch_grad1n(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, hipStream_t st) {
+static void launch_grad1n(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab, const OptArgs* fuse, hipStream_t st) {
     const int nparts = (B + 15) / 16;
-    const size_t lds = (size_t)(NW * NT * 256 + NW * NT * 16 + NT * 16 + NW * 8) * sizeof(float);
+    const size_t lds = (size_t)(NW * NT * 256 + NW * NT * 16 + NT * 16 + NW * 8 + 4) * sizeof(float);
+    const OptArgs none = {};
+    if (fuse) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)train_grad1n_kernel<NT, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((train_grad1n_kernel<NT, NW, true>), dim3(b.Fp / 16, 1), dim3(NW * 64), lds, st, s, b, perm, B, nparts, *fuse);
+        return;
+    }
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)train_grad1n_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((train_grad1n_kernel<NT, NW>), dim3(b.Fp / 16, nslab), dim3(NW * 64), lds, st, s, b, perm, B, nparts);
+        (void)hipFuncSetAttribute((const void*)train_grad1n_kernel<NT, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((train_grad1n_kernel<NT, NW, false>), dim3(b.Fp / 16, nslab), dim3(NW * 64), lds, st, s, b, perm, B, nparts, none);
 }
 
-void isk_launch_train_grad1n(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab_flags, hipStream_t st) {
+// the optimizer step can ride on train_grad1n: one row slab, at most 64 units (one wave sums their loss partials), and every
+// element of the small-gradient partial vector has a 16-lane group of its own (its optimizer operands are prefetched per group)
+bool isk_train_grad1n_can_fuse(const TrainShape& s, int Fp, int B, int nslab, int nw8) {
+    const int nt1 = isk_pad16(s.widths[1]) / 16;
+    const int NW = (nw8 || nt1 > 9) ? 8 : 16;
+    return nslab == 1 && (B + 15) / 16 <= 64 && part_size(s) <= (long long)(Fp / 16) * NW * 4;
+}
+
+void isk_launch_train_grad1n(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, int nslab_flags, hipStream_t st, const OptArgs* fuse) {
     const int nt1 = isk_pad16(s.widths[1]) / 16;
     const int nslab = nslab_flags & 0xff;
     const int nw8 = (nslab_flags & 0x100) != 0;            // the engine decides (option grad1_nw8, or: the featurizer shares the CUs)
-#define G1CASE(NT_) case NT_: if (nw8) launch_grad1n<NT_, 8>(s, b, perm, B, nslab, st); else launch_grad1n<NT_, 16>(s, b, perm, B, nslab, st); break;
+#define G1CASE(NT_) case NT_: if (nw8) launch_grad1n<NT_, 8>(s, b, perm, B, nslab, fuse, st); else launch_grad1n<NT_, 16>(s, b, perm, B, nslab, fuse, st); break;
     switch (nt1) {
         G1CASE(1) G1CASE(2) G1CASE(3) G1CASE(4) G1CASE(5) G1CASE(6) G1CASE(7) G1CASE(8) G1CASE(9)
-        default: launch_grad1n<10, 8>(s, b, perm, B, nslab, st); break;
+        default: launch_grad1n<10, 8>(s, b, perm, B, nslab, fuse, st); break;
     }
 #undef G1CASE
 }
@@ -971,19 +1104,10 @@ __device__ __forceinline__ void opt_step_body(const OptArgs& a, const OptPeers& 
     }
     if (bad) return;
     auto update = [&](long long i, float th, float gs, float mi, float vi) {
-        const float g = gs * a.gscale + a.reg * th;
-        float d;
-        if (a.kind == ISK_OPT_ADAM) {
-            const float m = a.beta1 * mi + (1.f - a.beta1) * g;
-            const float v = a.beta2 * vi + (1.f - a.beta2) * g * g;
-            a.m[i] = m;
-            a.v[i] = v;
-            d = m / bc1 / (sqrtf(v / bc2) + a.eps) * a.lr;
-        } else {
-            d = -a.rho * a.rho * mi + (1.f + a.rho) * a.lr * g;
-            a.m[i] = a.rho * mi - a.lr * g;
-        }
-        a.theta[i] = th - d;
+        opt_rule(a, bc1, bc2, gs, th, mi, vi);
+        a.m[i] = mi;
+        if (a.kind == ISK_OPT_ADAM) a.v[i] = vi;
+        a.theta[i] = th;
     };
     if (in0) update(i0, th0, gs0, m0, v0);
     for (long long i = i0 + (long long)gridDim.x * 256; i < a.n; i += (long long)gridDim.x * 256) {

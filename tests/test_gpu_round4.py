@@ -111,3 +111,46 @@ def test_documented_shape_limits_are_error_codes(gpu_pkg):
         pkg.chicoords_pullback(iso, xw[:, :2], np.ones((1, 2)))
     assert ei.value.status == pkg.capi.EUNSUPPORTED
     iso.close()
+
+
+@pytest.mark.parametrize("widths,ln,mb,opt", [([60, 13, 4, 1], True, 32, "adam"), ([60, 13, 4, 1], True, 50, "nesterov"), ([231, 38, 6, 1], True, 100, "adam"),
+                                              ([200, 142, 12, 3], True, 100, "nesterov"), ([200, 40, 3], False, 64, "adam"),
+                                              ([100, 20, 10, 5, 2], True, 64, "adam"), ([48, 150, 40, 2], True, 16, "adam")])
+def test_optimizer_step_riding_on_the_gradient_kernel(gpu_pkg, widths, ln, mb, opt):
+    """option fuse_opt (one row slab, one GPU): train_grad1n applies WeightDecay + Adam / Nesterov to the parameters whose gradient
+    it produces -- three launches per optimizer step instead of four.  Same gradients, same update formula: the parameters and
+    the optimizer state must come out BIT-identical to the unfused chain (only the batch loss is summed in another order), over
+    narrow and generic tails, with and without LayerNorm, and the run must agree with the oracle as before.  The last case's small-
+    gradient vector has more elements than the grid has 16-lane groups: there the launcher must fall back to four launches."""
+    pkg = gpu_pkg
+    F, nout, N = widths[0], widths[-1], 320
+    A = 24
+    xs, ys = O.synthetic_coords(A, N, 2, seed=11)
+    pairs = O.random_pairs(A, F, seed=12)
+    om, _ = _model(pkg, widths, seed=13, ln=ln)
+    st = O.setup(O.OptRule(opt, 1e-2, 1e-3), om)
+    odata = O.SimulationData(np.asarray(xs, np.float64), np.asarray(ys, np.float64), O.FeaturesPairs(pairs))
+    isos = {f: pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_model(pkg, widths, seed=13, ln=ln)[1],
+                       opt=pkg.OptSpec(opt, 1e-2, 1e-3), minibatch=mb, options={"fuse_opt": f}) for f in (1, 0)}
+    rng = np.random.default_rng(0)
+    for ep in range(3):
+        tgt = np.asarray(rng.uniform(size=(nout, N)), np.float32)
+        perm = rng.permutation(N)
+        lo = O.train_batch(om, odata.features[0], tgt.astype(np.float64), st, mb, perm=perm)
+        l1, l0 = (pkg.train_batch(isos[f], tgt, perm=perm) for f in (1, 0))
+        assert abs(l1 - l0) <= 1e-6 * abs(l0) and abs(l1 - lo) <= 1e-4 * abs(lo), (ep, l1, l0, lo)
+    np.testing.assert_array_equal(isos[1].model.get_params(), isos[0].model.get_params())
+    m1, v1, bt1 = isos[1].get_opt_state()
+    m0, v0, bt0 = isos[0].get_opt_state()
+    np.testing.assert_array_equal(m1, m0)
+    np.testing.assert_array_equal(v1, v0)
+    assert bt1[0] == bt0[0] and bt1[1] == bt0[1]
+    np.testing.assert_allclose(isos[1].model.get_params(), om.get_flat(), atol=3e-5, rtol=3e-4)
+    # a non-finite loss: nothing is applied, the epoch reports the collapse
+    before = isos[1].model.get_params()
+    with pytest.raises(pkg.DomainError) as ei:
+        pkg.train_batch(isos[1], np.full((nout, N), np.nan, np.float32), perm=np.arange(N))
+    assert ei.value.status == pkg.capi.ECOLLAPSED
+    np.testing.assert_array_equal(isos[1].model.get_params(), before)
+    for iso in isos.values():
+        iso.close()
