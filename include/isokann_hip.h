@@ -144,6 +144,10 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *                                launches per optimizer step it replaces
  *   fuse_opt            1        training on one GPU with batches of at most 768 rows (one row slab): the optimizer step rides on the
  *                                layer-1 gradient kernel -- three launches per optimizer step instead of four
+ *   fuse_tail           0        training, narrow tail with sigmoid hidden layers and an identity output (every pairnet default): the layer-1
+ *                                forward and the tail step are ONE launch -- the workgroup whose partial product arrives last runs the tail
+ *                                of its rows; with fuse_opt two launches per optimizer step.  Experimental: bit-identical results, and the
+ *                                in-launch hand-off costs more than the launch boundary it replaces
  *   tail_narrow         1        training: register-resident tail kernel where every tail layer is <= 16 wide (0: the generic LDS kernel)
  *   fwd_waves_per_simd  1        residency of the f32-MFMA forward kernel
  *   bf16_skew           1        split-bf16 forward: the second wave of a SIMD converts in the first half of a stage
@@ -160,7 +164,7 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *   debug_feat_copy / debug_stamps / debug_rowmod   0   diagnostics
  * Read-only keys of isk_get_option: forward_mode (effective), layered, planes, nparams_engine, wide_fwd (1 when the resident
  * data set runs the fused bf16 forward of wide networks: layered network, forward_mode 2, pair features, option wide_fused),
- * dp_peer_active (1 when the last isk_dp_run / isk_dp_run_all summed the gradients over peer access), train_persist_active (1 when the last epoch ran as one persistent launch), layered_blas_active (1 once a rocBLAS handle exists, i.e. a wide network's f32 training GEMMs went to the library). */
+ * dp_peer_active (1 when the last isk_dp_run / isk_dp_run_all summed the gradients over peer access), train_persist_active (1 when the last epoch ran as one persistent launch), fuse_tail_active (1 when the last optimizer step ran the layer-1 forward and the tail step as one launch), layered_blas_active (1 once a rocBLAS handle exists, i.e. a wide network's f32 training GEMMs went to the library). */
 int  isk_set_option(isk_engine* e, const char* key, int64_t value);
 int  isk_get_option(isk_engine* e, const char* key, int64_t* value);
 

@@ -81,7 +81,7 @@ static void free_data(isk_engine* e) {
     free_dev(e->d_in_ys); free_dev(e->d_xs32_alt); e->d_xs32_alt = nullptr; free_dev(e->d_xhat); free_dev(e->d_xhat_alt); free_dev(e->d_out); free_dev(e->d_ks);
     free_dev(e->d_xscale); free_dev(e->d_xscale_alt); free_dev(e->d_xs32);
     e->d_xscale = e->d_xscale_alt = e->d_xs32 = nullptr;
-    free_dev(e->d_target); free_dev(e->d_kw); e->d_kw = nullptr; free_dev(e->d_z1); free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm); free_dev(e->d_isa_work);
+    free_dev(e->d_target); free_dev(e->d_kw); e->d_kw = nullptr; free_dev(e->d_z1); free_dev(e->d_tail_cnt); e->d_tail_cnt = nullptr; free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm); free_dev(e->d_isa_work);
     e->d_isa_work = nullptr;
     free_dev(e->d_actA); free_dev(e->d_actB); e->d_actA = e->d_actB = nullptr;
     free_dev(e->d_xb); e->d_xb = nullptr;
@@ -717,6 +717,9 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
             if (ks > 1) zrows = std::max(zrows, ks * RB * 32); else break;
         }
         HIPCHK(hipMalloc((void**)&e->d_z1, (size_t)zrows * H1p * sizeof(float)));
+        const size_t cw = (size_t)isk_train_fwdtail_counters(N);
+        HIPCHK(hipMalloc((void**)&e->d_tail_cnt, cw * sizeof(unsigned)));
+        HIPCHK(hipMemsetAsync(e->d_tail_cnt, 0, cw * sizeof(unsigned), e->stream));
     }
     HIPCHK(hipMalloc((void**)&e->d_delta1, (size_t)Bpad * H1p * sizeof(float)));
     const TrainShape ts = train_shape(e);
@@ -1083,8 +1086,14 @@ void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nsl
     isk_fwd1n_plan(B, e->Fp, isk_pad16(e->cfg.widths[1]) / 16, &b.KS, &cpb);
     b.zstride = z1_rows(B) * isk_pad16(e->cfg.widths[1]);
     if (step && (capturing ? e->bt_dev_valid : prepare_dev_bt(e))) b.bt = e->d_bt;
-    isk_launch_train_fwd1n(s, b, d_idx, B, e->stream);
-    isk_launch_train_tail(s, b, d_idx, B, inv_div, e->stream);
+    if (e->opt.fuse_tail && e->opt.tail_narrow && e->d_tail_cnt && isk_train_fwdtail_ok(s)) {
+        isk_launch_train_fwdtail(s, b, d_idx, B, inv_div, e->d_tail_cnt, e->stream);
+        e->last_fwdtail = true;
+    } else {
+        e->last_fwdtail = false;
+        isk_launch_train_fwd1n(s, b, d_idx, B, e->stream);
+        isk_launch_train_tail(s, b, d_idx, B, inv_div, e->stream);
+    }
     e->last_nslab = nslab;
     if (fuse_mode) {
         const OptArgs oa = opt_args(e, 1.0f, fuse_mode == 2);
@@ -1242,7 +1251,7 @@ static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
     if (!tg) {                                           // a free slot, else the one that does not belong to the other live buffer
         tg = !e->tg[0].exec ? &e->tg[0] : (!e->tg[1].exec ? &e->tg[1] : (e->tg[0].xs == e->d_xs32_alt ? &e->tg[1] : &e->tg[0]));
     }
-    const int flags_f = flags | (can_fuse_opt(e, (int)bs, nslab) ? 0x1000 : 0);        // (the fused step is part of what the graph was captured for)
+    const int flags_f = flags | (can_fuse_opt(e, (int)bs, nslab) ? 0x1000 : 0) | (e->opt.fuse_tail ? 0x2000 : 0) | (e->opt.tail_narrow ? 0x4000 : 0);        // (the fused step is part of what the graph was captured for)
     if (!tg->exec || tg->bs != bs || tg->nb != nb || tg->flags != flags_f || tg->xs != xs_rows) {
         if (tg->exec) { (void)hipGraphExecDestroy(tg->exec); tg->exec = nullptr; }
         const double s1 = e->bt1, s2 = e->bt2;

@@ -167,6 +167,7 @@ struct isk_engine {
     int bucket_issued = 0;                      // the hook ran in this step: the upper bucket is already on its way
     int bucket_err = 0;                         // ncclResult of the hook's collective (0 = success)
     bool tp_disabled = false;
+    bool last_fwdtail = false;                  // the last launch_grads took the one-launch forward + tail (option fuse_tail)
     bool last_epoch_persist = false;            // a launch failed or timed out: the four-kernel chain from then on
     unsigned long long* dbg_st = nullptr;            // diagnostics of forward_resident (options debug_stamps / debug_rowmod)
     int* dbg_rows = nullptr;
@@ -182,6 +183,7 @@ struct isk_engine {
     bool have_target = false, have_ks = false;
     // training workspace
     float *d_z1 = nullptr, *d_delta1 = nullptr, *d_part = nullptr;
+    unsigned* d_tail_cnt = nullptr;          // arrival counters of train_fwdtail_kernel (one line per 32-row block, zero between launches)
     int* d_perm = nullptr;
     hipEvent_t ev_perm = nullptr;   // the shuffle order of the coming epoch was uploaded on the side stream (isk_run)
     double* h_res = nullptr;     // pinned + mapped: [loss sum, collapsed flag, status word], published by opt_step (d_hres = its device address)

@@ -30,6 +30,7 @@ const OptDesc kOptions[] = {
     {"train_bf16", &IskOptions::train_bf16, 0, 1},
     {"tail_narrow", &IskOptions::tail_narrow, 0, 1},
     {"fuse_opt", &IskOptions::fuse_opt, 0, 1},
+    {"fuse_tail", &IskOptions::fuse_tail, 0, 1},
     {"train_persist", &IskOptions::train_persist, 0, 1},
     {"wide_fused", &IskOptions::wide_fused, 0, 1},
     {"debug_inject_rank_error", &IskOptions::debug_inject_rank_error, 0, 1 << 30},
@@ -81,6 +82,7 @@ extern "C" int isk_get_option(isk_engine* e, const char* key, int64_t* value) {
     if (!std::strcmp(key, "nparams_engine")) { *value = e->nparams; return ISK_OK; }
     if (!std::strcmp(key, "layered_blas_active")) { *value = e->blas ? 1 : 0; return ISK_OK; }   // a rocBLAS handle exists: f32 training GEMMs went to the library
     if (!std::strcmp(key, "dp_peer_active")) { *value = e->last_run_peer ? 1 : 0; return ISK_OK; }           // the last data-parallel run read its peers' gradients directly
+    if (!std::strcmp(key, "fuse_tail_active")) { *value = e->last_fwdtail ? 1 : 0; return ISK_OK; }                 // the last gradient ran train_fwd1n + tail as one launch
     if (!std::strcmp(key, "train_persist_active")) { *value = e->last_epoch_persist ? 1 : 0; return ISK_OK; }   // the last epoch ran as one persistent launch
     if (!std::strcmp(key, "wide_fwd")) { *value = e->xh16 ? 1 : 0; return ISK_OK; }              // resident data runs the fused wide forward
     return fail(ISK_EINVAL, std::string("unknown option: ") + key);

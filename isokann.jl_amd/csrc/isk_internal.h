@@ -42,6 +42,9 @@ struct IskOptions {
                                   // than the four launches per optimizer step it replaces -- DESIGN.md section 6c; default off)
     int fuse_opt = 1;             // training on one GPU, one row slab (batches <= 768 rows): the optimizer step rides on train_grad1n
                                   // (three launches per step instead of four)
+    int fuse_tail = 0;            // training, narrow tail with the pairnet default activations: train_fwd1n and the tail step as ONE launch
+                                  // (the workgroup whose K-slice partial arrives last runs the tail of its rows: kernels_train_fwdtail.hip).
+                                  // Bit-identical to the two launches and measured SLOWER (+2.3 us per step at minibatch 100): default off
     int tail_narrow = 1;          // fused path: register-resident train_tail for narrow tails (0: the generic LDS kernel)
     int train_bf16 = 0;           // layered path: training GEMMs with bf16 operands (f32 master weights, f32 accumulate): the C5
                                   // arithmetic of BASELINE.json; 0 = f32
@@ -359,6 +362,10 @@ void isk_launch_train_tail(const TrainShape& s, const TrainBuffers& b, const int
 // kernels_train_tailn.hip: the same step for narrow tails (every tail layer <= 16 wide), one 16-sample unit in registers
 bool isk_train_tail_narrow_ok(const TrainShape& s);
 void isk_launch_train_tail_narrow(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div, hipStream_t st);
+// kernels_train_fwdtail.hip: train_fwd1n + the narrow tail step as one launch; cnt: isk_train_fwdtail_counters(max batch) zeroed words
+bool isk_train_fwdtail_ok(const TrainShape& s);
+int  isk_train_fwdtail_counters(long long maxB);
+void isk_launch_train_fwdtail(const TrainShape& s, const TrainBuffers& b, const int* perm, int B, float inv_div, unsigned* cnt, hipStream_t st);
 // cotangent mode: b.target holds the cotangent [B][nout]; delta_L = cot .* act'(z_L), no loss, no weights
 struct OptArgs;
 // fuse: the optimizer step rides on the kernel (see isk_train_grad1n_can_fuse); nullptr: the gradient goes to b.grad

@@ -135,7 +135,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tn_rsrc(const void* p, int byt
 
 // One 16-sample unit on NW waves (all of them call; unit / B / prow: this lane's sample row c = lane % 16).
 // s_zred [NW][256], s_tile [NW][16 * TN_TS], s_d1 [16 * H1p] (!EP only).  Returns the unit's loss (every lane).
-template <int L, bool SIG, int NW, bool EP>
+// ZSC1: the K-slice partials were stored by other workgroups of THIS launch (kernels_train_fwdtail.hip): sc1 loads
+template <int L, bool SIG, int NW, bool EP, bool ZSC1 = false>
 __device__ __forceinline__ float tailn_unit(const TailNDesc& d, const TailNIO& io, int unit, int B, int prow, float* s_zred, float* s_tile_all,
                                             float* s_d1, int wv, int ln) {
     constexpr int TPW = (12 + NW - 1) / NW < 2 ? 2 : (12 + NW - 1) / NW;      // layer-1 tiles per wave (nt <= 10)
@@ -163,7 +164,7 @@ __device__ __forceinline__ float tailn_unit(const TailNDesc& d, const TailNIO& i
             const int zoff = (row_g * H1p + 16 * tt + 4 * q) * 4;
 #pragma unroll
             for (int ks = 0; ks < ISK_FWD1_MAXKS; ++ks)
-                zp[ti][ks] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, zoff, (ks < io.KS ? ks : 0) * zs4, 0));
+                zp[ti][ks] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, zoff, (ks < io.KS ? ks : 0) * zs4, ZSC1 ? 16 : 0));
         }
 #pragma unroll
         for (int ti = 0; ti < TPW; ++ti) {

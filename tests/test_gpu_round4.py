@@ -154,3 +154,42 @@ def test_optimizer_step_riding_on_the_gradient_kernel(gpu_pkg, widths, ln, mb, o
     np.testing.assert_array_equal(isos[1].model.get_params(), before)
     for iso in isos.values():
         iso.close()
+
+
+@pytest.mark.parametrize("widths,ln,mb,N", [([60, 13, 4, 1], True, 32, 320), ([60, 13, 4, 1], True, 50, 330), ([231, 38, 6, 1], True, 100, 320),
+                                            ([200, 142, 12, 3], True, 0, 1000), ([200, 142, 12, 3], True, 0, 1016), ([200, 40, 3], False, 64, 320),
+                                            ([100, 20, 10, 5, 2], True, 64, 200), ([1700, 142, 12, 3], True, 1000, 2000)])
+def test_tail_step_riding_on_the_layer1_forward(gpu_pkg, widths, ln, mb, N):
+    """option fuse_tail (narrow tail, pairnet default activations): train_fwd1n and the tail step are ONE launch -- the workgroup
+    whose K-slice partial of a 32-row block arrives last runs the tail of those rows (kernels_train_fwdtail.hip).  The same partials
+    are summed in the same order by the same device code, so losses, parameters and optimizer state must be BIT-identical to the
+    two launches; cases: one / two / three tail layers, no LayerNorm, a batch whose unit count is odd (50 rows = 4 units: no; 1000
+    rows = 63 units and 1016 = 64: the full-batch cases), several K slices (F = 1700 at B = 1000: the bench's step), and repeated
+    epochs (the arrival counters must be back at zero after every launch)."""
+    pkg = gpu_pkg
+    F, nout = widths[0], widths[-1]
+    A = 24 if F <= 231 else 60
+    xs, ys = O.synthetic_coords(A, N, 2, seed=11)
+    pairs = O.random_pairs(A, F, seed=12)
+    om, _ = _model(pkg, widths, seed=13, ln=ln)
+    st = O.setup(O.OptRule("adam", 1e-2, 1e-3), om)
+    odata = O.SimulationData(np.asarray(xs, np.float64), np.asarray(ys, np.float64), O.FeaturesPairs(pairs))
+    isos = {f: pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_model(pkg, widths, seed=13, ln=ln)[1],
+                       opt=pkg.OptSpec("adam", 1e-2, 1e-3), minibatch=mb, options={"fuse_tail": f}) for f in (1, 0)}
+    rng = np.random.default_rng(0)
+    for ep in range(4):
+        tgt = np.asarray(rng.uniform(size=(nout, N)), np.float32)
+        perm = rng.permutation(N)
+        lo = O.train_batch(om, odata.features[0], tgt.astype(np.float64), st, mb, perm=perm)
+        l1, l0 = (pkg.train_batch(isos[f], tgt, perm=perm) for f in (1, 0))
+        assert l1 == l0 and abs(l1 - lo) <= 1e-4 * abs(lo), (ep, l1, l0, lo)
+        assert isos[1].get_option("fuse_tail_active") == 1 and isos[0].get_option("fuse_tail_active") == 0
+    np.testing.assert_array_equal(isos[1].model.get_params(), isos[0].model.get_params())
+    m1, v1, bt1 = isos[1].get_opt_state()
+    m0, v0, bt0 = isos[0].get_opt_state()
+    np.testing.assert_array_equal(m1, m0)
+    np.testing.assert_array_equal(v1, v0)
+    assert bt1[0] == bt0[0] and bt1[1] == bt0[1]
+    np.testing.assert_allclose(isos[1].model.get_params(), om.get_flat(), atol=3e-5, rtol=3e-4)
+    for iso in isos.values():
+        iso.close()
