@@ -144,6 +144,9 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *                                launches per optimizer step it replaces
  *   fuse_opt            1        training on one GPU with batches of at most 768 rows (one row slab): the optimizer step rides on the
  *                                layer-1 gradient kernel -- three launches per optimizer step instead of four
+ *   fuse_opt_rows       768      ... for batches of up to this many rows (at most 1024; beyond 768 rows the gradient kernel by default splits
+ *                                the batch rows over two workgroups per feature tile and a separate optimizer launch sums the two slabs:
+ *                                faster at C3's 1000-row batches than one fused slab)
  *   fuse_tail           0        training, narrow tail with sigmoid hidden layers and an identity output (every pairnet default): the layer-1
  *                                forward and the tail step are ONE launch -- the workgroup whose partial product arrives last runs the tail
  *                                of its rows; with fuse_opt two launches per optimizer step.  Experimental: bit-identical results, and the

@@ -1078,6 +1078,13 @@ bool can_fuse_opt(const isk_engine* e, int B, int nslab) {
     return isk_train_grad1n_can_fuse(train_shape(e), e->Fp, B, nslab, nw8 ? 1 : 0);
 }
 
+// row slabs of a single-GPU training step: batches of up to fuse_opt_rows rows stay on ONE slab where that lets the optimizer
+// step ride on train_grad1n (a longer MFMA chain per wave, but no opt_step launch and no slab sum)
+int pick_slabs_fused(const isk_engine* e, int B) {
+    if (B <= e->opt.fuse_opt_rows && can_fuse_opt(e, B, 1)) return 1;
+    return pick_slabs(B);
+}
+
 void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nslab, bool step, bool capturing, int fuse_mode) {
     if (e->layered) { launch_grads_layered(e, d_idx, B, inv_div); return; }
     const TrainShape s = train_shape(e);
@@ -1241,7 +1248,7 @@ static bool train_epoch_persist(isk_engine* e, long long bs, long long nb) {
 // variant or the buffers change.  ISK_TRAIN_GRAPH=0 (or any capture error) keeps the per-kernel launches.
 static bool train_epoch_graph(isk_engine* e, long long bs, long long nb) {
     if (!e->opt.train_graph || e->tg_disabled || e->layered || nb < 2) return false;
-    const int nslab = pick_slabs((int)bs);
+    const int nslab = pick_slabs_fused(e, (int)bs);
     const int flags = grad1_flags(e, nslab);
     if (!prepare_dev_bt(e)) return false;
     const float* xs_rows = e->d_xs32;                    // part of the key: the buffer pair swaps every iteration
@@ -1341,7 +1348,7 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
         ScopedTimer t(e, ISK_T_TRAIN);
         const bool lazy_fold = epoch_lazy_fold(e);
         if (!train_epoch_persist(e, bs, nb) && !train_epoch_graph(e, bs, nb)) {
-            const int nsl = pick_slabs((int)bs);
+            const int nsl = pick_slabs_fused(e, (int)bs);
             const bool fuse = can_fuse_opt(e, (int)bs, nsl);
             for (long long b = 0; b < nb; ++b) {
                 launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, nsl, true, false, fuse ? (b == nb - 1 ? 2 : 1) : 0);

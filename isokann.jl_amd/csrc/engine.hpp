@@ -278,6 +278,7 @@ hipError_t zero_loss_acc(isk_engine* e);
 int check_status(isk_engine* e);
 int compute_target(isk_engine* e, bool check, bool ahead = false);
 int pick_slabs(int B);
+int pick_slabs_fused(const isk_engine* e, int B);
 bool prepare_dev_bt(isk_engine* e);
 void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nslab = 1, bool step = true, bool capturing = false, int fuse_mode = 0);
 bool can_fuse_opt(const isk_engine* e, int B, int nslab);

@@ -42,6 +42,9 @@ struct IskOptions {
                                   // than the four launches per optimizer step it replaces -- DESIGN.md section 6c; default off)
     int fuse_opt = 1;             // training on one GPU, one row slab (batches <= 768 rows): the optimizer step rides on train_grad1n
                                   // (three launches per step instead of four)
+    int fuse_opt_rows = 768;      // ... for batches of up to this many rows (<= 1024).  Beyond 768 the gradient kernel splits the rows over two
+                                  // workgroups per feature tile and opt_step sums the two slabs; keeping C3's 1000-row batches on one slab
+                                  // to fuse the step was measured SLOWER (1.177 against 1.129 ms per iteration: twice the MFMA chain per wave)
     int fuse_tail = 0;            // training, narrow tail with the pairnet default activations: train_fwd1n and the tail step as ONE launch
                                   // (the workgroup whose K-slice partial arrives last runs the tail of its rows: kernels_train_fwdtail.hip).
                                   // Bit-identical to the two launches and measured SLOWER (+2.3 us per step at minibatch 100): default off
