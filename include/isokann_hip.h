@@ -147,6 +147,10 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *   fuse_opt_rows       768      ... for batches of up to this many rows (at most 1024; beyond 768 rows the gradient kernel by default splits
  *                                the batch rows over two workgroups per feature tile and a separate optimizer launch sums the two slabs:
  *                                faster at C3's 1000-row batches than one fused slab)
+ *   epoch_gather        0        wide networks, training GEMMs: 1 = the batch images (row gather, transposed copy) of every batch of an epoch are
+ *                                written by ONE launch in front of the epoch's optimizer steps instead of one per step (measured: no faster)
+ *   g16_waves           0        wide networks, training GEMMs: waves per workgroup that split the contraction (4 or 8; 0 = eight for products
+ *                                at least 512 deep)
  *   fuse_tail           0        training, narrow tail with sigmoid hidden layers and an identity output (every pairnet default): the layer-1
  *                                forward and the tail step are ONE launch -- the workgroup whose partial product arrives last runs the tail
  *                                of its rows; with fuse_opt two launches per optimizer step.  Experimental: bit-identical results, and the

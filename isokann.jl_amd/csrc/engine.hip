@@ -1350,6 +1350,7 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
         if (!train_epoch_persist(e, bs, nb) && !train_epoch_graph(e, bs, nb)) {
             const int nsl = pick_slabs_fused(e, (int)bs);
             const bool fuse = can_fuse_opt(e, (int)bs, nsl);
+            EpochGatherScope images(e, e->d_perm, bs, nb);
             for (long long b = 0; b < nb; ++b) {
                 launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, nsl, true, false, fuse ? (b == nb - 1 ? 2 : 1) : 0);
                 launch_opt(e, 1.0f, !lazy_fold || (b == nb - 1 && !epoch_no_fold(e)), false, b == nb - 1, nullptr, fuse);

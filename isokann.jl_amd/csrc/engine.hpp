@@ -132,6 +132,12 @@ struct isk_engine {
         void* Wf[ISK_MAX_LAYERS] = {nullptr};         // the same numbers, fragment-linear [pad32(K_l) / 32][32][64][8] (fused wide forward; hidden layers <= 512 wide)
         float* G0 = nullptr;                          // LayerNorm: raw layer-0 gradient [F + 1][N_0] (row F = D)
         bool wt_dirty = true, wf_dirty = true;
+        // the batch images of a whole epoch, gathered in ONE launch in front of its steps (layered_epoch_gather)
+        void *xb_all = nullptr, *xt_all = nullptr;    // [nb][Bp][Fp], [nb][F + 1][Bp]
+        size_t xb_all_bytes = 0, xt_all_bytes = 0;
+        const int* ep_perm = nullptr;                 // valid while ep_nb > 0: the epoch's shuffle order, batch size, batch count
+        long long ep_bs = 0, ep_nb = 0;
+        int ep_esz = 0;
     } b16;
     float* d_zero = nullptr;                      // zero bias for the transposed GEMMs
     double* d_loss_acc = nullptr;
@@ -278,6 +284,13 @@ hipError_t zero_loss_acc(isk_engine* e);
 int check_status(isk_engine* e);
 int compute_target(isk_engine* e, bool check, bool ahead = false);
 int pick_slabs(int B);
+void layered_epoch_gather(isk_engine* e, const int* d_perm, long long bs, long long nb);
+void layered_epoch_end(isk_engine* e);
+struct EpochGatherScope {            // the epoch images are valid only while the epoch's steps are being enqueued
+    isk_engine* e;
+    EpochGatherScope(isk_engine* e_, const int* d_perm, long long bs, long long nb) : e(e_) { layered_epoch_gather(e, d_perm, bs, nb); }
+    ~EpochGatherScope() { layered_epoch_end(e); }
+};
 int pick_slabs_fused(const isk_engine* e, int B);
 bool prepare_dev_bt(isk_engine* e);
 void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nslab = 1, bool step = true, bool capturing = false, int fuse_mode = 0);

@@ -320,6 +320,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
             {
                 ScopedTimer t(e, ISK_T_TRAIN);
                 const bool lazy_fold = epoch_lazy_fold(e);
+                EpochGatherScope images(e, e->d_perm, local_batch, nbatches);
                 for (int b = 0; b < nbatches; ++b) {
                     ++step_no;
                     if (e->opt.debug_inject_rank_error > 0 && step_no == e->opt.debug_inject_rank_error)

@@ -229,6 +229,8 @@ void bf16_train_release(isk_engine* e) {
         b.a16[l] = b.at16[l] = b.d16[l] = b.dt16[l] = nullptr;
     }
     b.rows = 0; b.esz = 0;
+    free_dev(b.xb_all); free_dev(b.xt_all);
+    b.xb_all = b.xt_all = nullptr; b.xb_all_bytes = b.xt_all_bytes = 0; b.ep_nb = 0;
 }
 
 int bf16_weight_images_alloc(isk_engine* e) {
@@ -308,6 +310,36 @@ static bool bf16_train_ensure(isk_engine* e, long long Bp, int esz) {
     return true;
 }
 
+// The batch images (row gather + transposed copy with the row of ones) of EVERY batch of the coming epoch, in one launch: they
+// depend on the shuffle order only, and in front of each step's chain the gather was 9..19 us of its ~150.  Valid until
+// layered_epoch_end; a step whose rows are not a batch of this epoch (isk_batch_grads, another batch size) gathers for itself.
+void layered_epoch_gather(isk_engine* e, const int* d_perm, long long bs, long long nb) {
+    auto& b = e->b16;
+    b.ep_nb = 0;
+    if (!e->layered || !e->opt.epoch_gather || nb < 2 || !(bf16_train_active(e) || mfma32_train_active(e))) return;
+    const int esz = bf16_train_active(e) ? 2 : 4;
+    const long long Bp = isk_pad32((int)bs);
+    const size_t need_b = (size_t)nb * Bp * e->Fp * esz, need_t = (size_t)nb * (e->F + 1) * Bp * esz;
+    if (need_b + need_t > ((size_t)2 << 30)) return;                     // (a very long epoch of a very wide input: gather per step)
+    if (need_b > b.xb_all_bytes || need_t > b.xt_all_bytes) {
+        (void)hipStreamSynchronize(e->stream);
+        if (b.xb_all) (void)hipFree(b.xb_all);
+        if (b.xt_all) (void)hipFree(b.xt_all);
+        b.xb_all = b.xt_all = nullptr; b.xb_all_bytes = b.xt_all_bytes = 0;
+        if (hipMalloc(&b.xb_all, need_b) != hipSuccess || hipMalloc(&b.xt_all, need_t) != hipSuccess) {
+            (void)hipGetLastError();
+            if (b.xb_all) (void)hipFree(b.xb_all);
+            b.xb_all = b.xt_all = nullptr;
+            return;
+        }
+        b.xb_all_bytes = need_b; b.xt_all_bytes = need_t;
+    }
+    isk_launch_gather_epoch(e->d_xs32, e->Fp, d_perm, (int)bs, (int)Bp, e->F, e->Fp, b.xb_all, b.xt_all, Bp, esz == 4, (int)nb,
+                            (long long)Bp * e->Fp * esz, (long long)(e->F + 1) * Bp * esz, e->stream);
+    b.ep_perm = d_perm; b.ep_bs = bs; b.ep_nb = nb; b.ep_esz = esz;
+}
+void layered_epoch_end(isk_engine* e) { e->b16.ep_nb = 0; }
+
 // f32math: the same chain of fused products in Float32 arithmetic (f32 images, v_mfma_f32_16x16x4_f32)
 static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, float inv_div, const int f32math) {
     const int L = e->L;
@@ -318,19 +350,34 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
     const long long ldB = b.rows;                    // row length of the transposed images
     hipStream_t st = e->stream;
     const bool ln = e->cfg.layernorm != 0;
+    const void* xb = b.xb;                          // this batch's images: [Bp][Fp] and [F + 1][ldX]
+    const void* xt = b.xt;
+    long long ldX = ldB;
     {
-        // the batch images and (behind an optimizer step: always) the row-major weight images, one launch
+        // the batch images and (behind an optimizer step: always) the row-major weight images, one launch -- unless the batch
+        // is one of an epoch whose images were gathered up front (layered_epoch_gather)
         WtImagesArgs w;
-        if (weight_image_args(e, true, false, w, esz)) isk_launch_prep_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, f32math, w, st);
-        else isk_launch_gather_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, f32math, st);
+        const bool dirty = weight_image_args(e, true, false, w, esz);
+        const long long off = b.ep_nb > 0 && B == b.ep_bs && esz == b.ep_esz && d_idx >= b.ep_perm ? (long long)(d_idx - b.ep_perm) : -1;
+        if (off >= 0 && off % B == 0 && off / B < b.ep_nb) {
+            const long long k = off / B;
+            xb = (const char*)b.xb_all + (size_t)k * Bp * e->Fp * esz;
+            xt = (const char*)b.xt_all + (size_t)k * (e->F + 1) * Bp * esz;
+            ldX = Bp;
+            if (dirty) isk_launch_wt_images(w, st);
+        } else if (dirty) {
+            isk_launch_prep_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, f32math, w, st);
+        } else {
+            isk_launch_gather_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, f32math, st);
+        }
     }
     bool ok = true;
     for (int l = 0; l < L && ok; ++l) {
         const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];
         Gemm16Args g = {};
-        g.A = l == 0 ? b.xb : b.a16[l - 1]; g.lda = l == 0 ? e->Fp : isk_pad32(K); g.a_f32 = f32math;
+        g.A = l == 0 ? xb : b.a16[l - 1]; g.lda = l == 0 ? e->Fp : isk_pad32(K); g.a_f32 = f32math;
         g.B = b.Wt[l]; g.ldb = isk_pad32(K); g.b_f32 = f32math; g.f32math = f32math;
-        g.M = B; g.Nn = N; g.Kc = isk_pad32(K); g.kvalid = g.Kc;
+        g.M = B; g.Nn = N; g.Kc = isk_pad32(K); g.kvalid = g.Kc; g.waves = e->opt.g16_waves;
         g.epi = ISK_G16_FWD;
         g.bias = (l == 0 && ln) ? e->d_bias[0] : e->d_theta + e->off_b[l];
         g.act = l < L - 1 ? act_of_layer(e, l) : ISK_ACT_IDENTITY;          // the last layer's activation is applied by the loss kernel
@@ -348,9 +395,9 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
         const bool ln0 = l == 0 && ln;
         Gemm16Args pair[3] = {};
         Gemm16Args& g = pair[0];
-        g.A = l == 0 ? b.xt : b.at16[l - 1]; g.lda = ldB; g.a_f32 = f32math;
+        g.A = l == 0 ? xt : b.at16[l - 1]; g.lda = l == 0 ? ldX : ldB; g.a_f32 = f32math;
         g.B = b.dt16[l]; g.ldb = ldB; g.b_f32 = f32math; g.f32math = f32math;
-        g.M = K + 1; g.Nn = N; g.Kc = Bp; g.kvalid = Bp;
+        g.M = K + 1; g.Nn = N; g.Kc = Bp; g.kvalid = Bp; g.waves = e->opt.g16_waves;
         g.epi = ISK_G16_DW;
         g.gout = ln0 ? b.G0 : e->d_grad + e->off_W[l]; g.gld = N;           // row K lands on b_l: Flux keeps it right behind W_l
         int np = 1;
@@ -359,7 +406,7 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
             Gemm16Args& x = pair[1];
             x.A = b.d16[l]; x.lda = isk_pad32(N); x.a_f32 = f32math; x.f32math = f32math;
             x.B = e->d_theta + e->off_W[l]; x.ldb = N; x.b_f32 = 1;           // Flux (out, in) column-major == [k][n]: n contiguous
-            x.M = B; x.Nn = K; x.Kc = isk_pad32(N); x.kvalid = N;
+            x.M = B; x.Nn = K; x.Kc = isk_pad32(N); x.kvalid = N; x.waves = e->opt.g16_waves;
             x.epi = ISK_G16_DX;
             x.zprev = e->d_lz[l - 1]; x.ldzp = isk_pad16(K); x.act = act_of_layer(e, l - 1);
             x.o16 = b.d16[l - 1]; x.ld16 = isk_pad32(K); x.M16 = Bp; x.ot16 = b.dt16[l - 1]; x.ldt = (int)ldB;

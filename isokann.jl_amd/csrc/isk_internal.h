@@ -45,6 +45,10 @@ struct IskOptions {
     int fuse_opt_rows = 768;      // ... for batches of up to this many rows (<= 1024).  Beyond 768 the gradient kernel splits the rows over two
                                   // workgroups per feature tile and opt_step sums the two slabs; keeping C3's 1000-row batches on one slab
                                   // to fuse the step was measured SLOWER (1.177 against 1.129 ms per iteration: twice the MFMA chain per wave)
+    int epoch_gather = 0;         // layered training GEMMs: the batch images of a whole epoch are gathered in one launch in front of its steps.
+                                  // Bit-identical, and no faster (C5 shard 2.99 against 2.95 ms: the step keeps a launch for the weight images)
+    int g16_waves = 0;            // layered training GEMMs: waves per workgroup that split the contraction (4 | 8; 0: eight where the product is
+                                  // at least 16 steps of 32 deep)
     int fuse_tail = 0;            // training, narrow tail with the pairnet default activations: train_fwd1n and the tail step as ONE launch
                                   // (the workgroup whose K-slice partial arrives last runs the tail of its rows: kernels_train_fwdtail.hip).
                                   // Bit-identical to the two launches and measured SLOWER (+2.3 us per step at minibatch 100): default off
@@ -223,6 +227,7 @@ struct Gemm16Args {
     void* ot16; int ldt;                         // optional TRANSPOSED bf16 image [Nn][ldt]: columns i in [M, ldt) are zeros
     // ISK_G16_DW: gout[i * gld + j] = C (f32)
     float* gout; long long gld;
+    int waves;                                   // waves that split the contraction: 4 | 8, 0 = by depth (8 from 16 steps on)
     int f32math;                                 // 1: Float32 arithmetic -- f32 fragments (a_f32 = b_f32 = 1), eight v_mfma_f32_16x16x4_f32 per
                                                  // 32-deep step instead of one bf16 MFMA -- and the images o16 / ot16 are FLOAT arrays
 };
@@ -239,6 +244,9 @@ int  isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st);
 // img_f32: the images are FLOAT arrays (Float32 arithmetic of the training GEMMs) instead of bf16
 void isk_launch_gather_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
                               int img_f32, hipStream_t st);
+// ... of every batch of an epoch: batch y reads perm[y * B .. + B) and writes its images y * stride bytes further
+void isk_launch_gather_epoch(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
+                             int img_f32, int nbatch, long long xb_stride_bytes, long long xt_stride_bytes, hipStream_t st);
 struct WtImagesArgs {
     const float* theta; const float* scale0;     // scale0: LayerNorm scale folded into layer 0's image (or nullptr)
     int nlayers;

@@ -104,10 +104,13 @@ __device__ __forceinline__ bf16x8 load_frag(const void* base, const int F32, lon
 
 // one 32 x 64 output tile (bx, by) of problem `a`; the operand element types are wave-uniform run-time flags (a grouped launch
 // mixes products with bf16 and f32 operands)
-template <bool SLOW, bool F32 = false>
+// NW waves split the contraction (4 or 8: the k-loop of a wave is a chain of memory round trips -- a workgroup reads its operand
+// rows exactly once, mostly from beyond L2, ~1 us per step with two steps in flight -- so the deep products take eight waves)
+// BW (bf16 arithmetic, fast path): the B operand is an f32 array (dX reads the master weights); an f32 A operand takes the slow path
+template <bool SLOW, bool F32 = false, int NW = 4, bool BW = false>
 __device__ __forceinline__ void gemm16_tile(const Gemm16Args& a, const int bx, const int by, float (*red)[G16_TM][G16_LDR]) {
     using frag_t = typename std::conditional<F32, f32x8, bf16x8>::type;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 15, lq = lane >> 4;
     const int i0 = bx * G16_TM, j0 = by * G16_TN;
     const int AF32 = a.a_f32, BF32 = a.b_f32;
@@ -116,22 +119,59 @@ __device__ __forceinline__ void gemm16_tile(const Gemm16Args& a, const int bx, c
     for (int rt = 0; rt < 2; ++rt) { int r = i0 + rt * 16 + li; r = r < a.M ? r : a.M - 1; offA[rt] = (long long)r * a.lda + lq * 8; }
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) { int r = j0 + ct * 16 + li; r = r < a.Nn ? r : a.Nn - 1; offB[ct] = (long long)r * a.ldb + lq * 8; }
+    // fast path: buffer loads -- (operand base in SGPRs) + (one 32-bit byte offset per fragment row) + (the step as a scalar
+    // offset).  With 64-bit addresses per load the kernel needed ~250 registers per wave; the fragment sets themselves are 104
+    // (Float32 arithmetic: 128), and at <= 128 (168) registers two of these workgroups share a CU with a side-stream featurizer wave
+    constexpr int ea = F32 ? 4 : 2, eb = (F32 || BW) ? 4 : 2;                    // bytes per operand element
+    __amdgpu_buffer_rsrc_t ra, rb;
+    int voA[2], voB[4];
+    if constexpr (!SLOW) {
+        ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, 0x7ffffffc, 0x00020000);
+        rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, 0x7ffffffc, 0x00020000);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) voA[rt] = (int)offA[rt] * ea;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) voB[ct] = (int)offB[ct] * eb;
+    }
+    auto bload = [&](__amdgpu_buffer_rsrc_t r, int vo, int so) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
+    };
+    // one operand fragment of step ks: 8 consecutive contraction elements (wide: an f32 operand, two 16-byte loads)
+    auto bfrag = [&](__amdgpu_buffer_rsrc_t r, int vo, int ks, int esz, auto WIDE) -> frag_t {
+        const int so = __builtin_amdgcn_readfirstlane(ks * 32 * esz);
+        if constexpr (F32) {
+            const f32x4 lo = bload(r, vo, so), hi = bload(r, vo + 16, so);
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+            if constexpr (decltype(WIDE)::value) {
+                const f32x4 lo = bload(r, vo, so), hi = bload(r, vo + 16, so);
+                const f32x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                return __builtin_convertvector(v, bf16x8);
+            }
+            return __builtin_bit_cast(bf16x8, bload(r, vo, so));
+        }
+    };
     f32x4 acc[2][4];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = a.Kc / 32;
-    // this wave's k-steps: wave, wave + 4, ...  Fragments are requested TWO steps ahead (three register sets, rotated statically):
-    // the chain of a wave is 8..16 dependent memory round trips long, and beside the side-stream featurizer one of them is ~1 us
-    // (Float32 arithmetic: two register sets, one step ahead -- a fragment is eight registers, and a step is 64 MFMAs of 32 cycles,
-    // which covers a round trip by itself)
-    constexpr int NSET = F32 ? 2 : 3;
+    // this wave's k-steps: wave, wave + NW, ...  Fragments are requested ONE step ahead (two register sets).  Round 3 kept three
+    // sets (two steps ahead) at ~250 registers per wave; two sets fit 128, and what hides the round trips -- ~1 us each beside the
+    // side-stream featurizer -- is then the other workgroups on the CU (two 4-wave or one 8-wave workgroup beside a featurizer wave,
+    // four / two without it): C5-shard iteration 3.08 -> 2.90 ms (bf16), and the deep products split K over eight waves
+    constexpr int NSET = 2;
     frag_t fa[NSET][2], fb[NSET][4];
     auto loadset = [&](int ks, auto SLOT) {
         constexpr int sl = decltype(SLOT)::value;
         if (ks < nk) {
-            if constexpr (F32) {
+            if constexpr (!SLOW) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) fa[sl][rt] = bfrag(ra, voA[rt], ks, ea, std::false_type{});
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) fb[sl][ct] = bfrag(rb, voB[ct], ks, eb, std::integral_constant<bool, BW>{});
+            } else if constexpr (F32) {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) fa[sl][rt] = load_frag32<SLOW>(a.A, offA[rt] + ks * 32, ks * 32 + lq * 8, a.kvalid);
 #pragma unroll
@@ -164,52 +204,54 @@ __device__ __forceinline__ void gemm16_tile(const Gemm16Args& a, const int bx, c
     using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
     int ks = wave;
     loadset(ks, S0{});
-    if constexpr (F32) {
-        for (; ks < nk; ks += 8) {
-            loadset(ks + 4, S1{});
-            mma(S0{});
-            if (ks + 4 >= nk) break;
-            loadset(ks + 8, S0{});
-            mma(S1{});
-        }
-    } else {
-        loadset(ks + 4, S1{});
-        for (; ks < nk; ks += 12) {
-            loadset(ks + 8, std::integral_constant<int, NSET - 1>{});
-            mma(S0{});
-            if (ks + 4 >= nk) break;
-            loadset(ks + 12, S0{});
-            mma(S1{});
-            if (ks + 8 >= nk) break;
-            loadset(ks + 16, S1{});
-            mma(std::integral_constant<int, NSET - 1>{});
-        }
+    for (; ks < nk; ks += 2 * NW) {
+        loadset(ks + NW, S1{});
+        mma(S0{});
+        if (ks + NW >= nk) break;
+        loadset(ks + 2 * NW, S0{});
+        mma(S1{});
     }
     // C layout of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + r
+    // (eight waves: two stages, so that the buffer stays at four tile sets -- waves 4..7 park their tiles, waves 0..3 add their own
+    // to the same elements, which only they touch)
+    if (NW == 4 || wave >= 4) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][rt * 16 + 4 * lq + r][ct * 16 + li] = acc[rt][ct][r];
+                for (int r = 0; r < 4; ++r) red[wave & 3][rt * 16 + 4 * lq + r][ct * 16 + li] = acc[rt][ct][r];
+    }
     __syncthreads();
+    if constexpr (NW == 8) {
+        if (wave < 4) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[wave][rt * 16 + 4 * lq + r][ct * 16 + li] += acc[rt][ct][r];
+        }
+        __syncthreads();
+    }
     // pass 1: consecutive threads along j -- the K-split sum, the epilogue, the row-major stores.  Every global operand of the
     // epilogue (bias / previous pre-activations) is requested UNCONDITIONALLY, from clamped addresses, before the first use: behind
     // a per-element `if` the eight loads of a thread became eight dependent memory round trips (~1 us each: the whole kernel took
     // 12 us for a product that needs 2)
     const bool want_t = a.ot16 != nullptr;
-    float ext[8];
+    constexpr int NT = NW * 64, NP = G16_TM * G16_TN / NT;        // threads, elements per thread
+    float ext[NP];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int idx = tid + 256 * p, row = idx >> 6, col = idx & 63;
+    for (int p = 0; p < NP; ++p) {
+        const int idx = tid + NT * p, row = idx >> 6, col = idx & 63;
         const int ic = (i0 + row) < a.M ? (i0 + row) : a.M - 1, jc = (j0 + col) < a.Nn ? (j0 + col) : a.Nn - 1;
         ext[p] = 0.f;
         if (a.epi == ISK_G16_FWD) { if (a.bias) ext[p] = a.bias[jc]; }
         else if (a.epi == ISK_G16_DX) ext[p] = a.zprev[(long long)ic * a.ldzp + jc];
     }
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int idx = tid + 256 * p, row = idx >> 6, col = idx & 63;
+    for (int p = 0; p < NP; ++p) {
+        const int idx = tid + NT * p, row = idx >> 6, col = idx & 63;
         const int i = i0 + row, j = j0 + col;
         float v = (red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col]);
         const bool in = i < a.M && j < a.Nn;
@@ -235,42 +277,38 @@ __device__ __forceinline__ void gemm16_tile(const Gemm16Args& a, const int bx, c
     __syncthreads();
     // pass 2: consecutive threads along i -- the transposed bf16 image [j][i] (rows of it beyond Nn are never read)
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int idx = tid + 256 * p, col = idx >> 5, row = idx & 31;
+    for (int p = 0; p < NP; ++p) {
+        const int idx = tid + NT * p, col = idx >> 5, row = idx & 31;
         const int i = i0 + row, j = j0 + col;
         if (j < a.Nn && i < a.ldt) st_img(a.ot16, (long long)j * a.ldt + i, red[0][row][col], F32);
     }
 }
 
-template <bool SLOW, bool F32>
-__global__ __launch_bounds__(256) void gemm16_kernel(Gemm16Args a) {
+// Register cap: left to itself hipcc spends ~250 registers per wave here (copies parked in AGPRs), which lets ONE 4-wave workgroup
+// share a CU with the side-stream featurizer (its waves hold ~248 of a SIMD's 512) and no 8-wave workgroup at all.  128 (bf16) /
+// 168 (Float32 fragments) registers are what the fragment sets need.
+#define G16_WAVES_PER_EU(F32_) ((F32_) ? 2 : 4)
+template <bool SLOW, bool F32, int NW, bool BW>
+__global__ __launch_bounds__(NW * 64, G16_WAVES_PER_EU(F32)) void gemm16_kernel(Gemm16Args a) {
     __shared__ float red[4][G16_TM][G16_LDR];
     ISK_LATENCY_CHAIN_PRIO();
-    gemm16_tile<SLOW, F32>(a, blockIdx.x, blockIdx.y, red);
+    gemm16_tile<SLOW, F32, NW, BW>(a, blockIdx.x, blockIdx.y, red);
 }
 
 // several INDEPENDENT products in one launch (dW_l beside dX_l: both need only delta_l): a step of the layered training path is a
 // chain of dependent launches, and two products that do not depend on each other should not wait for each other
-__global__ __launch_bounds__(256) void gemm16_group_kernel(Gemm16Group g) {
+template <bool F32, int NW>
+__global__ __launch_bounds__(NW * 64, G16_WAVES_PER_EU(F32)) void gemm16_group_kernel(Gemm16Group g) {
     __shared__ float red[4][G16_TM][G16_LDR];
     ISK_LATENCY_CHAIN_PRIO();
     int p = 0, b = blockIdx.x;
     while (p + 1 < g.n && b >= g.first[p + 1]) ++p;
     b -= g.first[p];
     // (a member with a ragged shape -- the last layer's one-column products -- takes the elementwise operand path: the choice is
-    // uniform per workgroup)
-    if (g.slow[p]) gemm16_tile<true>(g.g[p], b % g.gx[p], b / g.gx[p], red);
-    else gemm16_tile<false>(g.g[p], b % g.gx[p], b / g.gx[p], red);
-}
-// the same for products in Float32 arithmetic (a kernel of its own: its fragments need twice the registers)
-__global__ __launch_bounds__(256) void gemm32_group_kernel(Gemm16Group g) {
-    __shared__ float red[4][G16_TM][G16_LDR];
-    ISK_LATENCY_CHAIN_PRIO();
-    int p = 0, b = blockIdx.x;
-    while (p + 1 < g.n && b >= g.first[p + 1]) ++p;
-    b -= g.first[p];
-    if (g.slow[p]) gemm16_tile<true, true>(g.g[p], b % g.gx[p], b / g.gx[p], red);
-    else gemm16_tile<false, true>(g.g[p], b % g.gx[p], b / g.gx[p], red);
+    // uniform per workgroup; Float32 arithmetic is a kernel of its own: its fragments need twice the registers)
+    if (g.slow[p]) gemm16_tile<true, F32, NW>(g.g[p], b % g.gx[p], b / g.gx[p], red);
+    else if (!F32 && g.g[p].b_f32) gemm16_tile<false, F32, NW, !F32>(g.g[p], b % g.gx[p], b / g.gx[p], red);
+    else gemm16_tile<false, F32, NW>(g.g[p], b % g.gx[p], b / g.gx[p], red);
 }
 
 static bool g16_grid(const Gemm16Args& a, int* gx, int* gy, bool* slow) {
@@ -282,35 +320,50 @@ static bool g16_grid(const Gemm16Args& a, int* gx, int* gy, bool* slow) {
     if (a.f32math && !(a.a_f32 && a.b_f32)) return false;               // Float32 arithmetic reads f32 operands
     const int ea = a.a_f32 ? 4 : 8, eb = a.b_f32 ? 4 : 8;
     const bool a_al = ((uintptr_t)a.A % 16 == 0) && (a.lda % ea == 0), b_al = ((uintptr_t)a.B % 16 == 0) && (a.ldb % eb == 0);
-    *slow = !a_al || !b_al || a.kvalid < a.Kc;
+    *slow = !a_al || !b_al || a.kvalid < a.Kc || (!a.f32math && a.a_f32);       // (bf16 arithmetic on an f32 A operand: no fast path)
     return true;
 }
+
+// waves per workgroup: eight where a wave would otherwise walk more than four 32-deep steps (option-free: both variants give the
+// same sums up to the order of the K-split partials)
+// (Float32 arithmetic keeps four: its fragments need ~190 registers, and two such waves per SIMD do not fit beside a featurizer wave --
+// measured 4.2 against 3.75 ms per C5-shard iteration)
+static int g16_waves(const Gemm16Args& a) { return a.waves == 4 || a.waves == 8 ? a.waves : (!a.f32math && a.Kc / 32 >= 16 ? 8 : 4); }
 
 int isk_launch_gemm16(const Gemm16Args& a, hipStream_t st) {
     int gx, gy; bool slow;
     if (!g16_grid(a, &gx, &gy, &slow)) return ISK_EINVAL;
     void* args[] = {(void*)&a};
-    const void* fn = a.f32math ? (slow ? (const void*)gemm16_kernel<true, true> : (const void*)gemm16_kernel<false, true>)
-                               : (slow ? (const void*)gemm16_kernel<true, false> : (const void*)gemm16_kernel<false, false>);
-    return hipLaunchKernel(fn, dim3(gx, gy), dim3(256), args, 0, st) == hipSuccess ? 0 : ISK_EHIP;
+    const int nw = g16_waves(a);
+    const bool bw = !a.f32math && a.b_f32 && !slow;
+    const void* fn;
+#define G16_PICK(NW_)                                                                                                              \
+    (a.f32math ? (slow ? (const void*)gemm16_kernel<true, true, NW_, false> : (const void*)gemm16_kernel<false, true, NW_, false>)      \
+               : (slow ? (const void*)gemm16_kernel<true, false, NW_, false>                                                           \
+                       : (bw ? (const void*)gemm16_kernel<false, false, NW_, true> : (const void*)gemm16_kernel<false, false, NW_, false>)))
+    if (nw == 8) fn = G16_PICK(8); else fn = G16_PICK(4);
+#undef G16_PICK
+    return hipLaunchKernel(fn, dim3(gx, gy), dim3(nw * 64), args, 0, st) == hipSuccess ? 0 : ISK_EHIP;
 }
 
 int isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st) {
     if (n < 1 || n > ISK_G16_MAXGROUP) return ISK_EINVAL;
     Gemm16Group g;
     g.n = n;
-    int total = 0;
+    int total = 0, nw = 4;
     for (int p = 0; p < n; ++p) {
         int gx, gy; bool slow;
         if (!g16_grid(list[p], &gx, &gy, &slow)) return ISK_EINVAL;
         g.g[p] = list[p]; g.gx[p] = gx; g.first[p] = total; g.slow[p] = slow ? 1 : 0; g.f32[p] = list[p].f32math;
         if (list[p].f32math != list[0].f32math) return ISK_EINVAL;     // one arithmetic per launch
         total += gx * gy;
+        if (g16_waves(list[p]) == 8) nw = 8;
     }
     if (n == 1) return isk_launch_gemm16(list[0], st);
     void* args[] = {(void*)&g};
-    const void* fn = list[0].f32math ? (const void*)gemm32_group_kernel : (const void*)gemm16_group_kernel;
-    return hipLaunchKernel(fn, dim3(total), dim3(256), args, 0, st) == hipSuccess ? 0 : ISK_EHIP;
+    const void* fn = list[0].f32math ? (nw == 8 ? (const void*)gemm16_group_kernel<true, 8> : (const void*)gemm16_group_kernel<true, 4>)
+                                     : (nw == 8 ? (const void*)gemm16_group_kernel<false, 8> : (const void*)gemm16_group_kernel<false, 4>);
+    return hipLaunchKernel(fn, dim3(total), dim3(nw * 64), args, 0, st) == hipSuccess ? 0 : ISK_EHIP;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -374,6 +427,22 @@ static GatherArgs gather_args(const float* X, int ldx, const int* perm, int B, i
     GatherArgs g = {X, ldx, perm, B, Bp, K, Kp, xb, xt, ldt, (Bp + 31) / 32, f32};
     *nblocks = g.gx * ((K + 1 + 31) / 32);                             // covers k = K (the ones row)
     return g;
+}
+// the batch images of a whole EPOCH in one launch (blockIdx.y = batch: rows perm[y * B .. + B), images y strides further): the
+// gather depends on the shuffle order only, so it need not sit in front of every optimizer step's chain
+__global__ __launch_bounds__(256) void gather_epoch_kernel(GatherArgs g, long long xb_stride, long long xt_stride) {
+    __shared__ float tile[32][33];
+    const int y = blockIdx.y;
+    g.perm += (long long)y * g.B;
+    g.xb = (char*)g.xb + y * xb_stride;
+    g.xt = (char*)g.xt + y * xt_stride;
+    gather_tile(g, blockIdx.x % g.gx, blockIdx.x / g.gx, tile);
+}
+void isk_launch_gather_epoch(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
+                             int img_f32, int nbatch, long long xb_stride_bytes, long long xt_stride_bytes, hipStream_t st) {
+    int nb;
+    const GatherArgs g = gather_args(X, ldx, perm, B, Bp, K, Kp, xb, xt, ldt, img_f32, &nb);
+    hipLaunchKernelGGL(gather_epoch_kernel, dim3(nb, nbatch), dim3(256), 0, st, g, xb_stride_bytes, xt_stride_bytes);
 }
 void isk_launch_gather_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
                               int img_f32, hipStream_t st) {

@@ -193,3 +193,33 @@ def test_tail_step_riding_on_the_layer1_forward(gpu_pkg, widths, ln, mb, N):
     np.testing.assert_allclose(isos[1].model.get_params(), om.get_flat(), atol=3e-5, rtol=3e-4)
     for iso in isos.values():
         iso.close()
+
+
+@pytest.mark.parametrize("train_bf16", [0, 1])
+@pytest.mark.parametrize("ln", [False, True])
+def test_wide_network_epoch_images_gathered_up_front(gpu_pkg, train_bf16, ln):
+    """wide networks (layered path), option epoch_gather: the batch images of every batch of an epoch are written by one launch in
+    front of the epoch's steps instead of one launch per step.  Same images, same products: losses, parameters and optimizer state
+    bit-identical to the per-step gather, in Float32 and in bf16 arithmetic, over epochs with different shuffle orders; and a
+    gradient-only call between epochs (rows that are not a batch of an epoch) is unaffected."""
+    pkg = gpu_pkg
+    widths, N, mb = [64, 200, 48, 2], 330, 64
+    A = 24
+    xs, ys = O.synthetic_coords(A, N, 2, seed=21)
+    pairs = O.random_pairs(A, widths[0], seed=22)
+    isos = {g: pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_model(pkg, widths, seed=23, ln=ln)[1],
+                       opt=pkg.OptSpec("adam", 1e-2, 1e-3), minibatch=mb, options={"epoch_gather": g, "train_bf16": train_bf16}) for g in (1, 0)}
+    assert all(i.get_option("layered") == 1 for i in isos.values())
+    rng = np.random.default_rng(0)
+    for ep in range(3):
+        tgt = np.asarray(rng.uniform(size=(widths[-1], N)), np.float32)
+        perm = rng.permutation(N)
+        l1, l0 = (pkg.train_batch(isos[g], tgt, perm=perm) for g in (1, 0))
+        assert l1 == l0 and np.isfinite(l1), (ep, l1, l0)
+    np.testing.assert_array_equal(isos[1].model.get_params(), isos[0].model.get_params())
+    m1, v1, _ = isos[1].get_opt_state()
+    m0, v0, _ = isos[0].get_opt_state()
+    np.testing.assert_array_equal(m1, m0)
+    np.testing.assert_array_equal(v1, v0)
+    for iso in isos.values():
+        iso.close()
