@@ -327,7 +327,8 @@ static bool g16_grid(const Gemm16Args& a, int* gx, int* gy, bool* slow) {
 // waves per workgroup: eight where a wave would otherwise walk more than four 32-deep steps (option-free: both variants give the
 // same sums up to the order of the K-split partials)
 // (Float32 arithmetic keeps four: its fragments need ~190 registers, and two such waves per SIMD do not fit beside a featurizer wave --
-// measured 4.2 against 3.75 ms per C5-shard iteration)
+// measured 4.2 against 3.75 ms per C5-shard iteration.  Walking the contraction in 16-deep steps instead -- four-register fragments,
+// 128 registers, eight waves -- was built and is slower still, 236..250 against 213 us per optimizer step: twice the round trips)
 static int g16_waves(const Gemm16Args& a) { return a.waves == 4 || a.waves == 8 ? a.waves : (!a.f32math && a.Kc / 32 >= 16 ? 8 : 4); }
 
 int isk_launch_gemm16(const Gemm16Args& a, hipStream_t st) {
