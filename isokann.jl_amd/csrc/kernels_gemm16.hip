@@ -161,7 +161,7 @@ __device__ __forceinline__ void gemm16_tile(const Gemm16Args& a, const int bx, c
     // sets (two steps ahead) at ~250 registers per wave; two sets fit 128, and what hides the round trips -- ~1 us each beside the
     // side-stream featurizer -- is then the other workgroups on the CU (two 4-wave or one 8-wave workgroup beside a featurizer wave,
     // four / two without it): C5-shard iteration 3.08 -> 2.90 ms (bf16), and the deep products split K over eight waves
-    constexpr int NSET = 2;
+    constexpr int NSET = F32 ? 1 : 2;
     frag_t fa[NSET][2], fb[NSET][4];
     auto loadset = [&](int ks, auto SLOT) {
         constexpr int sl = decltype(SLOT)::value;
@@ -201,15 +201,20 @@ __device__ __forceinline__ void gemm16_tile(const Gemm16Args& a, const int bx, c
                 for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[sl][rt], fb[sl][ct], acc[rt][ct], 0, 0, 0);
         }
     };
-    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+    using S0 = std::integral_constant<int, 0>;
     int ks = wave;
-    loadset(ks, S0{});
-    for (; ks < nk; ks += 2 * NW) {
-        loadset(ks + NW, S1{});
-        mma(S0{});
-        if (ks + NW >= nk) break;
-        loadset(ks + 2 * NW, S0{});
-        mma(S1{});
+    if constexpr (NSET == 1) {
+        for (; ks < nk; ks += NW) { loadset(ks, S0{}); mma(S0{}); }
+    } else {
+        using S1 = std::integral_constant<int, NSET - 1>;
+        loadset(ks, S0{});
+        for (; ks < nk; ks += 2 * NW) {
+            loadset(ks + NW, S1{});
+            mma(S0{});
+            if (ks + NW >= nk) break;
+            loadset(ks + 2 * NW, S0{});
+            mma(S1{});
+        }
     }
     // C layout of the 16x16 tile: column = lane & 15, row = 4 * (lane >> 4) + r
     // (eight waves: two stages, so that the buffer stays at four tile sets -- waves 4..7 park their tiles, waves 0..3 add their own
@@ -287,7 +292,7 @@ __device__ __forceinline__ void gemm16_tile(const Gemm16Args& a, const int bx, c
 // Register cap: left to itself hipcc spends ~250 registers per wave here (copies parked in AGPRs), which lets ONE 4-wave workgroup
 // share a CU with the side-stream featurizer (its waves hold ~248 of a SIMD's 512) and no 8-wave workgroup at all.  128 (bf16) /
 // 168 (Float32 fragments) registers are what the fragment sets need.
-#define G16_WAVES_PER_EU(F32_) ((F32_) ? 2 : 4)
+#define G16_WAVES_PER_EU(F32_) 4
 template <bool SLOW, bool F32, int NW, bool BW>
 __global__ __launch_bounds__(NW * 64, G16_WAVES_PER_EU(F32)) void gemm16_kernel(Gemm16Args a) {
     __shared__ float red[4][G16_TM][G16_LDR];
@@ -326,10 +331,11 @@ static bool g16_grid(const Gemm16Args& a, int* gx, int* gy, bool* slow) {
 
 // waves per workgroup: eight where a wave would otherwise walk more than four 32-deep steps (option-free: both variants give the
 // same sums up to the order of the K-split partials)
-// (Float32 arithmetic keeps four: its fragments need ~190 registers, and two such waves per SIMD do not fit beside a featurizer wave --
-// measured 4.2 against 3.75 ms per C5-shard iteration.  Walking the contraction in 16-deep steps instead -- four-register fragments,
-// 128 registers, eight waves -- was built and is slower still, 236..250 against 213 us per optimizer step: twice the round trips)
-static int g16_waves(const Gemm16Args& a) { return a.waves == 4 || a.waves == 8 ? a.waves : (!a.f32math && a.Kc / 32 >= 16 ? 8 : 4); }
+// (Float32 arithmetic: a fragment is eight registers, so ONE fragment set -- a 32-deep step is 64 MFMAs of 32 cycles, ~0.85 us,
+// which a second wave on the SIMD fills with its own round trip: 72 registers, 3.75 -> 3.67 ms per C5-shard iteration against two sets
+// at ~190 registers and one workgroup per CU.  Walking the contraction in 16-deep steps instead (four-register fragments) is slower,
+// 236..250 against 209 us per optimizer step: twice the round trips.  bf16 with one set: 145..148 against 143 us)
+static int g16_waves(const Gemm16Args& a) { return a.waves == 4 || a.waves == 8 ? a.waves : (a.Kc / 32 >= 16 ? 8 : 4); }
 
 int isk_launch_gemm16(const Gemm16Args& a, hipStream_t st) {
     int gx, gy; bool slow;
