@@ -126,12 +126,16 @@ __device__ __forceinline__ void gemm16_tile(const Gemm16Args& a, const int bx, c
     __amdgpu_buffer_rsrc_t ra, rb;
     int voA[2], voB[4];
     if constexpr (!SLOW) {
-        ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, 0x7ffffffc, 0x00020000);
-        rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, 0x7ffffffc, 0x00020000);
+        // descriptors based at the tile's first operand row (64-bit scalar arithmetic), lane offsets relative to it: an operand may
+        // be larger than the 2^31 bytes a 32-bit offset reaches (full-batch training of a wide network on 10^6 rows).  A tile
+        // that lies wholly in the padding rows (i0 >= M: it only writes zeros into the images) gets negative offsets, i.e. huge
+        // unsigned ones: out of range, the loads return 0
+        ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.A + (long long)i0 * a.lda * ea), 0, 0x7ffffffc, 0x00020000);
+        rb = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.B + (long long)j0 * a.ldb * eb), 0, 0x7ffffffc, 0x00020000);
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) voA[rt] = (int)offA[rt] * ea;
+        for (int rt = 0; rt < 2; ++rt) voA[rt] = (int)(offA[rt] - (long long)i0 * a.lda) * ea;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) voB[ct] = (int)offB[ct] * eb;
+        for (int ct = 0; ct < 4; ++ct) voB[ct] = (int)(offB[ct] - (long long)j0 * a.ldb) * eb;
     }
     auto bload = [&](__amdgpu_buffer_rsrc_t r, int vo, int so) -> f32x4 {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
