@@ -11,7 +11,7 @@ The directory name is not a Python identifier; load it with
 """
 from . import capi  # noqa: F401
 from .api import (  # noqa: F401
-    AdamRegularized, DomainError, FeaturesAll, FeaturesAtoms, FeaturesPairs, HipModel, IskError, Iso, ModelSpec,
+    AdamRegularized, DomainError, FeaturesAll, FeaturesAtoms, FeaturesCoords, FeaturesPairs, HipModel, IskError, Iso, ModelSpec,
     NesterovRegularized, OptSpec, SimulationData, TransformISA, TransformPseudoInv, TransformShiftscale, batch_grads, chicoords, chis,
     coords, densenet, featuredim, features, halfinds, identity, inputdim, isotarget, koopman, outputdim, pairnet,
     pairnet_widths, propcoords, propfeatures, run, train_batch, koopman_coords, chi_kchi, validationloss,

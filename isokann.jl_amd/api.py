@@ -83,6 +83,11 @@ class FeaturesPairs:
 identity = None      # featurizer(::IsoSimulation) = identity  (src/simulation.jl:15)
 
 
+def FeaturesCoords():
+    """the coordinates themselves are the features (src/utils/features.jl:18-19: `(f::FeaturesCoords)(coords) = coords`)"""
+    return identity
+
+
 # ----------------------------------------------------------------------------- model ---
 def pairnet_widths(n: int, layers: int = 3, nout: int = 1) -> List[int]:
     """src/models.jl:66-67 (Julia's round(Int, x) and Python's round both round half to even)"""

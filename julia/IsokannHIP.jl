@@ -15,7 +15,7 @@ module IsokannHIP
 
 using ISOKANN, Flux, Optimisers
 import ISOKANN: Iso, run!, train_batch!, isotarget, chis, chicoords, koopman, outputdim, inputdim, iscuda, gpu, cpu, save
-import ISOKANN: SimulationData, FeaturesAll, FeaturesAtoms, FeaturesPairs, TransformShiftscale, TransformISA, halfinds
+import ISOKANN: SimulationData, FeaturesCoords, FeaturesAll, FeaturesAtoms, FeaturesPairs, TransformShiftscale, TransformISA, halfinds
 
 const LIB = Ref{String}("libisokann_hip.so")      # set to isokann.jl_amd/lib/libisokann_hip.so of the build tree
 const ABI_VERSION = Int32(2)
@@ -98,10 +98,10 @@ function make_config(data, model::Flux.Chain, opt, target, minibatch;
     f = data.featurizer
     D = size(data.coords[1], 1)
     pl = feat_pairs(f)
-    fkind, natoms, npairs, pptr = f === identity ? (Int32(0), Int32(0), Int32(0), Ptr{Int32}(C_NULL)) :
+    fkind, natoms, npairs, pptr = (f === identity || f isa FeaturesCoords) ? (Int32(0), Int32(0), Int32(0), Ptr{Int32}(C_NULL)) :
         f isa FeaturesAll ? (Int32(1), Int32(D ÷ 3), Int32(0), Ptr{Int32}(C_NULL)) :
         pl !== nothing ? (Int32(2), Int32(D ÷ 3), Int32(length(pl) ÷ 2), pointer(pl)) :
-        error("featurizer $f: the engine implements identity, FeaturesAll, FeaturesAtoms and FeaturesPairs")
+        error("featurizer $f: the engine implements identity / FeaturesCoords, FeaturesAll, FeaturesAtoms and FeaturesPairs")
     tkind, perm, whit = target isa TransformShiftscale ? (0, 1, 0) :
         target isa TransformISA ? (1, Int(target.permute), Int(target.whitening)) : (2, 1, 0)   # 2: host-side transform
     cfg = IskConfig(ABI_VERSION, device, length(dense), Tuple(w), act, act_id(dense[end].σ),
