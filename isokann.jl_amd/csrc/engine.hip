@@ -1125,15 +1125,18 @@ bool epoch_no_fold(isk_engine* e) { return epoch_lazy_fold(e) && e->xh16 && (bf1
 void launch_opt(isk_engine* e, float gscale, bool fold, bool capturing, bool publish, const OptPeers* peers, bool kernel_done) {
     const bool dev = !e->layered && e->bt_dev_valid;
     (void)capturing;
+    bool images_fresh = false;                   // the wide-network path wrote the next step's weight images with the step
     if (!kernel_done) {                          // (kernel_done: train_grad1n carried the step -- launch_grads with fuse_mode)
         const OptArgs a = opt_args(e, gscale, publish);
         if (peers) isk_launch_opt_step_peers(a, *peers, e->stream);
+        else if (layered_opt_boundary(e, a)) images_fresh = true;
         else isk_launch_opt_step(a, e->stream);
     }
+    e->next_idx = nullptr;
     e->loss_acc_zeroed = false;
     e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2;
     if (!dev) e->bt_dev_valid = false;           // this step advanced only the host copy
-    e->b16.wt_dirty = e->b16.wf_dirty = true;
+    e->b16.wt_dirty = !images_fresh; e->b16.wf_dirty = true;
     if (e->native) { e->wt_dirty = true; e->w16_dirty = true; }      // the training steps read theta; forwards re-fold on demand
     else if (fold) launch_fold(e);
     else e->wt_dirty = true;                     // a forward folds on demand (ensure_folded)
@@ -1353,6 +1356,7 @@ static int train_epoch(isk_engine* e, int32_t minibatch, const int32_t* perm, do
             EpochGatherScope images(e, e->d_perm, bs, nb);
             for (long long b = 0; b < nb; ++b) {
                 launch_grads(e, e->d_perm + b * bs, (int)bs, 1.0f / (float)bs, nsl, true, false, fuse ? (b == nb - 1 ? 2 : 1) : 0);
+                e->next_idx = b + 1 < nb ? e->d_perm + (b + 1) * bs : nullptr; e->next_B = (int)bs;
                 launch_opt(e, 1.0f, !lazy_fold || (b == nb - 1 && !epoch_no_fold(e)), false, b == nb - 1, nullptr, fuse);
             }
         }

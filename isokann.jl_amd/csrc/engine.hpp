@@ -135,6 +135,8 @@ struct isk_engine {
         // the batch images of a whole epoch, gathered in ONE launch in front of its steps (layered_epoch_gather)
         void *xb_all = nullptr, *xt_all = nullptr;    // [nb][Bp][Fp], [nb][F + 1][Bp]
         size_t xb_all_bytes = 0, xt_all_bytes = 0;
+        const int* pre_idx = nullptr;                 // the batch whose images the last step-boundary launch wrote into xb / xt (or nullptr)
+        int pre_B = 0, pre_esz = 0;
         const int* ep_perm = nullptr;                 // valid while ep_nb > 0: the epoch's shuffle order, batch size, batch count
         long long ep_bs = 0, ep_nb = 0;
         int ep_esz = 0;
@@ -173,6 +175,8 @@ struct isk_engine {
     int bucket_issued = 0;                      // the hook ran in this step: the upper bucket is already on its way
     int bucket_err = 0;                         // ncclResult of the hook's collective (0 = success)
     bool tp_disabled = false;
+    const int* next_idx = nullptr;              // set by the epoch loops around launch_opt: the rows of the NEXT optimizer step (or nullptr)
+    int next_B = 0;
     bool last_fwdtail = false;                  // the last launch_grads took the one-launch forward + tail (option fuse_tail)
     bool last_epoch_persist = false;            // a launch failed or timed out: the four-kernel chain from then on
     unsigned long long* dbg_st = nullptr;            // diagnostics of forward_resident (options debug_stamps / debug_rowmod)
@@ -286,6 +290,8 @@ int compute_target(isk_engine* e, bool check, bool ahead = false);
 int pick_slabs(int B);
 void layered_epoch_gather(isk_engine* e, const int* d_perm, long long bs, long long nb);
 void layered_epoch_end(isk_engine* e);
+struct OptArgs;
+bool layered_opt_boundary(isk_engine* e, const OptArgs& a);
 struct EpochGatherScope {            // the epoch images are valid only while the epoch's steps are being enqueued
     isk_engine* e;
     EpochGatherScope(isk_engine* e_, const int* d_perm, long long bs, long long nb) : e(e_) { layered_epoch_gather(e, d_perm, bs, nb); }

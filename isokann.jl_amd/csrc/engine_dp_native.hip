@@ -360,6 +360,7 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
                         // a collective this rank could not even enqueue: the peers are lost anyway, say why and stop
                         if (r != ncclSuccess) { (void)dp_clear_poison(e); return fail(ISK_EHIP, std::string("rccl: ") + g_rccl.GetErrorString(r)); }
                     }
+                    e->next_idx = b + 1 < nbatches ? e->d_perm + (long long)(b + 1) * local_batch : nullptr; e->next_B = local_batch;
                     launch_opt(e, 1.0f, !lazy_fold || (b == nbatches - 1 && !epoch_no_fold(e)), false, b == nbatches - 1);
                 }
             }

@@ -340,6 +340,27 @@ void layered_epoch_gather(isk_engine* e, const int* d_perm, long long bs, long l
 }
 void layered_epoch_end(isk_engine* e) { e->b16.ep_nb = 0; }
 
+// The boundary between two optimizer steps as ONE launch (option fuse_boundary; kernels_gemm16.hip opt_prep_kernel): the optimizer
+// step, the weight images of the next step, and -- when the epoch loop has announced them (e->next_idx) -- the batch images of the
+// next step.  false: not applicable here (the caller launches opt_step; the next step prepares its own images).
+bool layered_opt_boundary(isk_engine* e, const OptArgs& a) {
+    auto& b = e->b16;
+    b.pre_idx = nullptr;
+    if (!e->layered || !e->opt.fuse_boundary || e->cfg.layernorm || !(bf16_train_active(e) || mfma32_train_active(e))) return false;
+    if (b.rows <= 0 || !b.Wt[0] || !b.xb || a.nslab != 1) return false;
+    const int esz = bf16_train_active(e) ? 2 : 4;
+    if (b.esz != esz) return false;
+    WtImagesArgs w;
+    b.wt_dirty = true;                                               // (the step changes every weight)
+    if (!weight_image_args(e, true, false, w, esz)) return false;
+    const int* next = e->next_idx;
+    const int B = e->next_B, Bp = isk_pad32(B);
+    if (next && (B < 1 || Bp > b.rows)) next = nullptr;
+    isk_launch_opt_prep(a, w, e->off_b, e->d_xs32, e->Fp, next, B, Bp, e->F, e->Fp, b.xb, b.xt, b.rows, esz == 4, e->stream);
+    if (next) { b.pre_idx = next; b.pre_B = B; b.pre_esz = esz; }
+    return true;
+}
+
 // f32math: the same chain of fused products in Float32 arithmetic (f32 images, v_mfma_f32_16x16x4_f32)
 static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, float inv_div, const int f32math) {
     const int L = e->L;
@@ -358,13 +379,17 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
         // is one of an epoch whose images were gathered up front (layered_epoch_gather)
         WtImagesArgs w;
         const bool dirty = weight_image_args(e, true, false, w, esz);
-        const long long off = b.ep_nb > 0 && B == b.ep_bs && esz == b.ep_esz && d_idx >= b.ep_perm ? (long long)(d_idx - b.ep_perm) : -1;
+        const bool pre = b.pre_idx && b.pre_idx == d_idx && b.pre_B == B && b.pre_esz == esz;    // written by the last step-boundary launch
+        b.pre_idx = nullptr;
+        const long long off = pre ? -1 : b.ep_nb > 0 && B == b.ep_bs && esz == b.ep_esz && d_idx >= b.ep_perm ? (long long)(d_idx - b.ep_perm) : -1;
         if (off >= 0 && off % B == 0 && off / B < b.ep_nb) {
             const long long k = off / B;
             xb = (const char*)b.xb_all + (size_t)k * Bp * e->Fp * esz;
             xt = (const char*)b.xt_all + (size_t)k * (e->F + 1) * Bp * esz;
             ldX = Bp;
             if (dirty) isk_launch_wt_images(w, st);
+        } else if (pre) {
+            if (dirty) isk_launch_wt_images(w, st);                  // (parameters set from outside since: the batch images stand)
         } else if (dirty) {
             isk_launch_prep_images(e->d_xs32, e->Fp, d_idx, B, Bp, e->F, e->Fp, b.xb, b.xt, ldB, f32math, w, st);
         } else {

@@ -45,6 +45,7 @@ struct IskOptions {
     int fuse_opt_rows = 768;      // ... for batches of up to this many rows (<= 1024).  Beyond 768 the gradient kernel splits the rows over two
                                   // workgroups per feature tile and opt_step sums the two slabs; keeping C3's 1000-row batches on one slab
                                   // to fuse the step was measured SLOWER (1.177 against 1.129 ms per iteration: twice the MFMA chain per wave)
+    int fuse_boundary = 1;        // layered training GEMMs, no leading LayerNorm: opt_step + the next step's weight and batch images as ONE launch
     int epoch_gather = 0;         // layered training GEMMs: the batch images of a whole epoch are gathered in one launch in front of its steps.
                                   // Bit-identical, and no faster (C5 shard 2.99 against 2.95 ms: the step keeps a launch for the weight images)
     int g16_waves = 0;            // layered training GEMMs: waves per workgroup that split the contraction (4 | 8; 0: eight where the product is
@@ -259,6 +260,11 @@ struct WtImagesArgs {
     int wt_f32;                                  // 1: the Wt images are FLOAT arrays (Float32 arithmetic of the training GEMMs)
 };
 void isk_launch_wt_images(WtImagesArgs& a, hipStream_t st);
+// the boundary between two optimizer steps of the wide-network path as one launch: optimizer step + the next step's weight images +
+// the next step's batch images (next_perm == nullptr: none); networks without a leading LayerNorm
+struct OptArgs;
+void isk_launch_opt_prep(const OptArgs& oa, WtImagesArgs& w, const long long* off_b, const float* X, int ldx, const int* next_perm, int B, int Bp,
+                         int K, int Kp, void* xb, void* xt, long long ldt, int img_f32, hipStream_t st);
 // isk_launch_gather_images + isk_launch_wt_images as ONE launch (the head of an optimizer step of the bf16 layered path)
 void isk_launch_prep_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
                             int img_f32, WtImagesArgs& w, hipStream_t st);

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "isk_internal.h"
+#include "opt_rule.hpp"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -518,6 +519,110 @@ __global__ __launch_bounds__(256) void prep_images_kernel(GatherArgs g, WtImages
     if (b < ngather) gather_tile(g, b % g.gx, b / g.gx, tile);
     else wt_tile(w, b - ngather, tile);
 }
+// The boundary between two optimizer steps of the wide-network path as ONE launch: the optimizer step of step s (every weight
+// matrix tile by tile, the biases elementwise), the row-major weight images of step s + 1 written from the freshly updated tile
+// (the same numbers wt_images_kernel would read back), and the batch images of step s + 1 (they depend on the shuffle order only).
+// It replaces opt_step + prep_images: one dependent launch less per step.  Semantics of opt_step_kernel: a non-finite batch loss, a
+// flagged rank or an earlier collapse of the epoch skips the update (the images then keep their -- still valid -- contents).
+// No leading LayerNorm (its scale is folded into layer 0's image and is itself a parameter of the step): the caller keeps the two
+// launches there.
+__device__ __forceinline__ void opt_wt_tile(const OptArgs& oa, const WtImagesArgs& a, int blk, const bool bad, const float bc1, const float bc2,
+                                            float (*tile)[33]) {
+    int l = 0;
+    while (l + 1 < a.nlayers && blk >= a.first_block[l + 1]) ++l;
+    blk -= a.first_block[l];
+    const int K = a.K[l], N = a.N[l], Kp = a.Kp[l];
+    const int tk = (Kp + 31) / 32;
+    const int k0 = (blk % tk) * 32, n0 = (blk / tk) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const bool adam = oa.kind == ISK_OPT_ADAM;
+    long long idx[4];
+    float th[4], gs[4], mi[4], vi[4];
+    const int nc = (n0 + tx) < N ? (n0 + tx) : N - 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                                     // every operand requested together, from clamped addresses
+        const int kc = (k0 + ty + 8 * q) < K ? (k0 + ty + 8 * q) : K - 1;
+        idx[q] = a.off_W[l] + (long long)kc * N + nc;
+        th[q] = oa.theta[idx[q]]; gs[q] = oa.grad[idx[q]]; mi[q] = oa.m[idx[q]]; vi[q] = adam ? oa.v[idx[q]] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = ty + 8 * q;
+        const int k = k0 + r, n = n0 + tx;
+        const bool in = k < K && n < N;
+        if (in && !bad) {
+            opt_rule(oa, bc1, bc2, gs[q], th[q], mi[q], vi[q]);
+            oa.theta[idx[q]] = th[q]; oa.m[idx[q]] = mi[q];
+            if (adam) oa.v[idx[q]] = vi[q];
+        }
+        tile[r][tx] = in ? th[q] : 0.f;
+    }
+    if (bad) return;                                                  // (uniform) nothing changed: the images are current
+    __syncthreads();
+    void* out = a.Wt[l];
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        if (n < N && k < Kp && out) {
+            if (a.wt_f32) ((float*)out)[(long long)n * Kp + k] = tile[tx][r]; else ((u16*)out)[(long long)n * Kp + k] = to_bf16(tile[tx][r]);
+        }
+    }
+}
+struct OptPrepBias { int nlayers; long long off_b[ISK_MAX_LAYERS]; int n[ISK_MAX_LAYERS]; };
+__global__ __launch_bounds__(256) void opt_prep_kernel(OptArgs oa, WtImagesArgs w, OptPrepBias bb, GatherArgs g, int nwt, int nbias, int ngather) {
+    __shared__ float tile[32][33];
+    ISK_LATENCY_CHAIN_PRIO();
+    const int b = blockIdx.x;
+    if (b >= nwt + nbias) { if (ngather > 0) gather_tile(g, (b - nwt - nbias) % g.gx, (b - nwt - nbias) / g.gx, tile); return; }
+    const float bc1 = oa.bt ? (float)(1.0 - oa.bt[0]) : oa.bc1, bc2 = oa.bt ? (float)(1.0 - oa.bt[1]) : oa.bc2;
+    const float lstep = oa.grad[oa.n], peer = oa.grad[oa.n + 1];
+    const double collapsed = oa.loss_acc[1];
+    const bool bad = (collapsed != 0.0) || !isfinite(lstep) || peer != 0.f;
+    if (b < nwt) {
+        opt_wt_tile(oa, w, b, bad, bc1, bc2, tile);
+    } else {
+        // the biases: element e of their concatenation
+        int e = (b - nwt) * 256 + threadIdx.x, l = 0;
+        while (l < bb.nlayers && e >= bb.n[l]) { e -= bb.n[l]; ++l; }
+        if (l < bb.nlayers && !bad) {
+            const long long i = bb.off_b[l] + e;
+            float th = oa.theta[i], mi = oa.m[i], vi = oa.kind == ISK_OPT_ADAM ? oa.v[i] : 0.f;
+            opt_rule(oa, bc1, bc2, oa.grad[i], th, mi, vi);
+            oa.theta[i] = th; oa.m[i] = mi;
+            if (oa.kind == ISK_OPT_ADAM) oa.v[i] = vi;
+        }
+    }
+    if (b == 0 && threadIdx.x == 0) {                                 // the epoch's bookkeeping, as in opt_step_kernel
+        double* const loss_acc = oa.loss_acc;
+        double acc0 = loss_acc[0];
+        if (peer != 0.f) loss_acc[3] = (double)peer;
+        if (bad) loss_acc[1] = 1.0;
+        else { acc0 += (double)lstep; loss_acc[0] = acc0; }
+        if (oa.host_pub) {
+            oa.host_pub[0] = acc0;
+            oa.host_pub[1] = bad ? 1.0 : 0.0;
+            ((int*)(oa.host_pub + 2))[0] = ((const int*)(loss_acc + 2))[0];
+            oa.host_pub[3] = peer != 0.f ? (double)peer : loss_acc[3];
+            __threadfence_system();
+        }
+    }
+}
+// next_perm == nullptr: no batch follows (the epoch's last step)
+void isk_launch_opt_prep(const OptArgs& oa, WtImagesArgs& w, const long long* off_b, const float* X, int ldx, const int* next_perm, int B, int Bp,
+                         int K, int Kp, void* xb, void* xt, long long ldt, int img_f32, hipStream_t st) {
+    int nwt = 0;
+    for (int l = 0; l < w.nlayers; ++l) { w.first_block[l] = nwt; nwt += ((w.Kp[l] + 31) / 32) * ((w.N[l] + 31) / 32); }
+    OptPrepBias bb = {};
+    bb.nlayers = w.nlayers;
+    int nbe = 0;
+    for (int l = 0; l < w.nlayers; ++l) { bb.off_b[l] = off_b[l]; bb.n[l] = w.N[l]; nbe += w.N[l]; }
+    const int nbias = (nbe + 255) / 256;
+    int ng = 0;
+    GatherArgs g = {};
+    if (next_perm) g = gather_args(X, ldx, next_perm, B, Bp, K, Kp, xb, xt, ldt, img_f32, &ng);
+    hipLaunchKernelGGL(opt_prep_kernel, dim3(nwt + nbias + ng), dim3(256), 0, st, oa, w, bb, g, nwt, nbias, ng);
+}
+
 void isk_launch_wt_images(WtImagesArgs& a, hipStream_t st) {
     int total = 0;
     for (int l = 0; l < a.nlayers; ++l) { a.first_block[l] = total; total += ((a.Kp[l] + 31) / 32) * ((a.N[l] + 31) / 32); }

@@ -223,3 +223,46 @@ def test_wide_network_epoch_images_gathered_up_front(gpu_pkg, train_bf16, ln):
     np.testing.assert_array_equal(v1, v0)
     for iso in isos.values():
         iso.close()
+
+
+@pytest.mark.parametrize("train_bf16", [0, 1])
+@pytest.mark.parametrize("opt", ["adam", "nesterov"])
+def test_wide_network_step_boundary_as_one_launch(gpu_pkg, train_bf16, opt):
+    """wide networks without a leading LayerNorm, option fuse_boundary: the optimizer step, the next step's weight images and the next
+    step's batch images are ONE launch (opt_prep_kernel) instead of opt_step + prep_images.  The update rule is the shared opt_rule
+    and the images are written from the values opt_step would have stored: losses, parameters and optimizer state bit-identical to
+    the two launches, over several epochs (the first step of an epoch prepares its own images, the last one gathers nothing); a
+    non-finite loss applies nothing and reports the collapse."""
+    pkg = gpu_pkg
+    widths, N, mb = [64, 200, 48, 2], 330, 64
+    A = 24
+    xs, ys = O.synthetic_coords(A, N, 2, seed=31)
+    pairs = O.random_pairs(A, widths[0], seed=32)
+    isos = {f: pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_model(pkg, widths, seed=33, ln=False)[1],
+                       opt=pkg.OptSpec(opt, 1e-2, 1e-3), minibatch=mb, options={"fuse_boundary": f, "train_bf16": train_bf16}) for f in (1, 0)}
+    assert all(i.get_option("layered") == 1 for i in isos.values())
+    rng = np.random.default_rng(0)
+    for ep in range(3):
+        tgt = np.asarray(rng.uniform(size=(widths[-1], N)), np.float32)
+        perm = rng.permutation(N)
+        l1, l0 = (pkg.train_batch(isos[f], tgt, perm=perm) for f in (1, 0))
+        assert l1 == l0 and np.isfinite(l1), (ep, l1, l0)
+        np.testing.assert_array_equal(pkg.chis(isos[1]), pkg.chis(isos[0]))          # (a forward between epochs: the images it needs are rebuilt)
+    np.testing.assert_array_equal(isos[1].model.get_params(), isos[0].model.get_params())
+    m1, v1, _ = isos[1].get_opt_state()
+    m0, v0, _ = isos[0].get_opt_state()
+    np.testing.assert_array_equal(m1, m0)
+    np.testing.assert_array_equal(v1, v0)
+    before = isos[1].model.get_params()
+    for f in (1, 0):
+        with pytest.raises(pkg.DomainError) as ei:
+            pkg.train_batch(isos[f], np.full((widths[-1], N), np.nan, np.float32), perm=np.arange(N))
+        assert ei.value.status == pkg.capi.ECOLLAPSED
+        np.testing.assert_array_equal(isos[f].model.get_params(), before)
+    # ... and the engine trains on afterwards (the images were left valid)
+    tgt = np.asarray(rng.uniform(size=(widths[-1], N)), np.float32)
+    perm = rng.permutation(N)
+    l1, l0 = (pkg.train_batch(isos[f], tgt, perm=perm) for f in (1, 0))
+    assert l1 == l0
+    for iso in isos.values():
+        iso.close()
