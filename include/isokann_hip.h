@@ -147,6 +147,9 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *   fuse_opt_rows       768      ... for batches of up to this many rows (at most 1024; beyond 768 rows the gradient kernel by default splits
  *                                the batch rows over two workgroups per feature tile and a separate optimizer launch sums the two slabs:
  *                                faster at C3's 1000-row batches than one fused slab)
+ *   fuse_head           1        wide networks with at least three layers and at most four outputs, training GEMMs: the last layer's forward,
+ *                                the loss, delta_L and delta_{L-1} are ONE launch (three before); its per-workgroup partial sums of
+ *                                dW_L / db_L / the loss are added up by the next launch
  *   fuse_boundary       1        wide networks without a leading LayerNorm, training GEMMs: the optimizer step, the next step's weight images
  *                                and the next step's batch images are ONE launch at the boundary between two optimizer steps
  *   epoch_gather        0        wide networks, training GEMMs: 1 = the batch images (row gather, transposed copy) of every batch of an epoch are

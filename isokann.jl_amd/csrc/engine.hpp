@@ -131,6 +131,8 @@ struct isk_engine {
         void* Wt[ISK_MAX_LAYERS] = {nullptr};         // W_l' image     [N_l][pad32(K_l)]      (training GEMMs)
         void* Wf[ISK_MAX_LAYERS] = {nullptr};         // the same numbers, fragment-linear [pad32(K_l) / 32][32][64][8] (fused wide forward; hidden layers <= 512 wide)
         float* G0 = nullptr;                          // LayerNorm: raw layer-0 gradient [F + 1][N_0] (row F = D)
+        float* head_part = nullptr;                   // head kernel: per-workgroup partials [ISK_HEAD_MAXG][head_stride] of dW_L | db_L | loss
+        long long head_stride = 0;
         bool wt_dirty = true, wf_dirty = true;
         // the batch images of a whole epoch, gathered in ONE launch in front of its steps (layered_epoch_gather)
         void *xb_all = nullptr, *xt_all = nullptr;    // [nb][Bp][Fp], [nb][F + 1][Bp]

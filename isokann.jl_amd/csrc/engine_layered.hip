@@ -222,8 +222,8 @@ bool mfma32_train_active(const isk_engine* e) { return e->layered && !e->opt.tra
 // the per-batch images (the weight images belong to the engine, not to the data)
 void bf16_train_release(isk_engine* e) {
     auto& b = e->b16;
-    free_dev(b.xb); free_dev(b.xt); free_dev(b.G0);
-    b.xb = b.xt = nullptr; b.G0 = nullptr;
+    free_dev(b.xb); free_dev(b.xt); free_dev(b.G0); free_dev(b.head_part);
+    b.xb = b.xt = nullptr; b.G0 = nullptr; b.head_part = nullptr; b.head_stride = 0;
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) {
         free_dev(b.a16[l]); free_dev(b.at16[l]); free_dev(b.d16[l]); free_dev(b.dt16[l]);
         b.a16[l] = b.at16[l] = b.d16[l] = b.dt16[l] = nullptr;
@@ -305,6 +305,10 @@ static bool bf16_train_ensure(isk_engine* e, long long Bp, int esz) {
         if (ok && esz == 4) hipLaunchKernelGGL(fill_f32_kernel, dim3(64), dim3(256), 0, e->stream, (float*)b.at16[l] + (size_t)N * rows, rows, 1.0f);
     }
     if (ok && e->cfg.layernorm) alloc((void**)&b.G0, (size_t)(e->F + 1) * e->cfg.widths[1] * sizeof(float));
+    if (ok && L >= 2) {
+        b.head_stride = ((long long)e->cfg.widths[L - 1] * e->nout + e->nout + 1 + 3) & ~3ll;
+        alloc((void**)&b.head_part, (size_t)ISK_HEAD_MAXG * b.head_stride * sizeof(float));
+    }
     if (!ok) { bf16_train_release(e); return false; }
     b.rows = rows; b.esz = esz;
     return true;
@@ -397,7 +401,10 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
         }
     }
     bool ok = true;
-    for (int l = 0; l < L && ok; ++l) {
+    // the head of the backward pass as one launch (kernels_gemm16.hip head_kernel) where the network has >= 3 layers and <= 4 outputs
+    const int Kh = e->cfg.widths[L - 1];
+    const bool head = e->opt.fuse_head && L >= 3 && b.head_part && isk_head_ok(Kh, e->nout, B, Bp, isk_pad32(Kh), isk_pad16(Kh));
+    for (int l = 0; l < (head ? L - 1 : L) && ok; ++l) {
         const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];
         Gemm16Args g = {};
         g.A = l == 0 ? xb : b.a16[l - 1]; g.lda = l == 0 ? e->Fp : isk_pad32(K); g.a_f32 = f32math;
@@ -413,9 +420,19 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
     if (!ok) return false;
     // (the last layer + loss + both deltas as ONE "head" kernel was built and measured: 59 us against the 45 us of the four launches
     // it replaced -- eight rows per wave are eight dependent round trips; not kept)
-    isk_launch_loss_delta16(e->d_lz[L - 1], isk_pad16(e->nout), e->d_target, e->d_lossw, d_idx, B, Bp, e->nout, inv_div, e->cfg.lastactivation,
-                            b.d16[L - 1], isk_pad32(e->nout), b.dt16[L - 1], ldB, f32math, e->d_grad + e->nparams, e->d_rank_err, st);
-    for (int l = L - 1; l >= 0 && ok; --l) {
+    Gemm16Head hj = {};
+    if (head) {
+        isk_launch_head(b.a16[L - 2], isk_pad32(Kh), f32math, e->d_lz[L - 2], isk_pad16(Kh), act_of_layer(e, L - 2), e->d_theta + e->off_W[L - 1],
+                        e->d_theta + e->off_b[L - 1], Kh, e->nout, e->d_target, e->d_lossw, d_idx, B, Bp, inv_div, e->cfg.lastactivation,
+                        b.d16[L - 2], isk_pad32(Kh), b.dt16[L - 2], ldB, f32math, b.head_part, b.head_stride, st);
+        hj.part = b.head_part; hj.stride = b.head_stride; hj.G = Bp / ISK_HEAD_ROWS; hj.len = (long long)Kh * e->nout + e->nout;
+        hj.out = e->d_grad + e->off_W[L - 1];                            // W_L then b_L: Flux keeps the bias right behind the weights
+        hj.loss = e->d_grad + e->nparams; hj.rank_err = e->d_rank_err;
+    } else {
+        isk_launch_loss_delta16(e->d_lz[L - 1], isk_pad16(e->nout), e->d_target, e->d_lossw, d_idx, B, Bp, e->nout, inv_div, e->cfg.lastactivation,
+                                b.d16[L - 1], isk_pad32(e->nout), b.dt16[L - 1], ldB, f32math, e->d_grad + e->nparams, e->d_rank_err, st);
+    }
+    for (int l = head ? L - 2 : L - 1; l >= 0 && ok; --l) {
         const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1];
         const bool ln0 = l == 0 && ln;
         Gemm16Args pair[3] = {};
@@ -437,7 +454,7 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
             x.o16 = b.d16[l - 1]; x.ld16 = isk_pad32(K); x.M16 = Bp; x.ot16 = b.dt16[l - 1]; x.ldt = (int)ldB;
         }
         // dW_l + db_l and delta_{l-1} both need only delta_l: one launch
-        ok = isk_launch_gemm16_group(pair, np, st) == 0;
+        ok = isk_launch_gemm16_group(pair, np, st, head && l == L - 2 ? &hj : nullptr) == 0;
         // every gradient block of the layers >= 1 is now enqueued (Flux order: they are one contiguous range behind layer 0's):
         // the data-parallel driver sends them on their way while the first layer's products run
         if (ok && l == 1 && e->grad_hook) e->grad_hook(e);

@@ -34,6 +34,7 @@ const OptDesc kOptions[] = {
     {"g16_waves", &IskOptions::g16_waves, 0, 8},
     {"epoch_gather", &IskOptions::epoch_gather, 0, 1},
     {"fuse_boundary", &IskOptions::fuse_boundary, 0, 1},
+    {"fuse_head", &IskOptions::fuse_head, 0, 1},
     {"fuse_opt_rows", &IskOptions::fuse_opt_rows, 0, 1024},
     {"train_persist", &IskOptions::train_persist, 0, 1},
     {"wide_fused", &IskOptions::wide_fused, 0, 1},

@@ -45,6 +45,7 @@ struct IskOptions {
     int fuse_opt_rows = 768;      // ... for batches of up to this many rows (<= 1024).  Beyond 768 the gradient kernel splits the rows over two
                                   // workgroups per feature tile and opt_step sums the two slabs; keeping C3's 1000-row batches on one slab
                                   // to fuse the step was measured SLOWER (1.177 against 1.129 ms per iteration: twice the MFMA chain per wave)
+    int fuse_head = 1;            // layered training GEMMs, >= 3 layers, nout <= 4: last layer forward + loss + both deltas as ONE launch
     int fuse_boundary = 1;        // layered training GEMMs, no leading LayerNorm: opt_step + the next step's weight and batch images as ONE launch
     int epoch_gather = 0;         // layered training GEMMs: the batch images of a whole epoch are gathered in one launch in front of its steps.
                                   // Bit-identical, and no faster (C5 shard 2.99 against 2.95 ms: the step keeps a launch for the weight images)
@@ -234,13 +235,27 @@ struct Gemm16Args {
 };
 int  isk_launch_gemm16(const Gemm16Args& a, hipStream_t st);
 #define ISK_G16_MAXGROUP 3
+#define ISK_HEAD_ROWS 8                          /* rows per workgroup of the head kernel */
+#define ISK_HEAD_MAXG 256                        /* workgroups of the head kernel whose partials the next launch sums (8 rows each) */
+struct Gemm16Head {                              // side job of a grouped launch: sum the head kernel's per-workgroup partials
+    const float* part; long long stride; int G;  // [G][stride]
+    long long len;                               // out[0 .. len) = sums of elements 0 .. len-1 (dW_L | db_L); element len is the batch loss
+    float* out; float* loss; const int* rank_err;   // loss[0] = batch loss, loss[1] = this rank's error flag (as loss_delta16 leaves them)
+};
 struct Gemm16Group {                             // several independent products as ONE launch (kernels_gemm16.hip)
     Gemm16Args g[ISK_G16_MAXGROUP];
     int n, gx[ISK_G16_MAXGROUP], first[ISK_G16_MAXGROUP];
     int slow[ISK_G16_MAXGROUP];                  // member takes the elementwise operand path (ragged / unaligned shapes)
     int f32[ISK_G16_MAXGROUP];                   // member runs in Float32 arithmetic
+    const float* head_part; long long head_stride; int head_G; long long head_len; float* head_out; float* head_loss; const int* head_rank_err;
 };
-int  isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st);
+int  isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st, const Gemm16Head* head = nullptr);
+// the head of the backward pass as one launch (kernels_gemm16.hip head_kernel): last layer forward + loss + delta_L + delta_{L-1}
+// images + per-workgroup partials of dW_L | db_L | loss (summed by the next grouped launch through Gemm16Head)
+bool isk_head_ok(int K, int N, int B, int Bp, int lda, int ldzp);
+void isk_launch_head(const void* a, int lda, int a_f32, const float* zprev, int ldzp, int act, const float* W, const float* bias, int K, int N,
+                     const float* target, const float* lossw, const int* perm, int B, int Bp, float inv_div, int lastact, void* d16, int ld16,
+                     void* dt16, long long ldt, int img_f32, float* part, long long pstride, hipStream_t st);
 // gathered batch rows -> xb [Bp][Kp] bf16 and xt [K + 1][ldt] bf16 (row K = ones; columns [B, Bp) zeros)
 // img_f32: the images are FLOAT arrays (Float32 arithmetic of the training GEMMs) instead of bf16
 void isk_launch_gather_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,

@@ -311,6 +311,22 @@ template <bool F32, int NW>
 __global__ __launch_bounds__(NW * 64, G16_WAVES_PER_EU(F32)) void gemm16_group_kernel(Gemm16Group g) {
     __shared__ float red[4][G16_TM][G16_LDR];
     ISK_LATENCY_CHAIN_PRIO();
+    if (g.head_part) {
+        // the head kernel's per-workgroup partials (dW_L | db_L | loss) summed by this launch's first blocks: sixteen lanes per
+        // element, each takes every sixteenth workgroup's partial (independent loads, all in flight), then a fixed shuffle tree --
+        // one thread per element walking the G partials one after the other took 26 us
+        const long long e = ((long long)blockIdx.x * (NW * 64) + threadIdx.x) >> 4;
+        const int l16 = threadIdx.x & 15;
+        if (e <= g.head_len) {                                       // (uniform per 16-lane group)
+            float s = 0.f;
+            for (int w = l16; w < g.head_G; w += 16) s += g.head_part[(long long)w * g.head_stride + e];
+            s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+            if (l16 == 0) {
+                if (e < g.head_len) g.head_out[e] = s;
+                else { g.head_loss[0] = s; g.head_loss[1] = g.head_rank_err ? (float)*g.head_rank_err : 0.f; }
+            }
+        }
+    }
     int p = 0, b = blockIdx.x;
     while (p + 1 < g.n && b >= g.first[p + 1]) ++p;
     b -= g.first[p];
@@ -358,10 +374,16 @@ int isk_launch_gemm16(const Gemm16Args& a, hipStream_t st) {
     return hipLaunchKernel(fn, dim3(gx, gy), dim3(nw * 64), args, 0, st) == hipSuccess ? 0 : ISK_EHIP;
 }
 
-int isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st) {
+int isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st, const Gemm16Head* head) {
     if (n < 1 || n > ISK_G16_MAXGROUP) return ISK_EINVAL;
+    if (head && n < 2) return ISK_EINVAL;                              // (the side job rides on the grouped kernel)
     Gemm16Group g;
     g.n = n;
+    g.head_part = nullptr;
+    if (head) {
+        g.head_part = head->part; g.head_stride = head->stride; g.head_G = head->G; g.head_len = head->len; g.head_out = head->out;
+        g.head_loss = head->loss; g.head_rank_err = head->rank_err;
+    }
     int total = 0, nw = 4;
     for (int p = 0; p < n; ++p) {
         int gx, gy; bool slow;
@@ -372,6 +394,7 @@ int isk_launch_gemm16_group(const Gemm16Args* list, int n, hipStream_t st) {
         if (g16_waves(list[p]) == 8) nw = 8;
     }
     if (n == 1) return isk_launch_gemm16(list[0], st);
+    if (head && (long long)total * (nw * 64) <= 16 * (head->len + 1)) return ISK_EINVAL;   // (cannot happen: a product has far more threads than the last layer has weights)
     void* args[] = {(void*)&g};
     const void* fn = list[0].f32math ? (nw == 8 ? (const void*)gemm16_group_kernel<true, 8> : (const void*)gemm16_group_kernel<true, 4>)
                                      : (nw == 8 ? (const void*)gemm16_group_kernel<false, 8> : (const void*)gemm16_group_kernel<false, 4>);
@@ -635,6 +658,223 @@ void isk_launch_prep_images(const float* X, int ldx, const int* perm, int B, int
     int total = 0;
     for (int l = 0; l < w.nlayers; ++l) { w.first_block[l] = total; total += ((w.Kp[l] + 31) / 32) * ((w.N[l] + 31) / 32); }
     hipLaunchKernelGGL(prep_images_kernel, dim3(nb + total), dim3(256), 0, st, g, w, nb);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The head of the backward pass as ONE launch: last layer forward (nout <= 4 dot products per row), loss, delta_L, delta_{L-1}
+// (row-major and transposed images) and the per-workgroup partial sums of dW_L / db_L / the loss.  It replaces three launches of
+// ~0 flops each (the ragged last-layer product on the elementwise operand path, loss_delta16, the grouped dW_L / dX_L pair: 19 us
+// alone, 34 beside the featurizer at C5) -- round 3's first "head" kernel lost to them because a wave walked its eight rows one
+// dependent round trip after the other (and a second attempt with 32 rows per workgroup lost too: 32 workgroups of lone waves,
+// ~2500 instructions each); here a workgroup takes EIGHT rows (two per wave), every operand requested before its first use.  Everything is Float32 on the f32 master weights and the stored activations: at least as accurate as the bf16 products it
+// replaces.  The partial sums are added up, in workgroup order, by the first blocks of the NEXT launch (Gemm16Group.head_*): no
+// atomics, no seam, deterministic.
+struct HeadArgs {
+    const void* a; int lda, a_f32;                 // activations of the last hidden layer: image [Bp][lda] (bf16 | f32)
+    const float* zprev; int ldzp, act;            // its pre-activations [B][ldzp] and activation
+    const float* W; const float* bias; int K, N;  // last layer: Flux layout W[o + k N], bias [N]
+    const float* target; const float* lossw; const int* perm; int B; float inv_div; int lastact;
+    void* d16; int ld16; void* dt16; long long ldt; int img_f32;      // delta_{L-1}: [Bp][ld16] and transposed [K][ldt]
+    float* part; long long pstride;               // [gridDim.x][pstride]: dW_L (K N, Flux order) | db_L (N) | loss (1)
+};
+#define HEAD_RW 2                                  /* rows per wave */
+#define HEAD_ROWS (4 * HEAD_RW)                    /* rows per workgroup: many small workgroups -- a lone wave costs its instruction count */
+static_assert(HEAD_ROWS == ISK_HEAD_ROWS, "isk_internal.h: ISK_HEAD_ROWS");
+#define HEAD_MAXN 4
+#define HEAD_MAXK 1024
+__global__ __launch_bounds__(256) void head_kernel(HeadArgs h) {
+    __shared__ float sW[HEAD_MAXK * HEAD_MAXN];
+    __shared__ __attribute__((aligned(16))) float sBuf[4 * 512 * HEAD_MAXN];   // per-wave dW partials of a 512-wide chunk, then the chunk's delta tile [512][HEAD_ROWS]
+    __shared__ float sS[4][HEAD_MAXN + 1];                           // per-wave db and loss
+    ISK_LATENCY_CHAIN_PRIO();
+    constexpr int RW = HEAD_RW;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int K = h.K, N = h.N;
+    const int w0 = blockIdx.x * HEAD_ROWS;                           // the workgroup's first row
+    const int i0 = w0 + RW * wave;                                   // this wave's first row
+    const int nchunk = (K + 511) >> 9;
+    for (int i = tid; i < K * N; i += 256) sW[i] = h.W[i];
+    auto load_a = [&](int j, int c, float (&v)[8]) {
+        const int r = i0 + j;
+        const int k = (c << 9) + 8 * lane;
+        const long long off = (long long)r * h.lda + k;                // rows < Bp exist in the image (zeros beyond B)
+        const bool in = k < h.lda;
+        if (h.a_f32) {
+            const f32x4* p = (const f32x4*)((const float*)h.a + (in ? off : 0));
+            const f32x4 lo = p[0], hi = p[1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = in ? lo[q] : 0.f; v[4 + q] = in ? hi[q] : 0.f; }
+        } else {
+            const bf16x8 x = *(const bf16x8*)((const __bf16*)h.a + (in ? off : 0));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = in ? (float)x[q] : 0.f;
+        }
+    };
+    // the rows' sample indices and targets: requested with the first operands
+    long long prow[RW];
+    bool rv[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+        const int r = i0 + j;
+        rv[j] = r < h.B;
+        prow[j] = h.perm ? h.perm[rv[j] ? r : h.B - 1] : (rv[j] ? r : h.B - 1);
+    }
+    // ---- phase 1: z_L[r][o] = sum_k a[r][k] W[k][o]
+    float acc[RW][HEAD_MAXN];
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+        for (int o = 0; o < HEAD_MAXN; ++o) acc[j][o] = 0.f;
+    __syncthreads();                                                 // sW
+    for (int c = 0; c < nchunk; ++c) {
+        float av[RW][8];
+#pragma unroll
+        for (int j = 0; j < RW; ++j) load_a(j, c, av[j]);
+        const int k0 = (c << 9) + 8 * lane;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + q;
+#pragma unroll
+            for (int o = 0; o < HEAD_MAXN; ++o) {
+                const float w = (o < N && k < K) ? sW[k * N + o] : 0.f;
+#pragma unroll
+                for (int j = 0; j < RW; ++j) acc[j][o] = fmaf(av[j][q], w, acc[j][o]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+        for (int o = 0; o < HEAD_MAXN; ++o) {
+            float v = acc[j][o];
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) v += __shfl_xor(v, sh, 64);
+            acc[j][o] = v;                                           // every lane: the row's dot product
+        }
+    // ---- phase 2: loss and delta_L (uniform per row)
+    float dL[RW][HEAD_MAXN];
+    float lsum = 0.f, dbs[HEAD_MAXN];
+#pragma unroll
+    for (int o = 0; o < HEAD_MAXN; ++o) dbs[o] = 0.f;
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+#pragma unroll
+        for (int o = 0; o < HEAD_MAXN; ++o) {
+            float d = 0.f;
+            if (o < N && rv[j]) {
+                const float zz = acc[j][o] + h.bias[o];
+                const float w = h.lossw[o];
+                const float res = (g_act(h.lastact, zz) - h.target[prow[j] * N + o]) * w;
+                lsum += res * res;
+                d = 2.f * res * w * h.inv_div * g_dact(h.lastact, zz);
+            }
+            dL[j][o] = d;
+            dbs[o] += d;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int o = 0; o < HEAD_MAXN; ++o) sS[wave][o] = dbs[o];
+        sS[wave][HEAD_MAXN] = lsum;
+    }
+    // ---- phase 3: per chunk -- dW_L partials (this wave's rows), delta_{L-1} images
+    float* const part = h.part + (long long)blockIdx.x * h.pstride;
+    float* const sG = sBuf + wave * (512 * HEAD_MAXN);
+    for (int c = 0; c < nchunk; ++c) {
+        const int k0 = (c << 9) + 8 * lane;
+        float av[RW][8];
+        f32x4 zp[RW][2];
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            load_a(j, c, av[j]);
+            const int r = i0 + j;
+            const int rc = r < h.B ? r : h.B - 1;
+            const int kc = k0 + 8 <= h.ldzp ? k0 : 0;                  // (columns beyond the padded width: a dummy, masked below)
+            const f32x4* p = (const f32x4*)(h.zprev + (long long)rc * h.ldzp + kc);
+            zp[j][0] = p[0]; zp[j][1] = p[1];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int o = 0; o < HEAD_MAXN; ++o) {
+                float g = 0.f;
+#pragma unroll
+                for (int j = 0; j < RW; ++j) g = fmaf(av[j][q], dL[j][o], g);
+                sG[(8 * lane + q) * HEAD_MAXN + o] = g;
+            }
+        // delta_{L-1}[r][k] = (sum_o delta_L[r][o] W[k][o]) act'(z_{L-1}[r][k])
+        float dx[RW][8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + q;
+            float wq[HEAD_MAXN];
+#pragma unroll
+            for (int o = 0; o < HEAD_MAXN; ++o) wq[o] = (o < N && k < K) ? sW[k * N + o] : 0.f;
+#pragma unroll
+            for (int j = 0; j < RW; ++j) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int o = 0; o < HEAD_MAXN; ++o) sacc = fmaf(dL[j][o], wq[o], sacc);
+                dx[j][q] = k < K ? sacc * g_dact(h.act, zp[j][q >> 2][q & 3]) : 0.f;
+            }
+        }
+        if (k0 < h.ld16) {                                           // row-major image: 8 contiguous k per lane and row
+#pragma unroll
+            for (int j = 0; j < RW; ++j) {
+                const long long o16 = (long long)(i0 + j) * h.ld16 + k0;
+                if (h.img_f32) {
+                    f32x4* p = (f32x4*)((float*)h.d16 + o16);
+                    p[0] = (f32x4){dx[j][0], dx[j][1], dx[j][2], dx[j][3]}; p[1] = (f32x4){dx[j][4], dx[j][5], dx[j][6], dx[j][7]};
+                } else {
+                    bf16x8 v;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = (__bf16)dx[j][q];
+                    *(bf16x8*)((__bf16*)h.d16 + o16) = v;
+                }
+            }
+        }
+        __syncthreads();                                             // the four waves' sG
+        for (int i = tid; i < 512 * N; i += 256) {                   // element (kk, o) of the chunk, Flux order (k N + o)
+            const int kk = i / N, o = i - kk * N, k = (c << 9) + kk;
+            const int e = kk * HEAD_MAXN + o;
+            if (k < K) part[(long long)k * N + o] = (sBuf[e] + sBuf[512 * HEAD_MAXN + e]) + (sBuf[2 * 512 * HEAD_MAXN + e] + sBuf[3 * 512 * HEAD_MAXN + e]);
+        }
+        __syncthreads();                                             // sBuf becomes the delta tile [512][HEAD_ROWS]
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int j = 0; j < RW; ++j) sBuf[(8 * lane + q) * HEAD_ROWS + RW * wave + j] = dx[j][q];
+        __syncthreads();
+        for (int kk = tid; kk < 512; kk += 256) {                    // transposed image: HEAD_ROWS = 8 contiguous rows per k
+            const int k = (c << 9) + kk;
+            if (k < K) {
+                const f32x4 lo = *(const f32x4*)(sBuf + kk * HEAD_ROWS), hi = *(const f32x4*)(sBuf + kk * HEAD_ROWS + 4);
+                const long long ot = (long long)k * h.ldt + w0;
+                if (h.img_f32) { f32x4* p = (f32x4*)((float*)h.dt16 + ot); p[0] = lo; p[1] = hi; }
+                else {
+                    bf16x8 v;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { v[t] = (__bf16)lo[t]; v[4 + t] = (__bf16)hi[t]; }
+                    *(bf16x8*)((__bf16*)h.dt16 + ot) = v;
+                }
+            }
+        }
+        __syncthreads();                                             // before the next chunk overwrites sBuf
+    }
+    if (tid <= N) {                                                  // db_L (N) and the loss partial
+        const int o = tid < N ? tid : HEAD_MAXN;
+        part[(long long)K * N + tid] = (sS[0][o] + sS[1][o]) + (sS[2][o] + sS[3][o]);
+    }
+}
+bool isk_head_ok(int K, int N, int B, int Bp, int lda, int ldzp) {
+    return N >= 1 && N <= HEAD_MAXN && K >= 1 && K <= HEAD_MAXK && lda % 8 == 0 && lda >= K && ldzp % 8 == 0 && ldzp >= K && Bp % HEAD_ROWS == 0 && B >= 1 &&
+           Bp / HEAD_ROWS <= ISK_HEAD_MAXG;
+}
+void isk_launch_head(const void* a, int lda, int a_f32, const float* zprev, int ldzp, int act, const float* W, const float* bias, int K, int N,
+                     const float* target, const float* lossw, const int* perm, int B, int Bp, float inv_div, int lastact, void* d16, int ld16,
+                     void* dt16, long long ldt, int img_f32, float* part, long long pstride, hipStream_t st) {
+    HeadArgs h = {a, lda, a_f32, zprev, ldzp, act, W, bias, K, N, target, lossw, perm, B, inv_div, lastact, d16, ld16, dt16, ldt, img_f32, part, pstride};
+    hipLaunchKernelGGL(head_kernel, dim3(Bp / HEAD_ROWS), dim3(256), 0, st, h);   // (Bp is a multiple of 32)
 }
 
 // delta_L and the batch loss from the last layer's pre-activations (as loss_delta_kernel of kernels_layered.hip), plus the

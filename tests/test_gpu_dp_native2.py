@@ -143,7 +143,13 @@ def _two_ranks_vs_single_process(gpu_pkg, mock_lib, nout, minibatch, epochs, eve
         assert ref.get_option("layered") == 1 and ref.get_option("wide_fwd") == 1
         assert ref.get_option("train_bf16") == int(os.environ.get("ISK_TRAIN_BF16", "1"))
     pkg.run(ref, niter, epochs, perms=np.stack(gperms))
-    np.testing.assert_allclose(r[0]["losses"], ref.losses, rtol=2e-4)
+    # bf16 training GEMMs: the images of activations and deltas are ROUNDED to bf16, so float32-rounding differences between the two
+    # runs (order of the gradient sums: per rank then all-reduce against one 32-row sum) flip a rounding now and then and grow over
+    # the six epochs.  Measured on this very problem: a 1e-7 relative perturbation of the initial parameters moves the fifth and
+    # sixth loss by 1.7 - 2 % (with or without the head kernel); Float32 arithmetic stays at 1e-6.  Hence the bf16 loss tolerance
+    # of the other bf16 tests (5e-2); the first four losses agree to six digits
+    wide_bf16 = bool(os.environ.get("ISK_TEST_WIDE")) and os.environ.get("ISK_TRAIN_BF16", "1") == "1"
+    np.testing.assert_allclose(r[0]["losses"], ref.losses, rtol=5e-2 if wide_bf16 else 2e-4)
     want = ref.model.get_params()
     ref.close()
     assert_params_match(pkg, r[0]["params"], want, opt, mk, gperms[0][:gb if minibatch else N], LR, niter * epochs * nb)

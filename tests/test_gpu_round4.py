@@ -266,3 +266,42 @@ def test_wide_network_step_boundary_as_one_launch(gpu_pkg, train_bf16, opt):
     assert l1 == l0
     for iso in isos.values():
         iso.close()
+
+
+@pytest.mark.parametrize("widths,N,mb", [([64, 200, 48, 2], 330, 64), ([96, 256, 136, 1], 300, 100), ([64, 180, 64, 40, 3], 200, 0)])
+def test_wide_network_backward_head_as_one_launch(gpu_pkg, widths, N, mb):
+    """wide networks with >= 3 layers and <= 4 outputs, option fuse_head: the last layer's forward, the loss, delta_L and delta_{L-1}
+    are ONE launch (head_kernel) and the next launch sums its per-workgroup partials of dW_L / db_L / the loss.  Float32 on the
+    master weights, another summation order than the three launches it replaces: gradients, losses and trained parameters must agree
+    with them to float32 rounding (Float32 arithmetic) and with the oracle as before; in bf16 arithmetic the head is the more exact
+    of the two (no bf16 rounding of delta_L and of the last layer's weights), so both are held to the oracle at the bf16 tolerance."""
+    pkg = gpu_pkg
+    A = 24
+    xs, ys = O.synthetic_coords(A, N, 2, seed=41)
+    pairs = O.random_pairs(A, widths[0], seed=42)
+    nout = widths[-1]
+    rng = np.random.default_rng(0)
+    tgt = np.asarray(rng.uniform(size=(nout, N)), np.float32)
+    for train_bf16 in (0, 1):
+        om, _ = _model(pkg, widths, seed=43, ln=False)
+        st = O.setup(O.OptRule("adam", 1e-2, 1e-3), om)
+        odata = O.SimulationData(np.asarray(xs, np.float64), np.asarray(ys, np.float64), O.FeaturesPairs(pairs))
+        isos = {h: pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_model(pkg, widths, seed=43, ln=False)[1],
+                           opt=pkg.OptSpec("adam", 1e-2, 1e-3), minibatch=mb, options={"fuse_head": h, "train_bf16": train_bf16}) for h in (1, 0)}
+        assert all(i.get_option("layered") == 1 for i in isos.values())
+        idx = rng.permutation(N)[:min(N, 100)]
+        g1, gl1 = pkg.batch_grads(isos[1], tgt, idx)
+        g0, gl0 = pkg.batch_grads(isos[0], tgt, idx)
+        scale = np.max(np.abs(g0))
+        tol = 2e-2 if train_bf16 else 2e-6
+        assert abs(gl1 - gl0) <= (1e-2 if train_bf16 else 1e-6) * abs(gl0), (gl1, gl0)
+        np.testing.assert_allclose(g1, g0, atol=tol * scale, rtol=0)
+        for ep in range(2):
+            perm = rng.permutation(N)
+            lo = O.train_batch(om, odata.features[0], tgt.astype(np.float64), st, mb, perm=perm)
+            l1, l0 = (pkg.train_batch(isos[h], tgt, perm=perm) for h in (1, 0))
+            assert abs(l1 - lo) <= (5e-2 if train_bf16 else 1e-4) * abs(lo) and abs(l0 - lo) <= (5e-2 if train_bf16 else 1e-4) * abs(lo), (ep, l1, l0, lo)
+        if not train_bf16:
+            np.testing.assert_allclose(isos[1].model.get_params(), om.get_flat(), atol=5e-5, rtol=5e-4)
+        for iso in isos.values():
+            iso.close()
