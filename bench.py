@@ -157,8 +157,11 @@ class SclkSampler:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: about a second of timed iterations.  Round 4 measured the step count itself on one box: 20 steps (23 ms) 1.146-1.156 ms
+    # per step, 200 steps 1.113-1.123, 1000 steps 1.096-1.102 -- a 23-ms window ends before the chip has settled on its clocks, and it
+    # is too short for anybody's wall clock to corroborate
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5shard"])
     ap.add_argument("--minibatch", type=int, default=1000, help="per-rank minibatch (scripts/villin.jl:37 uses 1000); 0 = full batch")
     ap.add_argument("--opt", default="adam", choices=["adam", "nesterov"])
