@@ -43,6 +43,28 @@ __device__ __forceinline__ void block_sum_multi(double (&v)[M], double* sh /* [M
     }
 }
 
+// sum of G partial vectors (length M, at P[g * M + i]) in workgroup order g = 0 .. G-1, result in out[i] (LDS), i < M.  The partials
+// are requested by ALL threads at once and staged in LDS: written as `for g: s += P[g * M + tid]` the loop was G dependent memory
+// round trips (each load waited for before the next was issued: ~1 us apiece beside the featurizer), now it is one.
+#define ISA_STAGE 2048             /* doubles of LDS staging (16 KB): G * M beyond that falls back to the plain loop */
+__device__ __forceinline__ void sum_partials(const double* __restrict__ P, int G, int M, double* stage, double* out) {
+    const int tot = G * M;
+    if (tot <= ISA_STAGE) {
+        for (int i = threadIdx.x; i < tot; i += blockDim.x) stage[i] = P[i];
+        __syncthreads();
+        if ((int)threadIdx.x < M) {
+            double s = 0;
+            for (int g = 0; g < G; ++g) s += stage[g * M + threadIdx.x];
+            out[threadIdx.x] = s;
+        }
+    } else if ((int)threadIdx.x < M) {
+        double s = 0;
+        for (int g = 0; g < G; ++g) s += P[(long long)g * M + threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
 // workgroup argmax of (value, first index); winner broadcast through shd[0] / shi[0]
 __device__ __forceinline__ void block_argmax(double bv, long long bi, double* shd, long long* shi) {
 #pragma unroll
@@ -74,11 +96,22 @@ __device__ __forceinline__ void finalize_argmax(const double* __restrict__ P, in
     constexpr int PREC = IsaLayout<D>::PREC;
     double bv = -1.0;
     long long bi = 0x7fffffffffffffffLL;
+    double brow[D];                                             // the row of this thread's best record: it travels with the record, so
+#pragma unroll                                                  // the winner's row needs no second (dependent) round trip
+    for (int k = 0; k < D; ++k) brow[k] = 0.0;
     for (int g = threadIdx.x; g < G; g += ISA_T) {
         const double v = P[(long long)g * PREC];
         const long long i = (long long)P[(long long)g * PREC + 1];
-        if (i >= 0 && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+        double row[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) row[k] = P[(long long)g * PREC + 2 + k];
+        if (i >= 0 && (v > bv || (v == bv && i < bi))) {
+            bv = v; bi = i;
+#pragma unroll
+            for (int k = 0; k < D; ++k) brow[k] = row[k];
+        }
     }
+    const long long mine = bi;
     block_argmax(bv, bi, shd, shi);
     const long long sel = shi[0];
     const bool none = !(sel >= 0 && sel < N);                  // workgroup-uniform
@@ -90,28 +123,35 @@ __device__ __forceinline__ void finalize_argmax(const double* __restrict__ P, in
             if (blockIdx.x == 0) atomicOr(status, 2);
         }
         if (threadIdx.x < D) vrow_sh[threadIdx.x] = 0.0;
-    } else {
-        const int g = (int)(sel / ISA_ROWS);                   // the workgroup that owned that row
-        if (threadIdx.x < D) vrow_sh[threadIdx.x] = P[(long long)g * PREC + 2 + threadIdx.x];
+    } else if (mine == sel) {                                   // exactly one thread: a row index names one record
+#pragma unroll
+        for (int k = 0; k < D; ++k) vrow_sh[k] = brow[k];
     }
     __syncthreads();
 }
 
-// write this workgroup's partial argmax record (value, index, row values)
+// write this workgroup's partial argmax record (value, index, row values).  brow: the values of this thread's own best row (the
+// winner writes its row from registers: re-reading it from X behind the barrier was one more dependent round trip per kernel)
 template <int D>
-__device__ __forceinline__ void write_partial_argmax(double bv, long long bi, const double* __restrict__ X, double* __restrict__ P,
+__device__ __forceinline__ void write_partial_argmax(double bv, long long bi, const double (&brow)[D], double* __restrict__ P,
                                                      double* shd, long long* shi) {
     constexpr int PREC = IsaLayout<D>::PREC;
+    const long long mine = bi;
     block_argmax(bv, bi, shd, shi);
     const long long sel = shi[0];
     const bool any = sel != 0x7fffffffffffffffLL;              // false: no row of this slab was a candidate (all NaN, or an empty slab)
     if (threadIdx.x == 0) {
         P[(long long)blockIdx.x * PREC] = shd[0];
         P[(long long)blockIdx.x * PREC + 1] = any ? (double)sel : -1.0;
+        if (!any) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) P[(long long)blockIdx.x * PREC + 2 + k] = 0.0;
+        }
     }
-    // the winning row belongs to this workgroup's slab and was written by this kernel: re-read after a barrier
-    __syncthreads();
-    if (threadIdx.x < D) P[(long long)blockIdx.x * PREC + 2 + threadIdx.x] = any ? X[sel * D + threadIdx.x] : 0.0;
+    if (any && mine == sel) {                                   // exactly one thread owns the winning row
+#pragma unroll
+        for (int k = 0; k < D; ++k) P[(long long)blockIdx.x * PREC + 2 + k] = brow[k];
+    }
 }
 
 // ---- k0: X = Float64(ks'), finiteness; norms -> partial argmax, or whitening moments -------------------
@@ -125,6 +165,9 @@ __global__ __launch_bounds__(ISA_T) void isa_init_kernel(IsaArgs a, double* __re
     double bv = -1.0;
     long long bi = 0x7fffffffffffffffLL;
     int nf = 0;
+    double brow[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) brow[k] = 0.0;
     double cm[D * D];
 #pragma unroll
     for (int i = 0; i < D * D; ++i) cm[i] = 0;
@@ -155,7 +198,11 @@ __global__ __launch_bounds__(ISA_T) void isa_init_kernel(IsaArgs a, double* __re
                     for (int j = 0; j < D; ++j) cm[i * D + j] += (double)kv[r][i] * (double)kv[r][j];
             }
             s = sqrt(s);
-            if (s > bv) { bv = s; bi = n; }
+            if (s > bv) {
+                bv = s; bi = n;
+#pragma unroll
+                for (int k = 0; k < D; ++k) brow[k] = (double)kv[r][k];
+            }
         }
     }
     if (nf) atomicOr(a.status, 2);
@@ -168,7 +215,7 @@ __global__ __launch_bounds__(ISA_T) void isa_init_kernel(IsaArgs a, double* __re
             Pm[(long long)blockIdx.x * D * D + threadIdx.x] = v;
         }
     } else {
-        write_partial_argmax<D>(bv, bi, X, P, shd, shi);
+        write_partial_argmax<D>(bv, bi, brow, P, shd, shi);
     }
 }
 
@@ -180,15 +227,13 @@ __global__ __launch_bounds__(ISA_T) void isa_whiten_kernel(IsaArgs a, const doub
     __shared__ double shd[ISA_MAXD * ISA_MAXD * (ISA_T / 64)];
     __shared__ long long shi[ISA_T / 64];
     __shared__ double Wm[D * D];
+    __shared__ double stage[ISA_STAGE];
     __shared__ int badw;
     const long long N = a.N;
     double* X = a.work;
     if (threadIdx.x == 0) badw = 0;
-    if (threadIdx.x < D * D) {
-        double s = 0;
-        for (int g = 0; g < G; ++g) s += Pm[(long long)g * D * D + threadIdx.x];
-        Wm[threadIdx.x] = s / (double)N;
-    }
+    sum_partials(Pm, G, D * D, stage, Wm);
+    if (threadIdx.x < D * D) Wm[threadIdx.x] = Wm[threadIdx.x] / (double)N;
     __syncthreads();
     if (threadIdx.x == 0) {
         double V[D * D], Aj[D * D];
@@ -235,6 +280,9 @@ __global__ __launch_bounds__(ISA_T) void isa_whiten_kernel(IsaArgs a, const doub
     for (int i = 0; i < D * D; ++i) Wl[i] = Wm[i];
     double bv = -1.0;
     long long bi = 0x7fffffffffffffffLL;
+    double brow[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) brow[k] = 0.0;
     const long long base = (long long)blockIdx.x * ISA_ROWS + threadIdx.x;
     double xv[ISA_R][D];
 #pragma unroll
@@ -248,19 +296,25 @@ __global__ __launch_bounds__(ISA_T) void isa_whiten_kernel(IsaArgs a, const doub
         const long long n = base + (long long)r * ISA_T;
         if (n < N) {
             double s = 0;
+            double yv[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 double y = 0;
 #pragma unroll
                 for (int k = 0; k < D; ++k) y += xv[r][k] * Wl[k * D + j];
                 X[n * D + j] = y;
+                yv[j] = y;
                 s += y * y;
             }
             s = sqrt(s);
-            if (s > bv) { bv = s; bi = n; }
+            if (s > bv) {
+                bv = s; bi = n;
+#pragma unroll
+                for (int k = 0; k < D; ++k) brow[k] = yv[k];
+            }
         }
     }
-    write_partial_argmax<D>(bv, bi, X, P, shd, shi);
+    write_partial_argmax<D>(bv, bi, brow, P, shd, shi);
 }
 
 // ---- indexmap step j (j = 0 .. d-2): finalize the argmax of step j, update the rows, partial argmax of j+1 ----
@@ -292,6 +346,9 @@ __global__ __launch_bounds__(ISA_T) void isa_step_kernel(IsaArgs a, int j, const
     for (int k = 0; k < D; ++k) vr[k] = vrow[k] * inv;
     double bv = -1.0;
     long long bi = 0x7fffffffffffffffLL;
+    double brow[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) brow[k] = 0.0;
     __syncthreads();          // every thread holds its (old) rows before any row of this slab is overwritten
 #pragma unroll
     for (int r = 0; r < ISA_R; ++r) {
@@ -311,10 +368,14 @@ __global__ __launch_bounds__(ISA_T) void isa_step_kernel(IsaArgs a, int j, const
 #pragma unroll
             for (int k = 0; k < D; ++k) { X[n * D + k] = xv[r][k]; s += xv[r][k] * xv[r][k]; }
             s = sqrt(s);
-            if (s > bv) { bv = s; bi = n; }
+            if (s > bv) {
+                bv = s; bi = n;
+#pragma unroll
+                for (int k = 0; k < D; ++k) brow[k] = xv[r][k];
+            }
         }
     }
-    write_partial_argmax<D>(bv, bi, X, Pout, shd, shi);
+    write_partial_argmax<D>(bv, bi, brow, Pout, shd, shi);
 }
 
 // ---- finalize the last index, A = inv(ks[ind, :]), T = A' ks, partial fixperm cost matrices ------------------
@@ -339,24 +400,32 @@ __global__ __launch_bounds__(ISA_T) void isa_target_kernel(IsaArgs a, const doub
 #pragma unroll
         for (int k = 0; k < D; ++k) { kv[r][k] = (n < N) ? a.ks[n * D + k] : 0.f; cv[r][k] = (n < N) ? a.chi[n * D + k] : 0.f; }
     }
-    finalize_argmax<D>(Pin, G, shd, shi, vrow, a.status, N);
+    // thread 0: the simplex rows of the earlier steps (indices written by the kernels before this one) are requested before this
+    // kernel's own argmax is finalized -- two dependent round trips that used to stand behind it
+    int idx[D];
+    float kvs[D * D];
+    int bad0 = 0;
     if (threadIdx.x == 0) {
-        bad = 0;
-        int idx[D];
 #pragma unroll
         for (int i = 0; i < D - 1; ++i) idx[i] = ind[i];
-        idx[D - 1] = (int)shi[0];
 #pragma unroll
-        for (int i = 0; i < D; ++i)
-            if (idx[i] < 0 || idx[i] >= N) { idx[i] = 0; bad = 1; }      // belt and braces: finalize_argmax keeps them in range
-        if (blockIdx.x == 0) ind[D - 1] = idx[D - 1];
-        // the d x d rows in ONE memory round trip (registers first): filled element by element, the pivoting matrix lives
-        // in scratch memory and every load waited for the one before it -- d*d dependent round trips on one thread
-        float kvs[D * D];
+        for (int i = 0; i < D - 1; ++i)
+            if (idx[i] < 0 || idx[i] >= N) { idx[i] = 0; bad0 = 1; }      // belt and braces: finalize_argmax keeps them in range
 #pragma unroll
-        for (int i = 0; i < D; ++i)
+        for (int i = 0; i < D - 1; ++i)
 #pragma unroll
             for (int j = 0; j < D; ++j) kvs[i * D + j] = a.ks[(long long)idx[i] * D + j];
+    }
+    finalize_argmax<D>(Pin, G, shd, shi, vrow, a.status, N);
+    if (threadIdx.x == 0) {
+        bad = bad0;
+        idx[D - 1] = (int)shi[0];
+        if (idx[D - 1] < 0 || idx[D - 1] >= N) { idx[D - 1] = 0; bad = 1; }
+        if (blockIdx.x == 0) ind[D - 1] = idx[D - 1];
+        // the last row in ONE more round trip (registers first): filled element by element, the pivoting matrix lives
+        // in scratch memory and every load waited for the one before it -- d*d dependent round trips on one thread
+#pragma unroll
+        for (int j = 0; j < D; ++j) kvs[(D - 1) * D + j] = a.ks[(long long)idx[D - 1] * D + j];
         __builtin_amdgcn_sched_barrier(0);
         // the pivoting matrix is indexed at run time: in LDS (one thread uses it), not in a private array -- that one
         // lives in scratch memory and every access of the elimination is a dependent memory round trip
@@ -440,6 +509,7 @@ __global__ __launch_bounds__(ISA_T) void isa_perm_kernel(IsaArgs a, const double
     ISK_LATENCY_CHAIN_PRIO();
     __shared__ double shd[ISA_MAXD * ISA_MAXD * (ISA_T / 64)];
     __shared__ double Cst[D * D];
+    __shared__ double stage[ISA_STAGE];
     __shared__ int rperm[D];
     __shared__ int psh[2 * D];
     const long long N = a.N;
@@ -455,12 +525,7 @@ __global__ __launch_bounds__(ISA_T) void isa_perm_kernel(IsaArgs a, const double
     }
     if (threadIdx.x < D) rperm[threadIdx.x] = threadIdx.x;
     if (a.permute) {
-        if (threadIdx.x < D * D) {
-            double s = 0;
-            for (int g = 0; g < G; ++g) s += Pc[(long long)g * D * D + threadIdx.x];
-            Cst[threadIdx.x] = s;
-        }
-        __syncthreads();
+        sum_partials(Pc, G, D * D, stage, Cst);
         if (threadIdx.x == 0) {
             int* p = psh;                           // run-time indexed: LDS, not scratch (see isa_target_kernel)
             int* best = psh + D;
@@ -522,10 +587,12 @@ __global__ __launch_bounds__(ISA_T) void isa_perm_kernel(IsaArgs a, const double
 template <int D>
 __global__ __launch_bounds__(64) void isa_weights_kernel(IsaArgs a, const double* __restrict__ Pmom, int G) {
     ISK_LATENCY_CHAIN_PRIO();
+    __shared__ double stage[ISA_STAGE];
+    __shared__ double mom[2 * D];
+    sum_partials(Pmom, G, 2 * D, stage, mom);
     const int i = threadIdx.x;
     if (i >= D) return;
-    double s1 = 0, s2 = 0;
-    for (int g = 0; g < G; ++g) { s1 += Pmom[(long long)g * 2 * D + i]; s2 += Pmom[(long long)g * 2 * D + D + i]; }
+    const double s1 = mom[i], s2 = mom[D + i];
     const double N = (double)a.N;
     a.lossw[i] = (float)(1.0 / sqrt((s2 - s1 * s1 / N) / (N - 1.0)));
 }
