@@ -32,6 +32,8 @@ ISK_FUSE_TAIL=1 b c3_mb100_nesterov_fusetail --minibatch 100 --opt nesterov --no
 ISK_FUSE_OPT_ROWS=1024 b c3_fuseopt_1024rows --no-cpu-baseline                             # C3's 1000-row batches on one slab with the fused step
 ISK_G16_WAVES=4 b c5shard_bf16_g16w4 --workload c5shard --forward-mode 2 --train-bf16 --no-cpu-baseline   # training GEMMs: four waves everywhere
 ISK_EPOCH_GATHER=1 b c5shard_bf16_epochgather --workload c5shard --forward-mode 2 --train-bf16 --no-cpu-baseline
+ISK_FUSE_HEAD=0 b c5shard_bf16_nohead --workload c5shard --forward-mode 2 --train-bf16 --no-cpu-baseline          # three launches instead of the head kernel
+ISK_FUSE_BOUNDARY=0 b c5shard_bf16_noboundary --workload c5shard --forward-mode 2 --train-bf16 --no-cpu-baseline  # opt_step + prep_images instead of the boundary launch
 ISK_TAIL_NARROW=0 b c3_generic_tail --no-cpu-baseline                                    # round 3's train_tail kernel, for the A/B on this box
 # one rank's share of the 8-way strong-scaled runs (C4: N = 1250, local batch 125; collectives on a one-rank communicator)
 b c4_shard_of_8 --shard-of 8 --no-cpu-baseline
