@@ -427,40 +427,100 @@ __global__ __launch_bounds__(ISA_T) void isa_target_kernel(IsaArgs a, const doub
 #pragma unroll
         for (int j = 0; j < D; ++j) kvs[(D - 1) * D + j] = a.ks[(long long)idx[D - 1] * D + j];
         __builtin_amdgcn_sched_barrier(0);
-        // the pivoting matrix is indexed at run time: in LDS (one thread uses it), not in a private array -- that one
-        // lives in scratch memory and every access of the elimination is a dependent memory round trip
-        double* M = Msh;
+        if constexpr (D <= 4) {
+            // d <= 4 (the usual ISOKANN dimensions): the augmented matrix in REGISTERS -- every loop unrolled, the pivot row picked and
+            // swapped with selects, so no element is indexed at run time.  In LDS (below) the elimination is ~100 dependent LDS
+            // accesses of one thread, ~5 us that every workgroup spends in front of its row work
+            double R[D][2 * D];
 #pragma unroll
-        for (int i = 0; i < D; ++i)
+            for (int i = 0; i < D; ++i)
 #pragma unroll
-            for (int j = 0; j < D; ++j) { M[i * 2 * D + j] = (double)kvs[i * D + j]; M[i * 2 * D + D + j] = (i == j) ? 1.0 : 0.0; }
-        // elimination with the multiplier taken against the UNSCALED pivot row (as LU does), so exactly
-        // dependent rows cancel to exact zeros and are reported singular like Julia's inv()
-        for (int c = 0; c < D && !bad; ++c) {
-            int p = c;
-            for (int r = c + 1; r < D; ++r)
-                if (fabs(M[r * 2 * D + c]) > fabs(M[p * 2 * D + c])) p = r;
-            const double pv = M[p * 2 * D + c];
-            if (!(fabs(pv) > 0.0) || !isfinite(pv)) { bad = 1; break; }
-            if (p != c)
-                for (int j = 0; j < 2 * D; ++j) { const double t = M[p * 2 * D + j]; M[p * 2 * D + j] = M[c * 2 * D + j]; M[c * 2 * D + j] = t; }
-            for (int r = 0; r < D; ++r) {
-                if (r == c) continue;
-                const double f = M[r * 2 * D + c] / pv;
-                if (f == 0.0) continue;
-                for (int j = 0; j < 2 * D; ++j) M[r * 2 * D + j] -= f * M[c * 2 * D + j];
-                M[r * 2 * D + c] = 0.0;
+                for (int jj = 0; jj < D; ++jj) { R[i][jj] = (double)kvs[i * D + jj]; R[i][D + jj] = (i == jj) ? 1.0 : 0.0; }
+            int badl = bad;
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                if (!badl) {
+                    int pr = c;
+                    double pa = fabs(R[c][c]), pv = R[c][c];
+#pragma unroll
+                    for (int r = c + 1; r < D; ++r) {
+                        const double av = fabs(R[r][c]);
+                        if (av > pa) { pa = av; pr = r; pv = R[r][c]; }
+                    }
+                    if (!(fabs(pv) > 0.0) || !isfinite(pv)) badl = 1;
+                    else {
+#pragma unroll
+                        for (int r = c + 1; r < D; ++r)
+                            if (pr == r) {
+#pragma unroll
+                                for (int jj = 0; jj < 2 * D; ++jj) { const double t = R[r][jj]; R[r][jj] = R[c][jj]; R[c][jj] = t; }
+                            }
+#pragma unroll
+                        for (int r = 0; r < D; ++r) {
+                            if (r == c) continue;
+                            const double f = R[r][c] / pv;
+                            if (f != 0.0) {
+#pragma unroll
+                                for (int jj = 0; jj < 2 * D; ++jj) R[r][jj] -= f * R[c][jj];
+                                R[r][c] = 0.0;
+                            }
+                        }
+                    }
+                }
             }
-        }
-        for (int c = 0; c < D && !bad; ++c) {
-            const double inv = 1.0 / M[c * 2 * D + c];
-            for (int j = 0; j < 2 * D; ++j) M[c * 2 * D + j] *= inv;
-        }
-        for (int i = 0; i < D; ++i)
-            for (int j = 0; j < D; ++j) {
-                Am[i * D + j] = bad ? 0.0 : M[i * 2 * D + D + j];
-                if (!isfinite(Am[i * D + j])) bad = 1;
+            if (!badl) {
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    const double inv = 1.0 / R[c][c];
+#pragma unroll
+                    for (int jj = 0; jj < 2 * D; ++jj) R[c][jj] *= inv;
+                }
             }
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int jj = 0; jj < D; ++jj) {
+                    const double v = badl ? 0.0 : R[i][D + jj];
+                    Am[i * D + jj] = v;
+                    if (!isfinite(v)) badl = 1;
+                }
+            bad = badl;
+        } else {
+            // the pivoting matrix is indexed at run time: in LDS (one thread uses it), not in a private array -- that one
+            // lives in scratch memory and every access of the elimination is a dependent memory round trip
+            double* M = Msh;
+    #pragma unroll
+            for (int i = 0; i < D; ++i)
+    #pragma unroll
+                for (int j = 0; j < D; ++j) { M[i * 2 * D + j] = (double)kvs[i * D + j]; M[i * 2 * D + D + j] = (i == j) ? 1.0 : 0.0; }
+            // elimination with the multiplier taken against the UNSCALED pivot row (as LU does), so exactly
+            // dependent rows cancel to exact zeros and are reported singular like Julia's inv()
+            for (int c = 0; c < D && !bad; ++c) {
+                int p = c;
+                for (int r = c + 1; r < D; ++r)
+                    if (fabs(M[r * 2 * D + c]) > fabs(M[p * 2 * D + c])) p = r;
+                const double pv = M[p * 2 * D + c];
+                if (!(fabs(pv) > 0.0) || !isfinite(pv)) { bad = 1; break; }
+                if (p != c)
+                    for (int j = 0; j < 2 * D; ++j) { const double t = M[p * 2 * D + j]; M[p * 2 * D + j] = M[c * 2 * D + j]; M[c * 2 * D + j] = t; }
+                for (int r = 0; r < D; ++r) {
+                    if (r == c) continue;
+                    const double f = M[r * 2 * D + c] / pv;
+                    if (f == 0.0) continue;
+                    for (int j = 0; j < 2 * D; ++j) M[r * 2 * D + j] -= f * M[c * 2 * D + j];
+                    M[r * 2 * D + c] = 0.0;
+                }
+            }
+            for (int c = 0; c < D && !bad; ++c) {
+                const double inv = 1.0 / M[c * 2 * D + c];
+                for (int j = 0; j < 2 * D; ++j) M[c * 2 * D + j] *= inv;
+            }
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j < D; ++j) {
+                    Am[i * D + j] = bad ? 0.0 : M[i * 2 * D + D + j];
+                    if (!isfinite(Am[i * D + j])) bad = 1;
+                }
+        }
         if (bad && blockIdx.x == 0) atomicOr(a.status, 2);
     }
     __syncthreads();
