@@ -257,26 +257,32 @@ def main():
     # the optimizer to their initial state (every rank alike: the engine agrees on errors) and the chunk is run again.  Without a
     # collapse -- the case on every configuration run so far -- nothing differs from one call for all k iterations.
     theta0 = iso.model.get_params()
-    collapse = {"resets": 0}
+    collapse = {"resets": 0, "excluded_s": 0.0}
     CHUNK = 250
 
     def resilient(run_chunk, k, iso_=None, theta_=None):
+        """Only the TARGET's DomainErrors (constant chi, singular simplex: what the reference raises on data without dynamics) are
+        answered with a reset.  A non-finite training loss (ECOLLAPSED), a peer's failure (EPEER) or any HIP error propagates: the
+        run ends non-zero instead of reporting a number measured around a fault.  The wall time of a failed chunk and of the reset
+        is kept in collapse["excluded_s"] and taken out of the timed region: `value` counts K completed iterations only."""
         iso_ = iso if iso_ is None else iso_
         theta_ = theta0 if theta_ is None else theta_
         done = 0
         while done < k:
             n = min(CHUNK, k - done)
+            tc = time.perf_counter()
             try:
                 run_chunk(n)
                 done += n
             except (pkg.DomainError, pkg.IskError) as ex:
                 st = getattr(ex, "status", None)
-                if st not in (pkg.capi.ECONSTANT_CHI, pkg.capi.ESINGULAR, pkg.capi.ECOLLAPSED, pkg.capi.EPEER) or collapse["resets"] >= 20:
+                if st not in (pkg.capi.ECONSTANT_CHI, pkg.capi.ESINGULAR) or collapse["resets"] >= 20:
                     raise
                 collapse["resets"] += 1
                 print(f"[bench] rank {rank}: {ex} -- model and optimizer reset to their initial state, chunk repeated", file=sys.stderr)
                 iso_.model.set_params(theta_)
                 pkg.capi.check(iso_._lib.isk_reset_opt_state(iso_._h))
+                collapse["excluded_s"] += time.perf_counter() - tc
 
     if not use_dp:
         def step(k=1):
@@ -335,10 +341,11 @@ def main():
             print(f"[bench] rank {rank}: phase '{phase}' made no progress for {int(wd_limit)} s in the data-parallel run "
                   "(a collective is waiting for a peer?) -- aborting", file=sys.stderr, flush=True)
             if phase.startswith("sub-record") and wd.get("headline"):
-                # the headline was measured before the extra records: print it rather than lose the run
+                # the headline was measured before the extra records: print it rather than lose it -- but a hung collective is a
+                # FAILED run: the line says so (`watchdog_hang`) and the exit code stays non-zero like for every other phase
                 if rank == 0:
+                    wd["headline"][1]["watchdog_hang"] = {"phase": phase, "seconds_without_progress": int(wd_limit)}
                     os.write(wd["headline"][0], (json.dumps(wd["headline"][1]) + "\n").encode())
-                os._exit(0)
             os._exit(3)
         wd["timer"] = threading.Timer(wd_limit, _bail)
         wd["timer"].daemon = True
@@ -363,10 +370,12 @@ def main():
         step(args.warmup)
     sync(); barrier(); sync()
     arm("timed steps")
+    ex0 = collapse["excluded_s"]
     t0 = time.perf_counter()
     step(args.steps)
     sync(); barrier(); sync()
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0 - (collapse["excluded_s"] - ex0)
+    excluded_headline_s = collapse["excluded_s"] - ex0
     arm("")
     if use_dp:
         import torch
@@ -531,9 +540,11 @@ def main():
             "final_loss": iso.losses[-1],
         }
         if collapse["resets"]:
-            line["collapse_resets"] = {"count": collapse["resets"],
-                                       "note": "the synthetic data's chi collapsed (DomainError, as in the reference): model and optimizer were reset "
-                                               "to their initial state and the 250-iteration chunk was run again inside the timed regions"}
+            line["collapse_resets"] = {"count": collapse["resets"], "excluded_s_total": collapse["excluded_s"],
+                                       "excluded_s_headline": excluded_headline_s,
+                                       "note": "the target's DomainError (constant chi / singular simplex: synthetic data without dynamics, as in "
+                                               "the reference): model and optimizer were reset to their initial state and the 250-iteration chunk "
+                                               "was run again; the failed chunk's wall time is NOT part of ms_per_step / value"}
         return line
 
     # ---- the same metric over >= --sustained-s seconds of back-to-back iterations, shader clock sampled meanwhile: the timed
@@ -544,12 +555,12 @@ def main():
             idle_clk = read_sclk_mhz(local_rank)
             arm("sustained run")
             with SclkSampler(local_rank) as smp:
-                t0s, its = time.perf_counter(), 0
+                t0s, its, exs = time.perf_counter(), 0, collapse["excluded_s"]
                 while time.perf_counter() - t0s < args.sustained_s:
                     step(args.steps)
                     its += args.steps
                 sync()
-                dts = time.perf_counter() - t0s
+                dts = time.perf_counter() - t0s - (collapse["excluded_s"] - exs)
             sustained = {"seconds": dts, "iterations": its, "ms_per_step": 1e3 * dts / its, "value": N * K * its / dts,
                          "unit": "Koopman-samples/s", "sclk": smp.summary(), "sclk_idle_before_mhz": idle_clk}
             arm("")
@@ -585,10 +596,11 @@ def main():
                     resilient(lambda n: iso2.losses.extend(dp.dp_run(local2, comm, n, 1, gmb2, None, counts=counts2)), k, iso2, theta2)
                 step2(max(1, args.warmup))
                 sync(); barrier(); sync()
-                t02 = time.perf_counter()
+                t02, ex2 = time.perf_counter(), collapse["excluded_s"]
                 step2(args.steps)
                 sync(); barrier(); sync()
-                t2 = torch.tensor([time.perf_counter() - t02], dtype=torch.float64, device=torch.device("cuda", local_rank))
+                t2 = torch.tensor([time.perf_counter() - t02 - (collapse["excluded_s"] - ex2)], dtype=torch.float64,
+                                  device=torch.device("cuda", local_rank))
                 dist.all_reduce(t2, op=dist.ReduceOp.MAX)
                 dt2 = float(t2.item())
                 return {"scaling": scaling, "N_global": ng2, "N_per_gpu": N2, "minibatch_global": gmb2, "steps": args.steps,
@@ -603,10 +615,20 @@ def main():
             if label == "weak" and args.scaling == "weak":
                 continue                                              # (that IS the headline of this invocation)
             arm("sub-record " + label)
+            bad = 0
             try:
                 sub_records[label] = dp_sub_record(label, scaling, mb)
-            except Exception as ex:      # noqa: BLE001 - on every rank alike or the watchdog ends the run with the headline printed
-                sub_records[label] = {"error": str(ex)}
+            except Exception as ex:      # noqa: BLE001
+                sub_records[label], bad = {"error": str(ex)}, 1
+            # agree on the outcome BEFORE the next collective: a rank that raised must not leave its peers alone in the next
+            # sub-record's all-reduces (a rank that raised while its peers were still inside an engine collective cannot be helped
+            # from here: the watchdog ends that run, non-zero)
+            fb = torch.tensor([bad], dtype=torch.int32, device=torch.device("cuda", local_rank))
+            dist.all_reduce(fb, op=dist.ReduceOp.MAX)
+            if int(fb.item()):
+                if not bad:
+                    sub_records[label] = {"error": "a peer rank failed in this sub-record"}
+                break
         arm("")
     if use_dp:
         dist.barrier()
@@ -625,10 +647,10 @@ def main():
                 th00 = iso0.model.get_params()
                 resilient(lambda n: pkg.run(iso0, n, 1), max(1, args.warmup), iso0, th00)
                 pkg.capi.check(iso0._lib.isk_synchronize(iso0._h))
-                t00 = time.perf_counter()
+                t00, ex00 = time.perf_counter(), collapse["excluded_s"]
                 resilient(lambda n: pkg.run(iso0, n, 1), args.steps, iso0, th00)
                 pkg.capi.check(iso0._lib.isk_synchronize(iso0._h))
-                dt0 = time.perf_counter() - t00
+                dt0 = time.perf_counter() - t00 - (collapse["excluded_s"] - ex00)
                 iso0.timers(enable=True, reset=True)
                 pkg.run(iso0, args.profile_steps, 1)
                 pkg.capi.check(iso0._lib.isk_synchronize(iso0._h))

@@ -172,8 +172,12 @@ end
 function append_data!(m::HipModel, old, new, drop::Integer, nadd::Integer)
     D, K, _ = size(old.coords[2]); no = size(old.coords[1], 2)
     xs = Float32.(new.coords[1][:, no-drop+1:end]); ys = Float32.(new.coords[2][:, :, no-drop+1:end])
-    check(ccall((:isk_append_data, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int64, Int64, Int64, Int64),
-                m.h, nadd > 0 ? pointer(xs) : Ptr{Float32}(C_NULL), nadd > 0 ? pointer(ys) : Ptr{Float32}(C_NULL), D, K, nadd, drop))
+    # xs / ys are locals: `pointer(x)` alone does not root them, and isk_append_data copies host -> device synchronously (GBs at
+    # villin size) -- keep them alive across the call
+    GC.@preserve xs ys begin
+        check(ccall((:isk_append_data, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int64, Int64, Int64, Int64),
+                    m.h, nadd > 0 ? pointer(xs) : Ptr{Float32}(C_NULL), nadd > 0 ? pointer(ys) : Ptr{Float32}(C_NULL), D, K, nadd, drop))
+    end
 end
 
 """
