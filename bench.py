@@ -213,7 +213,7 @@ def main():
             sys.exit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     ge.build()
     pkg = ge.load_package()
-    if pkg.capi.device_count() <= local_rank:
+    if pkg.capi.device_count() <= (0 if os.environ.get("ISK_BENCH_DIST_BACKEND", "nccl") != "nccl" else local_rank):
         sys.exit("no HIP device for this rank: the product path has no CPU fallback")
 
     dist = None
@@ -221,6 +221,15 @@ def main():
         sys.exit("--shard-of rehearses one rank's share on ONE GPU")
     use_dp = world > 1 or args.force_dp or args.shard_of > 0
     real_stdout = None
+    # ISK_BENCH_DIST_BACKEND=gloo (+ ISK_RCCL_LIB=<tests/mock_rccl build>): REHEARSAL of the multi-rank branch on one GPU -- the
+    # ranks share device ISK_BENCH_DEVICE (default: local rank modulo the visible devices), torch.distributed runs on gloo with
+    # its control tensors on the host, and the engine's collectives go through the library ISK_RCCL_LIB names (real RCCL refuses
+    # two ranks on one device).  Every line of such a run carries "rehearsal": it exercises the code, it measures nothing.
+    backend = os.environ.get("ISK_BENCH_DIST_BACKEND", "nccl")
+    rehearsal = use_dp and world > 1 and backend != "nccl"
+    dev_index = local_rank
+    if rehearsal:
+        dev_index = int(os.environ.get("ISK_BENCH_DEVICE", local_rank % max(1, pkg.capi.device_count())))
     if use_dp:
         # RCCL prints a version banner on stdout; the driver wants exactly one JSON line there
         sys.stdout.flush()
@@ -228,10 +237,14 @@ def main():
         os.dup2(2, 1)
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(dev_index)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        ctl_dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)      # where the bench's own small tensors live
 
     if args.forward_mode == 3 and args.workload == "c5shard":
         args.forward_mode = 1      # 512-wide layers run on the layered path, where a split-f16 request means the split-bf16 kernels
@@ -243,7 +256,7 @@ def main():
         sys.exit(f"strong scaling needs equal shards: N = {n_global_wl} is not a multiple of {parts}")
     if strong and args.minibatch and (args.minibatch % parts or args.minibatch < parts):
         sys.exit(f"strong scaling splits the global minibatch over the ranks: {args.minibatch} is not a multiple of {parts}")
-    iso, c, widths = build_iso(pkg, args.workload, seed=rank, device=local_rank, args=args, n_local=n_global_wl // parts if strong else None)
+    iso, c, widths = build_iso(pkg, args.workload, seed=rank, device=dev_index, args=args, n_local=n_global_wl // parts if strong else None)
     N, K = c["N"], c["K"]                                             # per rank
     n_global = n_global_wl if strong else N * world
     gmb = args.minibatch if strong else args.minibatch * world        # global minibatch (0 = full batch)
@@ -298,7 +311,7 @@ def main():
     else:
         import torch
         from isokann_jl_amd import dp
-        comm = dp.Comm(device=torch.device("cuda", local_rank))
+        comm = dp.Comm(device=ctl_dev)
         local = dp.HipLocal(iso)
         counts = dp.shard_counts(local, comm)
         if args.shard_of:
@@ -361,7 +374,7 @@ def main():
         except Exception as ex:      # noqa: BLE001
             failed = 1
             print(f"[bench] rank {rank}: native data-parallel step failed ({ex}); falling back to host-driven collectives", file=sys.stderr)
-        f = torch.tensor([failed], dtype=torch.int32, device=torch.device("cuda", local_rank))
+        f = torch.tensor([failed], dtype=torch.int32, device=ctl_dev)
         dist.all_reduce(f, op=dist.ReduceOp.MAX)
         if int(f.item()):
             local._native_agreed = False
@@ -379,7 +392,7 @@ def main():
     arm("")
     if use_dp:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        t = torch.tensor([dt], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert os.environ.get("ISK_LIB") or all(np.isfinite(l) for l in iso.losses), "non-finite training loss"
@@ -387,8 +400,7 @@ def main():
     if use_dp and world > 1:
         # every rank applies the same all-reduced gradient: the reduced loss and the replicas must agree exactly
         import torch
-        chk = torch.tensor([iso.losses[-1], float(np.sum(np.abs(iso.model.get_params()).astype(np.float64)))], dtype=torch.float64,
-                           device=torch.device("cuda", local_rank))
+        chk = torch.tensor([iso.losses[-1], float(np.sum(np.abs(iso.model.get_params()).astype(np.float64)))], dtype=torch.float64, device=ctl_dev)
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -539,6 +551,11 @@ def main():
             "f32_reference": f32_reference, "sustained": sustained, "sub_records": sub_records, "pullback": pullback,
             "final_loss": iso.losses[-1],
         }
+        if rehearsal:
+            line["rehearsal"] = {"backend": backend, "collective_library": os.environ.get("ISK_RCCL_LIB"), "ranks": world,
+                                 "device_of_this_rank": dev_index,
+                                 "note": "NOT a multi-GPU measurement: the ranks share one GPU, torch.distributed runs on " + backend
+                                         + " and the engine's collectives on the library ISK_RCCL_LIB names; exercises bench.py's multi-rank branch only"}
         if collapse["resets"]:
             line["collapse_resets"] = {"count": collapse["resets"], "excluded_s_total": collapse["excluded_s"],
                                        "excluded_s_headline": excluded_headline_s,
@@ -580,7 +597,7 @@ def main():
             a2 = copy.copy(args)
             a2.minibatch = minibatch
             strong2 = scaling == "strong"
-            iso2, c2, _w2 = build_iso(pkg, args.workload, seed=rank, device=local_rank, args=a2, n_local=n_global_wl // world if strong2 else None)
+            iso2, c2, _w2 = build_iso(pkg, args.workload, seed=rank, device=dev_index, args=a2, n_local=n_global_wl // world if strong2 else None)
             try:
                 N2 = c2["N"]
                 ng2 = n_global_wl if strong2 else N2 * world
@@ -600,7 +617,7 @@ def main():
                 step2(args.steps)
                 sync(); barrier(); sync()
                 t2 = torch.tensor([time.perf_counter() - t02 - (collapse["excluded_s"] - ex2)], dtype=torch.float64,
-                                  device=torch.device("cuda", local_rank))
+                                  device=ctl_dev)
                 dist.all_reduce(t2, op=dist.ReduceOp.MAX)
                 dt2 = float(t2.item())
                 return {"scaling": scaling, "N_global": ng2, "N_per_gpu": N2, "minibatch_global": gmb2, "steps": args.steps,
@@ -623,7 +640,7 @@ def main():
             # agree on the outcome BEFORE the next collective: a rank that raised must not leave its peers alone in the next
             # sub-record's all-reduces (a rank that raised while its peers were still inside an engine collective cannot be helped
             # from here: the watchdog ends that run, non-zero)
-            fb = torch.tensor([bad], dtype=torch.int32, device=torch.device("cuda", local_rank))
+            fb = torch.tensor([bad], dtype=torch.int32, device=ctl_dev)
             dist.all_reduce(fb, op=dist.ReduceOp.MAX)
             if int(fb.item()):
                 if not bad:
@@ -642,7 +659,7 @@ def main():
             a0 = copy.copy(args)
             a0.forward_mode = 0
             arm("f32 reference")
-            iso0, c0, w0 = build_iso(pkg, args.workload, seed=rank, device=local_rank, args=a0)
+            iso0, c0, w0 = build_iso(pkg, args.workload, seed=rank, device=dev_index, args=a0)
             try:
                 th00 = iso0.model.get_params()
                 resilient(lambda n: pkg.run(iso0, n, 1), max(1, args.warmup), iso0, th00)

@@ -187,8 +187,10 @@ class HipLocal:
         if not comm.on:
             self._native = True                       # single rank: isk_dp_run runs without collectives
             return True
-        if comm.dist.get_backend() != "nccl" or comm.device.type != "cuda":
-            return False
+        import os
+        if (comm.dist.get_backend() != "nccl" or comm.device.type != "cuda") and not os.environ.get("ISK_RCCL_LIB"):
+            return False          # (ISK_RCCL_LIB: a stand-in collective library that works across the processes of one device --
+                                  #  tests/mock_rccl -- with whatever process group carries the 128-byte id)
         ident = np.zeros(128, np.uint8)
         if comm.rank == 0:
             capi.check(self.lib.isk_dp_comm_id(ident.ctypes.data_as(C.POINTER(C.c_uint8))))
