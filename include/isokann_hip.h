@@ -133,50 +133,36 @@ int  isk_set_stream(isk_engine* e, void* hip_stream);  /* run on the caller's st
  *   overlap_featurize   2        where the NEXT iteration's featurization runs: 2 = side stream beside the training kernels,
  *                                1 = beside the forward, 0 = inline on the main stream
  *   side_min_steps      4        fewest optimizer steps of the coming training phase for which the side stream is used
- *   side_early          1        start the side launch right behind the forward (0: after the target kernels)
- *   feat_wg_per_cu      1        throttle of the background featurizer (workgroups per CU) / feat_bg_wgs (in total, 0 = off)
+ *   feat_wg_per_cu      1        throttle of the background featurizer (workgroups per CU)
+ *   feat_bg_wgs         0        ... or its workgroups in total (0 = the per-CU rule)
  *   feat_pf             1        samples in flight per wave of the background featurizer (1 | 2)
- *   feat_early_pct      0        share of the next iteration's rows featurized beside THIS forward (feat_early_wgs workgroups)
  *   train_graph         1        replay a training epoch as one hipGraph
  *   grad1_nw8           -1       layer-1 gradient kernel: 1 = 8-wave variant, 0 = 16-wave, -1 = 8-wave while the featurizer runs
- *   train_persist       0        training on one GPU: 1 = an epoch as ONE persistent launch where the network allows it (narrow tail,
- *                                sigmoid hidden layers, batches of at most 1024 rows).  Experimental: correct, and slower than the four
- *                                launches per optimizer step it replaces
+ *   tail_narrow         1        training: register-resident tail kernel where every tail layer is <= 16 wide (0: the generic LDS kernel)
  *   fuse_opt            1        training on one GPU with batches of at most 768 rows (one row slab): the optimizer step rides on the
  *                                layer-1 gradient kernel -- three launches per optimizer step instead of four
- *   fuse_opt_rows       768      ... for batches of up to this many rows (at most 1024; beyond 768 rows the gradient kernel by default splits
- *                                the batch rows over two workgroups per feature tile and a separate optimizer launch sums the two slabs:
- *                                faster at C3's 1000-row batches than one fused slab)
+ *   dense_groups        1        wide networks, bf16 forward: one grouped launch per layer
+ *   wide_fused          1        wide networks, plain-bf16 forward (forward_mode 2): one fused kernel, activations in LDS
+ *   train_bf16          0        wide networks: training GEMMs on bf16 operands (f32 master weights, f32 accumulate); 0 = the same
+ *                                in-house MFMA kernels in Float32 arithmetic (no vendor BLAS is reachable from this library)
  *   fuse_head           1        wide networks with at least three layers and at most four outputs, training GEMMs: the last layer's forward,
  *                                the loss, delta_L and delta_{L-1} are ONE launch (three before); its per-workgroup partial sums of
  *                                dW_L / db_L / the loss are added up by the next launch
  *   fuse_boundary       1        wide networks without a leading LayerNorm, training GEMMs: the optimizer step, the next step's weight images
  *                                and the next step's batch images are ONE launch at the boundary between two optimizer steps
- *   epoch_gather        0        wide networks, training GEMMs: 1 = the batch images (row gather, transposed copy) of every batch of an epoch are
- *                                written by ONE launch in front of the epoch's optimizer steps instead of one per step (measured: no faster)
- *   g16_waves           0        wide networks, training GEMMs: waves per workgroup that split the contraction (4 or 8; 0 = eight for products
- *                                at least 512 deep)
- *   fuse_tail           0        training, narrow tail with sigmoid hidden layers and an identity output (every pairnet default): the layer-1
- *                                forward and the tail step are ONE launch -- the workgroup whose partial product arrives last runs the tail
- *                                of its rows; with fuse_opt two launches per optimizer step.  Experimental: bit-identical results, and the
- *                                in-launch hand-off costs more than the launch boundary it replaces
- *   tail_narrow         1        training: register-resident tail kernel where every tail layer is <= 16 wide (0: the generic LDS kernel)
- *   fwd_waves_per_simd  1        residency of the f32-MFMA forward kernel
- *   bf16_skew           1        split-bf16 forward: the second wave of a SIMD converts in the first half of a stage
- *   dense_groups        1        wide networks, bf16 forward: one grouped launch per layer
- *   layered_blas        0        wide networks, f32 training: 1 = rocBLAS sgemm for the plain layer GEMMs; 0 = the in-house MFMA kernels
- *                                in Float32 arithmetic (fused epilogues, grouped launches: the faster path, and no vendor BLAS)
- *   train_bf16          0        wide networks: training GEMMs on bf16 operands (f32 master weights, f32 accumulate)
- *   wide_fused          1        wide networks, plain-bf16 forward (forward_mode 2): one fused kernel, activations in LDS
  *   dp_bucket           1        native data-parallel run of a wide network: the gradient all-reduce in two buckets -- the blocks of the
  *                                layers >= 1 travel on a second stream while the first layer's backward products run (bit-identical results)
  *   dp_peer_reduce      0        isk_dp_run_all (one process, several GPUs): 1 = the gradient is not all-reduced; every engine's optimizer
  *                                step reads the other engines' gradient buffers over peer access and sums them in rank order
- *   dp_force_coll       0        issue the native collectives on a one-rank communicator (tests)
- *   debug_feat_copy / debug_stamps / debug_rowmod   0   diagnostics
+ *   dp_force_coll       0        issue the native collectives on a one-rank communicator (tests, bench.py --shard-of)
+ *   debug_inject_rank_error 0    test hook: this rank flags a local failure at its n-th optimizer step of a data-parallel run
+ * (18 keys.  A library built with -DISK_EXPERIMENTAL additionally carries the knobs of variants that were measured and rejected --
+ * train_persist, fuse_tail, epoch_gather, fuse_opt_rows, g16_waves, feat_early_pct / feat_early_wgs, side_early, bf16_skew,
+ * fwd_waves_per_simd -- and the diagnostics debug_feat_copy / debug_stamps / debug_rowmod, with the kernels behind them; the shipped
+ * library has neither: DESIGN.md section 6b.)
  * Read-only keys of isk_get_option: forward_mode (effective), layered, planes, nparams_engine, wide_fwd (1 when the resident
  * data set runs the fused bf16 forward of wide networks: layered network, forward_mode 2, pair features, option wide_fused),
- * dp_peer_active (1 when the last isk_dp_run / isk_dp_run_all summed the gradients over peer access), train_persist_active (1 when the last epoch ran as one persistent launch), fuse_tail_active (1 when the last optimizer step ran the layer-1 forward and the tail step as one launch), layered_blas_active (1 once a rocBLAS handle exists, i.e. a wide network's f32 training GEMMs went to the library). */
+ * dp_peer_active (1 when the last isk_dp_run / isk_dp_run_all summed the gradients over peer access). */
 int  isk_set_option(isk_engine* e, const char* key, int64_t value);
 int  isk_get_option(isk_engine* e, const char* key, int64_t* value);
 

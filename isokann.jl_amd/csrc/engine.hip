@@ -84,7 +84,6 @@ static void free_data(isk_engine* e) {
     free_dev(e->d_target); free_dev(e->d_kw); e->d_kw = nullptr; free_dev(e->d_z1); free_dev(e->d_tail_cnt); e->d_tail_cnt = nullptr; free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm); free_dev(e->d_isa_work);
     e->d_isa_work = nullptr;
     free_dev(e->d_actA); free_dev(e->d_actB); e->d_actA = e->d_actB = nullptr;
-    free_dev(e->d_xb); e->d_xb = nullptr;
     free_dev(e->dbg_st); free_dev(e->dbg_rows); e->dbg_st = nullptr; e->dbg_rows = nullptr;      // (dbg_rows is sized by the data)
     bf16_train_release(e);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_lz[l]); free_dev(e->d_la[l]); free_dev(e->d_ld[l]); e->d_lz[l] = e->d_la[l] = e->d_ld[l] = nullptr; }
@@ -391,7 +390,6 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
             ALLOC(e->d_W16L[l], (size_t)isk_bf16_chunks(layer_kp(e, l)) * 32 * isk_pad16(cfg->widths[l + 1]) * 3 * sizeof(uint16_t));
         ALLOC(e->d_G0, (size_t)F * cfg->widths[1] * sizeof(float));
         ALLOC(e->d_D0, (size_t)cfg->widths[1] * sizeof(float));
-        ALLOC(e->d_W0g, (size_t)F * cfg->widths[1] * sizeof(float));
         ALLOC(e->d_zero, (size_t)4096 * sizeof(float));
         (void)hipMemset(e->d_zero, 0, (size_t)4096 * sizeof(float));
         if (bf16_weight_images_alloc(e) != ISK_OK) { isk_destroy(e); return fail(ISK_ENOMEM, "hipMalloc: bf16 weight images"); }
@@ -440,9 +438,8 @@ extern "C" void isk_destroy(isk_engine* e) {
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_Wt[l]); free_dev(e->d_bias[l]); }
     free_dev(e->d_W16); free_dev(e->d_wmax); free_dev(e->d_wscale);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->d_W16L[l]); free_dev(e->d_WtT[l]); }
-    free_dev(e->d_G0); free_dev(e->d_D0); free_dev(e->d_zero); free_dev(e->d_W0g);
+    free_dev(e->d_G0); free_dev(e->d_D0); free_dev(e->d_zero);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->b16.Wt[l]); free_dev(e->b16.Wf[l]); }
-    blas_release(e);
     dp_comm_release(e);
     free_dev(e->d_gks); free_dev(e->d_gchi);
     drain_timers(e);
@@ -745,7 +742,6 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
             HIPCHK(hipMemsetAsync(e->d_la[l], 0, nb, e->stream));
             HIPCHK(hipMemsetAsync(e->d_ld[l], 0, nb, e->stream));
         }
-        HIPCHK(hipMalloc((void**)&e->d_xb, (size_t)Bpad * e->Fp * sizeof(float)));
     }
     HIPCHK(hipMemcpyAsync(e->d_in_xs, xs, (size_t)N * D * sizeof(float), kind, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_in_ys, ys, (size_t)N * K * D * sizeof(float), kind, e->stream));
@@ -1110,14 +1106,12 @@ void launch_grads(isk_engine* e, const int* d_idx, int B, float inv_div, int nsl
     }
 }
 
-// fold: refresh the weight images the forward / training kernels read.  The rocBLAS variant of the layered training
-// path reads theta itself (only layer 0's folded bias comes from an image, and only with LayerNorm), so inside an
-// epoch it skips the refresh and folds once at the end.
+// fold: refresh the weight images the forward / training kernels read.
 // publish: this is the epoch's LAST step -- it writes the result into mapped pinned host memory (a kernel ends only when its
 // stores are acknowledged: publishing from every step cost ~2 us per step, 0.2 ms per iteration at minibatch = 100)
-// layered path without LayerNorm: rocBLAS and the bf16 GEMMs read theta (or their own images of it), so the forward weight
+// layered path without LayerNorm: the MFMA training GEMMs read theta (or their own images of it), so the forward weight
 // images are folded once, behind the epoch's last step (every epoch driver asks here: the per-step fold is ~38 us at C5)
-bool epoch_lazy_fold(isk_engine* e) { return e->layered && !e->cfg.layernorm && (bf16_train_active(e) || mfma32_train_active(e) || blas_ready(e)); }
+bool epoch_lazy_fold(isk_engine* e) { return e->layered && !e->cfg.layernorm && (bf16_train_active(e) || mfma32_train_active(e)); }
 // ... and not at all where nothing reads them: the fused wide forward streams its own fragment-linear images of theta and the bf16
 // GEMMs theirs (a forward of foreign rows through the generic layered kernels folds on demand: wt_dirty stays set)
 bool epoch_no_fold(isk_engine* e) { return epoch_lazy_fold(e) && e->xh16 && (bf16_train_active(e) || mfma32_train_active(e)); }

@@ -13,7 +13,6 @@
 #include <mutex>
 
 #include <rccl/rccl.h>
-#include <rocblas/rocblas.h>
 #include "isk_internal.h"
 
 // ---------------------------------------------------------------------------------------
@@ -114,9 +113,6 @@ struct isk_engine {
     float* d_la[ISK_MAX_LAYERS] = {nullptr};      //           activations
     float* d_ld[ISK_MAX_LAYERS] = {nullptr};      //           deltas
     float *d_G0 = nullptr, *d_D0 = nullptr;       // raw layer-0 gradient for the LayerNorm unfold
-    float* d_xb = nullptr;                        // rocBLAS training path: the batch rows of layer 0, gathered contiguous
-    float* d_W0g = nullptr;                       //                        layer-0 weights with the LayerNorm scale folded in (Flux layout)
-    rocblas_handle blas = nullptr;
     // bf16 training GEMMs (option train_bf16; kernels_gemm16.hip): images of the batch, of the activations / deltas (row-major and
     // transposed) and of the weights, allocated on first use for the resident N
     struct Bf16Train {
@@ -314,11 +310,9 @@ int forward_layered(isk_engine* e, const float* X, long long S, float* out, floa
 void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float inv_div);
 void bf16_train_release(isk_engine* e);
 bool bf16_train_active(const isk_engine* e);
-bool mfma32_train_active(const isk_engine* e);   // layered f32 training on the in-house NT GEMMs in Float32 arithmetic (no rocBLAS)
+bool mfma32_train_active(const isk_engine* e);   // layered f32 training on the in-house NT GEMMs in Float32 arithmetic
 int bf16_weight_images_alloc(isk_engine* e);             // isk_create, layered engines: the [max(N, 512)][pad32 K] bf16 images W_l'
 void bf16_weight_images_ensure(isk_engine* e, bool want_wt, bool want_wf);           // refresh them if theta changed since they were built
-bool blas_ready(isk_engine* e);
-void blas_release(isk_engine* e);
 int bf16_planes(const isk_engine* e);
 bool wide_forward_shape_ok(const isk_engine* e);         // the fused wide forward covers this network (hidden widths <= 512, nout <= 16)
 // ---- engine_isa_host.hip ---------------------------------------------------------------

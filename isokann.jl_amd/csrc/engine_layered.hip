@@ -91,133 +91,13 @@ int forward_layered(isk_engine* e, const float* X, long long S, float* out, floa
 }
 
 // ---------------------------------------------------------------------------------------
-// rocBLAS for the PLAIN GEMMs of the layered (wide-network) training path, loaded lazily.  The fused kernels
-// cover the networks whose layers fit a workgroup; 512-wide layers at a 1000-row batch are ordinary
-// [1000 x 2016] x [2016 x 512] products, where a tiled library GEMM moves 4-8x fewer bytes through L2 than
-// the one-tile-per-workgroup row GEMM used before (C5 shard: 0.47 -> ~0.2 ms per optimizer step).
-// ISK_LAYERED_BLAS=0 keeps the in-house kernels (also the fallback when librocblas.so cannot be loaded).
-// ---------------------------------------------------------------------------------------
-namespace {
-struct BlasApi {
-    void* lib = nullptr;
-    rocblas_status (*create)(rocblas_handle*) = nullptr;
-    rocblas_status (*destroy)(rocblas_handle) = nullptr;
-    rocblas_status (*set_stream)(rocblas_handle, hipStream_t) = nullptr;
-    rocblas_status (*sgemm)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const float*,
-                            const float*, rocblas_int, const float*, rocblas_int, const float*, float*, rocblas_int) = nullptr;
-    bool failed = false;
-};
-BlasApi g_blas;
-std::mutex g_blas_mu;                       // isk_dp_run_all drives one host thread per engine: the first epochs race to get here
-
-// The host process may carry a rocBLAS of its own (PyTorch bundles one; so does AMDGPU.jl's artifact tree), and two things must
-// not happen: (1) a second copy whose symbols land in the GLOBAL scope -- the host's ROCm libraries, loaded later, would bind
-// their rocblas_* / hipblaslt references to it and die in their initialisers (recorded: `import torch` behind the engine's first
-// wide-network step, Segmentation fault inside torch/__init__.py; reproducible without a GPU with
-// ctypes.CDLL("librocblas.so.5", RTLD_GLOBAL) followed by `import torch`); (2) a copy registered under the DEVELOPER name
-// "librocblas.so", which is the name the host's libraries ask for: the loader would hand them OUR copy instead of their bundled
-// one.  So: reuse whatever the process already has (RTLD_NOLOAD, as rccl_load does), otherwise load by the versioned soname
-// with RTLD_LOCAL.
-bool blas_load() {
-    std::lock_guard<std::mutex> lk(g_blas_mu);
-    if (g_blas.lib) return true;
-    if (g_blas.failed) return false;
-    void* h = nullptr;
-    static const char* const names[] = {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so.5", "/opt/rocm/lib/librocblas.so"};
-    for (int i = 0; i < 2 && !h; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
-    for (int i = 0; i < 4 && !h; ++i) if (i != 1) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
-    if (!h) h = dlopen(names[1], RTLD_NOW | RTLD_LOCAL);
-    BlasApi a;
-    if (h) {
-        a.create = (decltype(a.create))dlsym(h, "rocblas_create_handle");
-        a.destroy = (decltype(a.destroy))dlsym(h, "rocblas_destroy_handle");
-        a.set_stream = (decltype(a.set_stream))dlsym(h, "rocblas_set_stream");
-        a.sgemm = (decltype(a.sgemm))dlsym(h, "rocblas_sgemm");
-    }
-    if (!h || !a.create || !a.destroy || !a.set_stream || !a.sgemm) { g_blas.failed = true; return false; }
-    a.lib = h;
-    g_blas = a;
-    return true;
-}
-}  // namespace
-
-void blas_release(isk_engine* e) {
-    if (e->blas && g_blas.destroy) (void)g_blas.destroy(e->blas);
-    e->blas = nullptr;
-}
-
-bool blas_ready(isk_engine* e) {
-    if (!e->opt.layered_blas || !e->layered || !e->d_xb) return false;
-    if (!blas_load()) return false;
-    if (!e->blas && g_blas.create(&e->blas) != rocblas_status_success) { e->blas = nullptr; g_blas.failed = true; return false; }
-    return g_blas.set_stream(e->blas, e->stream) == rocblas_status_success;
-}
-
-// one optimizer step's gradient on the layered path with library GEMMs.  All matrices are viewed column-major:
-// a row-major [rows][ld] activation buffer is the (ld x rows) matrix X', Flux's W (out, in) is the (N x K) matrix W.
-//   forward   Z' (N x B) = W (N x K) * X' (K x B)
-//   dW        G  (N x K) = D' (N x B) * X'^T          -> written in Flux layout directly
-//   dX        R' (K x B) = W^T (K x N) * D' (N x B)   -> no transposed weight image needed
-static bool launch_grads_layered_blas(isk_engine* e, const int* d_idx, int B, float inv_div) {
-    if (!blas_ready(e)) return false;
-    const int L = e->L;
-    const long long Bpad = ((B + 15) / 16) * 16;
-    const float* xs = e->d_xs32;
-    hipStream_t st = e->stream;
-    const float one = 1.f, zero = 0.f;
-    const float* X0 = xs;
-    if (d_idx) { isk_launch_gather_rows(xs, e->Fp, d_idx, B, e->d_xb, st); X0 = e->d_xb; }
-    const float* W0 = e->d_theta + e->off_W[0];
-    if (e->cfg.layernorm) {
-        isk_launch_scale_cols(e->d_theta + e->off_W[0], e->d_theta + e->off_lns, e->d_W0g, e->cfg.widths[1], e->F, st);
-        W0 = e->d_W0g;
-    }
-    bool ok = true;
-    for (int l = 0; l < L && ok; ++l) {
-        const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1], Np = isk_pad16(N);
-        const float* X = (l == 0) ? X0 : e->d_la[l - 1];
-        const int ldx = (l == 0) ? e->Fp : isk_pad16(K);
-        const float* W = (l == 0) ? W0 : e->d_theta + e->off_W[l];
-        ok = g_blas.sgemm(e->blas, rocblas_operation_none, rocblas_operation_none, N, B, K, &one, W, N, X, ldx, &zero, e->d_lz[l], Np) ==
-             rocblas_status_success;
-        // layer 0 with LayerNorm: the folded bias image (b1 + W1*beta); otherwise the bias straight from theta
-        const float* bias = (l == 0 && e->cfg.layernorm) ? e->d_bias[0] : e->d_theta + e->off_b[l];
-        isk_launch_bias_act(e->d_lz[l], bias, l < L - 1 ? e->d_la[l] : nullptr, B, Np, N, act_of_layer(e, l), st);
-    }
-    if (!ok) return false;
-    const int nop = isk_pad16(e->nout);
-    isk_launch_loss_delta(e->d_lz[L - 1], nop, e->d_target, e->d_lossw, d_idx, B, e->nout, inv_div, e->cfg.lastactivation,
-                          e->d_ld[L - 1], nop, e->d_grad + e->nparams, e->d_rank_err, st);
-    for (int l = L - 1; l >= 0 && ok; --l) {
-        const int K = e->cfg.widths[l], N = e->cfg.widths[l + 1], Np = isk_pad16(N);
-        const float* X = (l == 0) ? X0 : e->d_la[l - 1];
-        const int ldx = (l == 0) ? e->Fp : isk_pad16(K);
-        const bool ln0 = (l == 0 && e->cfg.layernorm);
-        float* gW = ln0 ? e->d_G0 : e->d_grad + e->off_W[l];
-        ok = g_blas.sgemm(e->blas, rocblas_operation_none, rocblas_operation_transpose, N, K, B, &one, e->d_ld[l], Np, X, ldx, &zero, gW, N) ==
-             rocblas_status_success;
-        isk_launch_colsum(e->d_ld[l], Np, B, N, e->d_grad + e->off_b[l], st);
-        if (ln0)
-            isk_launch_ln_unfold(e->d_G0, e->d_grad + e->off_b[0], e->d_theta, e->off_W[0], e->off_lns, e->off_lnb, e->F, N, e->d_grad, st);
-        if (l > 0 && ok) {
-            // delta_{l-1} = (delta_l W_l) .* act'(z_{l-1});  a_{l-1} is dead after dW_l and receives the raw product
-            ok = g_blas.sgemm(e->blas, rocblas_operation_transpose, rocblas_operation_none, K, B, N, &one, e->d_theta + e->off_W[l], N,
-                              e->d_ld[l], Np, &zero, e->d_la[l - 1], isk_pad16(K)) == rocblas_status_success;
-            isk_launch_dact_mul(e->d_la[l - 1], e->d_lz[l - 1], e->d_ld[l - 1], Bpad, isk_pad16(K), K, act_of_layer(e, l - 1), st);
-        }
-    }
-    e->last_nslab = 1;
-    return ok;
-}
-
-// ---------------------------------------------------------------------------------------
 // bf16 MFMA training GEMMs (option train_bf16): the arithmetic BASELINE.json names for the wide C5 network -- bf16 operands,
 // f32 accumulate, f32 master weights and optimizer.  kernels_gemm16.hip explains the operand images.
 // ---------------------------------------------------------------------------------------
 bool bf16_train_active(const isk_engine* e) { return e->layered && e->opt.train_bf16 != 0; }
 // ... and the same kernels in Float32 arithmetic (f32 fragments, v_mfma_f32_16x16x4_f32, f32 images): the DEFAULT of the layered
-// training path since round 4 -- option layered_blas = 1 selects rocBLAS sgemm instead
-bool mfma32_train_active(const isk_engine* e) { return e->layered && !e->opt.train_bf16 && !e->opt.layered_blas; }
+// training path since round 4 (round 5: the vendor-library sgemm route it had overtaken is gone)
+bool mfma32_train_active(const isk_engine* e) { return e->layered && !e->opt.train_bf16; }
 
 // the per-batch images (the weight images belong to the engine, not to the data)
 void bf16_train_release(isk_engine* e) {
@@ -320,6 +200,9 @@ static bool bf16_train_ensure(isk_engine* e, long long Bp, int esz) {
 void layered_epoch_gather(isk_engine* e, const int* d_perm, long long bs, long long nb) {
     auto& b = e->b16;
     b.ep_nb = 0;
+#ifndef ISK_EXPERIMENTAL
+    (void)d_perm; (void)bs; (void)nb;            // (measured: no faster than the per-step gather; built with -DISK_EXPERIMENTAL only)
+#else
     if (!e->layered || !e->opt.epoch_gather || nb < 2 || !(bf16_train_active(e) || mfma32_train_active(e))) return;
     const int esz = bf16_train_active(e) ? 2 : 4;
     const long long Bp = isk_pad32((int)bs);
@@ -341,6 +224,7 @@ void layered_epoch_gather(isk_engine* e, const int* d_perm, long long bs, long l
     isk_launch_gather_epoch(e->d_xs32, e->Fp, d_perm, (int)bs, (int)Bp, e->F, e->Fp, b.xb_all, b.xt_all, Bp, esz == 4, (int)nb,
                             (long long)Bp * e->Fp * esz, (long long)(e->F + 1) * Bp * esz, e->stream);
     b.ep_perm = d_perm; b.ep_bs = bs; b.ep_nb = nb; b.ep_esz = esz;
+#endif
 }
 void layered_epoch_end(isk_engine* e) { e->b16.ep_nb = 0; }
 
@@ -471,8 +355,8 @@ static bool launch_grads_layered_bf16(isk_engine* e, const int* d_idx, int B, fl
 void launch_grads_layered(isk_engine* e, const int* d_idx, int B, float inv_div) {
     if (bf16_train_active(e) && launch_grads_layered_bf16(e, d_idx, B, inv_div, 0)) return;
     if (mfma32_train_active(e) && launch_grads_layered_bf16(e, d_idx, B, inv_div, 1)) return;
-    if (launch_grads_layered_blas(e, d_idx, B, inv_div)) return;
-    ensure_folded(e);                // the in-house kernels read the f32 weight images (an epoch on the bf16 GEMMs leaves them unfolded)
+    // fallback when the GEMM images cannot be allocated: the row-GEMM / tile-dW kernels of kernels_layered.hip
+    ensure_folded(e);                // they read the f32 weight images (an epoch on the MFMA GEMMs leaves them unfolded)
     const int L = e->L;
     const long long Bpad = ((B + 15) / 16) * 16;
     const float* xs = e->d_xs32;

@@ -27,8 +27,6 @@ struct IskOptions {
     int feat_bg_wgs = 0;          //                                        ... or in total (0 = per-CU rule)
     int feat_pf = 1;              // samples in flight per wave of the background featurizer
     int dense_groups = 1;         // layered bf16 forward: one grouped launch per layer
-    int layered_blas = 0;         // layered f32 training: 1 = rocBLAS sgemm for the plain GEMMs; 0 (default since round 4) = the in-house
-                                  // NT kernels of kernels_gemm16.hip in Float32 arithmetic (no vendor BLAS on the default path)
     int train_graph = 1;          // replay the training epoch as one hipGraph
     int grad1_nw8 = -1;           // train_grad1n variant: 1 = 8 waves, 0 = 16 waves, -1 = 8 while the featurizer shares the CUs
     int fwd_waves_per_simd = 1;   // residency of the f32 forward kernel
@@ -187,11 +185,6 @@ int isk_launch_wide_fwd(const WideFwdArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------- layered (wide-network) path ----
 void isk_launch_act(const float* z, float* a, long long rows, int ld, int width, int act, hipStream_t st);
-// helpers of the rocBLAS variant of the layered training path (the library runs the plain GEMMs)
-void isk_launch_bias_act(float* z, const float* b, float* a /*nullable*/, long long rows, int ld, int width, int act, hipStream_t st);
-void isk_launch_gather_rows(const float* X, int ld, const int* idx, int B, float* out, hipStream_t st);
-void isk_launch_colsum(const float* d, int ld, int B, int N, float* out, hipStream_t st);
-void isk_launch_scale_cols(const float* W, const float* g, float* out, int N, int K, hipStream_t st);
 // delta_L and the batch loss (written to loss_slot[0]; loss_slot[1] <- *rank_err or 0, see TrainBuffers.rank_err) from the
 // last layer's pre-activations
 void isk_launch_loss_delta(const float* z, int ld, const float* target, const float* lossw, const int* perm, int B, int nout,

@@ -18,7 +18,7 @@
 // Float32 arithmetic (Gemm16Args.f32math; the default of the layered training path, option train_bf16 = 0): the same kernels with
 // f32 fragments -- a lane's eight consecutive contraction elements are eight registers -- and eight v_mfma_f32_16x16x4_f32 per
 // 32-deep step (step j contracts the elements 8 (lane / 16) + j: any bijection of the contraction index serves as long as both
-// operands use it), f32 images instead of bf16 ones.  Exact Float32 products and sums, i.e. what rocBLAS sgemm computed here
+// operands use it), f32 images instead of bf16 ones.  Exact Float32 products and sums, i.e. what a library sgemm computes here
 // until round 3 -- with the fused epilogues and grouped launches of the bf16 path instead of a library call per product plus
 // elementwise kernels around it.
 #include <type_traits>
@@ -463,6 +463,7 @@ static GatherArgs gather_args(const float* X, int ldx, const int* perm, int B, i
     *nblocks = g.gx * ((K + 1 + 31) / 32);                             // covers k = K (the ones row)
     return g;
 }
+#ifdef ISK_EXPERIMENTAL
 // the batch images of a whole EPOCH in one launch (blockIdx.y = batch: rows perm[y * B .. + B), images y strides further): the
 // gather depends on the shuffle order only, so it need not sit in front of every optimizer step's chain
 __global__ __launch_bounds__(256) void gather_epoch_kernel(GatherArgs g, long long xb_stride, long long xt_stride) {
@@ -479,6 +480,7 @@ void isk_launch_gather_epoch(const float* X, int ldx, const int* perm, int B, in
     const GatherArgs g = gather_args(X, ldx, perm, B, Bp, K, Kp, xb, xt, ldt, img_f32, &nb);
     hipLaunchKernelGGL(gather_epoch_kernel, dim3(nb, nbatch), dim3(256), 0, st, g, xb_stride_bytes, xt_stride_bytes);
 }
+#endif
 void isk_launch_gather_images(const float* X, int ldx, const int* perm, int B, int Bp, int K, int Kp, void* xb, void* xt, long long ldt,
                               int img_f32, hipStream_t st) {
     int nb;

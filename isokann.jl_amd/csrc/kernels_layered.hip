@@ -49,85 +49,6 @@ void isk_launch_act(const float* z, float* a, long long rows, int ld, int width,
     hipLaunchKernelGGL(act_kernel, dim3((unsigned)b), dim3(256), 0, st, z, a, rows, ld, width, act);
 }
 
-// ---- helpers of the rocBLAS variant of the training path (plain GEMMs by the library, everything else here) ----
-// z[n][o] += b[o] (pre-activation incl. bias, kept for the backward), a[n][o] = act(z[n][o]); padded columns stay 0
-__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ z, const float* __restrict__ b, float* __restrict__ a,
-                                                       long long rows, int ld, int width, int act) {
-    const long long tot = rows * ld;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
-        const int c = (int)(e % ld);
-        if (c < width) {
-            const float v = z[e] + b[c];
-            z[e] = v;
-            if (a) a[e] = l_act(act, v);
-        }
-    }
-}
-void isk_launch_bias_act(float* z, const float* b, float* a, long long rows, int ld, int width, int act, hipStream_t st) {
-    long long nb = (rows * ld + 255) / 256;
-    if (nb > 4096) nb = 4096;
-    if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)nb), dim3(256), 0, st, z, b, a, rows, ld, width, act);
-}
-
-// out[n][0..ld) = X[idx[n]][0..ld): the batch rows made contiguous for the library GEMM
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ X, int ld, const int* __restrict__ idx, int B,
-                                                          float* __restrict__ out) {
-    const int ld4 = ld / 4;
-    const long long tot = (long long)B * ld4;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
-        const long long n = e / ld4;
-        const int c = (int)(e % ld4);
-        ((f32x4*)out)[e] = ((const f32x4*)(X + (long long)idx[n] * ld))[c];
-    }
-}
-void isk_launch_gather_rows(const float* X, int ld, const int* idx, int B, float* out, hipStream_t st) {
-    long long nb = ((long long)B * (ld / 4) + 255) / 256;
-    if (nb > 8192) nb = 8192;
-    if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nb), dim3(256), 0, st, X, ld, idx, B, out);
-}
-
-// db[o] = sum_n delta[n][o]: 64 columns per workgroup, 16 waves stride the rows with 8 loads in flight each
-__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ d, int ld, int B, int N, float* __restrict__ out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int o = blockIdx.x * 64 + lane;
-    __shared__ float red[16][64];
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (o < N) {
-        for (int n0 = wave; n0 < B; n0 += 16 * 8) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int n = n0 + 16 * u; v[u] = (n < B) ? d[(long long)n * ld + o] : 0.f; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += v[u];
-        }
-    }
-    red[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-    __syncthreads();
-    if (wave == 0 && o < N) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) t += red[w][lane];
-        out[o] = t;
-    }
-}
-void isk_launch_colsum(const float* d, int ld, int B, int N, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, d, ld, B, N, out);
-}
-
-// Wg[o + k*N] = W[o + k*N] * g[k]: the LayerNorm scale folded into layer 0, in Flux layout for the library GEMM
-__global__ __launch_bounds__(256) void scale_cols_kernel(const float* __restrict__ W, const float* __restrict__ g, float* __restrict__ out,
-                                                         int N, long long tot) {
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) out[e] = W[e] * g[e / N];
-}
-void isk_launch_scale_cols(const float* W, const float* g, float* out, int N, int K, hipStream_t st) {
-    const long long tot = (long long)N * K;
-    long long nb = (tot + 255) / 256;
-    if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)nb), dim3(256), 0, st, W, g, out, N, tot);
-}
-
 __global__ __launch_bounds__(256) void dact_mul_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                                        float* __restrict__ d, long long rows, int ld, int width, int act) {
     const long long tot = rows * ld;

@@ -20,6 +20,12 @@
 // fits beside a wave of the side-stream featurizer on every SIMD.  Workgroups u < U (= ceil(B/16)) also run the tail of unit u
 // (train_tailn.hpp, eight waves) and own a slice of the tail parameters; workgroups with ks = 0 own the layer-1 bias of their tile.
 // Results: those of the four-kernel chain up to summation order (27 K-slice partials instead of 8, rows split over 8 waves).
+#include "isk_internal.h"
+#ifndef ISK_EXPERIMENTAL
+// shipped library: the persistent epoch is not built (it measured slower); option train_persist does not exist there
+bool isk_train_epoch_plan(const TrainShape&, int, int, int, EpochPlan*) { return false; }
+int isk_launch_train_epoch(const TrainShape&, const EpochPlan&, EpochArgs, hipStream_t) { return -1; }
+#else
 #include "train_tailn.hpp"
 
 #define EP_THREADS 512
@@ -567,3 +573,4 @@ int isk_launch_train_epoch(const TrainShape& s, const EpochPlan& p, EpochArgs a,
 #undef EPCASE
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
+#endif  // ISK_EXPERIMENTAL

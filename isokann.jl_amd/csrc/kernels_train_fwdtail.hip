@@ -19,6 +19,13 @@
 //
 // Only the pairnet default activations (SIG) are instantiated: their unit fits the 128 registers train_fwd1n is held to (two
 // workgroups per CU beside a featurizer wave); every other network keeps the two launches.
+#include "isk_internal.h"
+#ifndef ISK_EXPERIMENTAL
+// shipped library: the variant is not built (it measured slower); option fuse_tail does not exist there and these are never reached
+bool isk_train_fwdtail_ok(const TrainShape&) { return false; }
+void isk_launch_train_fwdtail(const TrainShape&, const TrainBuffers&, const int*, int, float, unsigned*, hipStream_t) {}
+int isk_train_fwdtail_counters(long long) { return 32; }            // (one line's worth: the engine allocates and zeroes it, nothing reads it)
+#else
 #include "train_fwd1n.hpp"
 #include "train_tailn.hpp"
 
@@ -109,3 +116,4 @@ void isk_launch_train_fwdtail(const TrainShape& s, const TrainBuffers& b, const 
 #undef FT_L
 #undef FT_LAUNCH
 }
+#endif  // ISK_EXPERIMENTAL

@@ -20,23 +20,14 @@ b c2 --workload c2
 b c5shard --workload c5shard --forward-mode 1 --no-cpu-baseline                               # split-bf16 forward (f32-equivalent), f32 training
 b c5shard_f32fwd --workload c5shard --forward-mode 0 --no-cpu-baseline
 b c5shard_bf16fwd --workload c5shard --forward-mode 2 --no-train-bf16 --no-cpu-baseline      # fused bf16 forward, f32 training: the in-house NT GEMMs in Float32 arithmetic (default since round 4)
-ISK_LAYERED_BLAS=1 b c5shard_bf16fwd_rocblas --workload c5shard --forward-mode 2 --no-train-bf16 --no-cpu-baseline   # ... and through rocBLAS sgemm (option layered_blas = 1)
 b c5shard_bf16 --workload c5shard --forward-mode 2 --train-bf16 --no-cpu-baseline          # the arithmetic BASELINE names for C5: forward AND training GEMMs on bf16
 # the same through the native data-parallel driver with every collective on a one-rank communicator: what ONE of C5's 8 ranks runs
 ISK_DP_FORCE_COLL=1 b c5shard_bf16_dp1 --workload c5shard --forward-mode 2 --train-bf16 --force-dp --no-cpu-baseline
 b c3_bf16fwd --forward-mode 2 --no-cpu-baseline
 b c3_pullback --pullback 2048 --no-cpu-baseline                                          # + the coordinate pullback on 2048 columns (field "pullback")
-# the persistent training-epoch kernel (experimental option train_persist, default off): measured against the launch chain
-ISK_TRAIN_PERSIST=1 b c3_persist --no-cpu-baseline
-ISK_TRAIN_PERSIST=1 b c3_cached_persist --cached-features --no-cpu-baseline
-ISK_TRAIN_PERSIST=1 b c3_mb100_nesterov_persist --minibatch 100 --opt nesterov --no-cpu-baseline
-# the optimizer step riding on train_grad1n (option fuse_opt, default on for batches <= 768 rows) and the one-launch forward + tail
-# (option fuse_tail, default off): A/B at the reference's default minibatch
+# (the A/B runs of train_persist / fuse_tail / fuse_opt_rows / g16_waves / epoch_gather are round-4 evidence, profiles/r04_*: those
+# variants exist in -DISK_EXPERIMENTAL builds only since round 5)
 ISK_FUSE_OPT=0 b c3_mb100_nesterov_nofuseopt --minibatch 100 --opt nesterov --no-cpu-baseline
-ISK_FUSE_TAIL=1 b c3_mb100_nesterov_fusetail --minibatch 100 --opt nesterov --no-cpu-baseline
-ISK_FUSE_OPT_ROWS=1024 b c3_fuseopt_1024rows --no-cpu-baseline                             # C3's 1000-row batches on one slab with the fused step
-ISK_G16_WAVES=4 b c5shard_bf16_g16w4 --workload c5shard --forward-mode 2 --train-bf16 --no-cpu-baseline   # training GEMMs: four waves everywhere
-ISK_EPOCH_GATHER=1 b c5shard_bf16_epochgather --workload c5shard --forward-mode 2 --train-bf16 --no-cpu-baseline
 ISK_FUSE_HEAD=0 b c5shard_bf16_nohead --workload c5shard --forward-mode 2 --train-bf16 --no-cpu-baseline          # three launches instead of the head kernel
 ISK_FUSE_BOUNDARY=0 b c5shard_bf16_noboundary --workload c5shard --forward-mode 2 --train-bf16 --no-cpu-baseline  # opt_step + prep_images instead of the boundary launch
 ISK_TAIL_NARROW=0 b c3_generic_tail --no-cpu-baseline                                    # round 3's train_tail kernel, for the A/B on this box

@@ -50,3 +50,16 @@ def gpu_pkg(pkg):
     if n < 1:
         pytest.fail("gpu test selected but no HIP device is visible")
     return pkg
+
+
+@pytest.fixture(scope="session")
+def experimental_lib(gpu_pkg):
+    """the tests of measured-and-rejected variants (persistent epoch, forward + tail as one launch, epoch-wide gather) need a
+    library built with -DISK_EXPERIMENTAL (DEVFLAGS_ALL=-DISK_EXPERIMENTAL scripts/devbuild.sh devlib/libisokann_hip_exp.so,
+    then ISK_LIB=devlib/libisokann_hip_exp.so pytest ...); the shipped library carries neither the options nor the kernels"""
+    lib = gpu_pkg.capi.load()
+    try:
+        lib.isk_experimental_build
+    except AttributeError:
+        pytest.skip("shipped library: experimental variants are not built (-DISK_EXPERIMENTAL)")
+    return lib

@@ -11,7 +11,7 @@ import pytest
 
 from oracle import isokann_oracle as O
 
-pytestmark = [pytest.mark.gpu, pytest.mark.own_fwd_mode, pytest.mark.usefixtures("fwd_mode")]
+pytestmark = [pytest.mark.gpu, pytest.mark.own_fwd_mode, pytest.mark.usefixtures("fwd_mode", "experimental_lib")]
 
 
 def _mk_model(pkg, om):

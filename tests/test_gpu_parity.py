@@ -819,7 +819,6 @@ def test_wide_network_switching_the_training_arithmetic_mid_run(gpu_pkg, monkeyp
     idx = rng.permutation(N)[:96]
     g16, l16 = pkg.batch_grads(iso, tgt, idx)
     iso.set_option("train_bf16", 0)
-    iso.set_option("layered_blas", 0)                                 # the in-house f32 kernels: they read the folded images
     g32, l32 = pkg.batch_grads(iso, tgt, idx)
     assert abs(l16 - l32) <= 2e-2 * abs(l32)
     assert np.abs(g16 - g32).max() <= 3e-2 * np.abs(g32).max()
@@ -829,83 +828,6 @@ def test_wide_network_switching_the_training_arithmetic_mid_run(gpu_pkg, monkeyp
     lo, go, _ = O.batch_loss_and_grads(om2, fx[:, idx], tgt[:, idx].astype(np.float64), np.ones(1))
     gflat = np.concatenate([a.reshape(-1, order="F") for a in go])
     np.testing.assert_allclose(g32, gflat, atol=5e-5 * np.abs(gflat).max(), rtol=2e-4)
-    iso.close()
-
-
-@pytest.mark.own_fwd_mode
-def test_torch_imports_behind_a_wide_network_step_on_rocblas(gpu_pkg):
-    """The engine loads the system's rocBLAS lazily for the f32 training GEMMs of a wide network (option layered_blas).  Loaded
-    RTLD_GLOBAL it made every later `import torch` in the process die in the initialisers of torch's bundled ROCm libraries
-    (round-3 crash record); blas_load() now reuses a copy the host already has or loads its own RTLD_LOCAL by soname.  A fresh
-    child process: engine first, one optimizer step on the rocBLAS path, THEN torch (and a matmul on it)."""
-    import subprocess
-    code = r"""
-import sys
-sys.path.insert(0, %r)
-assert 'torch' not in sys.modules
-import numpy as np
-import __graft_entry__ as ge
-pkg = ge.load_package()
-from oracle import isokann_oracle as O
-A, F, N, K = 20, 100, 128, 3
-xs, ys = O.synthetic_coords(A, N, K, seed=5)
-pairs = O.random_pairs(A, F, seed=6)
-iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=pkg.densenet([F, 200, 64, 1], layernorm=False, seed=1),
-              opt=pkg.AdamRegularized(), minibatch=64, forward_mode=0, options={"layered_blas": 1, "train_bf16": 0})
-pkg.run(iso, 1, 1)
-assert iso.get_option("layered_blas_active") == 1, "the step did not run on rocBLAS"
-assert 'torch' not in sys.modules
-import torch
-a = torch.arange(6.0).reshape(2, 3)
-assert float((a @ a.T).sum()) == 5 + 14 + 14 + 50
-if torch.cuda.is_available():
-    b = a.cuda()
-    assert float((b @ b.T).sum().cpu()) == 83.0
-pkg.run(iso, 1, 1)
-print("OK", iso.losses)
-""" % ROOT
-    env = dict(os.environ)
-    env.pop("ISK_FWD_MODE", None)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and "OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
-
-
-# --------------------------------------------------------------- TransformPseudoInv (SURVEY 8f rank 4) ----
-@pytest.mark.parametrize("eigenvecs", [False, True])
-def test_pseudoinv_target_and_run_match_oracle(gpu_pkg, eigenvecs):
-    """isotarget(::TransformPseudoInv) (src/isotarget.jl:152-179): chi and K chi from the HIP forward, the d x d
-    algebra on the host (as in the reference); three run! iterations against the oracle."""
-    pkg = gpu_pkg
-    A, F, N, K, nout = 14, 40, 320, 5, 3
-    data, odata, om = _coords_case(pkg, A, F, N, K, nout, seed=23)
-    # permute only together with eigenvecs: with well separated rows two permutations tie to rounding in fixperm's
-    # L1 cost, so the end-to-end comparison against the oracle's own forward is done without it
-    tr = O.TransformPseudoInv(eigenvecs=eigenvecs, permute=eigenvecs)
-    oiso = O.Iso(odata, om, O.setup(O.AdamRegularized(), om), target=tr, minibatch=0)
-    iso = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(),
-                  target=pkg.TransformPseudoInv(eigenvecs=eigenvecs, permute=eigenvecs), minibatch=0)
-    t_gpu = pkg.isotarget(iso)
-    assert t_gpu.shape == (nout, N)
-    # rows have L1 norm N (src/isotarget.jl:175)
-    np.testing.assert_allclose(np.abs(t_gpu.astype(np.float64)).sum(axis=1), N, rtol=1e-5)
-    # the host algebra against the oracle's on the SAME chi / K chi (LAPACK's Schur vectors are only defined up to
-    # sign, and the sign can flip under the 1e-6 difference between the f32 GPU forward and the fp64 oracle forward)
-    t_same = O.pseudoinv_target(tr, pkg.chis(iso), pkg.koopman(iso))
-    assert np.abs(t_gpu - t_same).max() <= 1e-5 * max(1.0, np.abs(t_same).max())
-    perms = np.stack([np.arange(N)] * 3)
-    if not eigenvecs:
-        t_ref = O.isotarget(tr, om, *odata.features)
-        assert np.abs(t_gpu - t_ref).max() <= 5e-4 * max(1.0, np.abs(t_ref).max())
-        pkg.run(iso, 3, 1, perms=perms)
-        O.run(oiso, 3, 1, perms=list(perms))
-        np.testing.assert_allclose(iso.losses, oiso.losses, rtol=2e-3)
-        assert np.abs(pkg.chis(iso) - O.chis(oiso)).max() <= 2e-4
-    else:
-        pkg.run(iso, 2, 1, perms=perms[:2])
-        assert len(iso.losses) == 2 and np.isfinite(iso.losses).all()
-    with pytest.raises(Exception):      # the engine itself has no device-side version of this transform
-        out = np.empty((nout, N), np.float32, order="F")
-        pkg.capi.check(iso._lib.isk_target(iso._h, pkg.capi.ptr_f32(out)))
     iso.close()
 
 

@@ -159,7 +159,7 @@ def test_optimizer_step_riding_on_the_gradient_kernel(gpu_pkg, widths, ln, mb, o
 @pytest.mark.parametrize("widths,ln,mb,N", [([60, 13, 4, 1], True, 32, 320), ([60, 13, 4, 1], True, 50, 330), ([231, 38, 6, 1], True, 100, 320),
                                             ([200, 142, 12, 3], True, 0, 1000), ([200, 142, 12, 3], True, 0, 1016), ([200, 40, 3], False, 64, 320),
                                             ([100, 20, 10, 5, 2], True, 64, 200), ([1700, 142, 12, 3], True, 1000, 2000)])
-def test_tail_step_riding_on_the_layer1_forward(gpu_pkg, widths, ln, mb, N):
+def test_tail_step_riding_on_the_layer1_forward(gpu_pkg, experimental_lib, widths, ln, mb, N):
     """option fuse_tail (narrow tail, pairnet default activations): train_fwd1n and the tail step are ONE launch -- the workgroup
     whose K-slice partial of a 32-row block arrives last runs the tail of those rows (kernels_train_fwdtail.hip).  The same partials
     are summed in the same order by the same device code, so losses, parameters and optimizer state must be BIT-identical to the
@@ -197,7 +197,7 @@ def test_tail_step_riding_on_the_layer1_forward(gpu_pkg, widths, ln, mb, N):
 
 @pytest.mark.parametrize("train_bf16", [0, 1])
 @pytest.mark.parametrize("ln", [False, True])
-def test_wide_network_epoch_images_gathered_up_front(gpu_pkg, train_bf16, ln):
+def test_wide_network_epoch_images_gathered_up_front(gpu_pkg, experimental_lib, train_bf16, ln):
     """wide networks (layered path), option epoch_gather: the batch images of every batch of an epoch are written by one launch in
     front of the epoch's steps instead of one launch per step.  Same images, same products: losses, parameters and optimizer state
     bit-identical to the per-step gather, in Float32 and in bf16 arithmetic, over epochs with different shuffle orders; and a
