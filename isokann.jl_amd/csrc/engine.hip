@@ -253,7 +253,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
         return fail(ISK_EINVAL, "TransformShiftscale only works with one dimensional chi functions");
     if (cfg->target_kind == ISK_TARGET_ISA && nout < 2)
         return fail(ISK_EINVAL, "TransformISA does not work with one dimensional chi functions");
-    if (cfg->target_kind == ISK_TARGET_ISA && nout > 8) return fail(ISK_EUNSUPPORTED, "ISA fixperm is brute force over d! permutations; d <= 8");
+    if (cfg->target_kind == ISK_TARGET_ISA && nout > ISK_ISA_HOST_MAXD) return fail(ISK_EUNSUPPORTED, "TransformISA: at most 64 outputs");
     for (int l = 1; l <= cfg->n_layers; ++l)
         if (cfg->widths[l] > 4096) return fail(ISK_EUNSUPPORTED, "layer width > 4096");
     int F = cfg->widths[0], Din = F;
@@ -723,7 +723,8 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
     HIPCHK(hipMalloc((void**)&e->d_part, (size_t)isk_train_part_floats(ts, (int)N) * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_perm, (size_t)N * sizeof(int)));
     HIPCHK(hipHostMalloc((void**)&e->h_perm, (size_t)N * sizeof(int), hipHostMallocDefault));
-    if (e->cfg.target_kind == ISK_TARGET_ISA) HIPCHK(hipMalloc((void**)&e->d_isa_work, (size_t)isk_isa_work_doubles(N, e->nout) * sizeof(double)));
+    if (e->cfg.target_kind == ISK_TARGET_ISA && e->nout <= ISK_ISA_DEV_MAXD)
+        HIPCHK(hipMalloc((void**)&e->d_isa_work, (size_t)isk_isa_work_doubles(N, e->nout) * sizeof(double)));
     if (e->layered) {
         int mh = 32;
         for (int l = 1; l < e->L; ++l) mh = std::max(mh, isk_pad32(e->cfg.widths[l]));
@@ -997,6 +998,26 @@ int compute_target(isk_engine* e, bool check, bool ahead) {
     side_featurize_hook(e);
     ScopedTimer t(e, ISK_T_TARGET);
     launch_kmean(e);
+    if (d > ISK_ISA_DEV_MAXD) {
+        // more outputs than the device chain is built for (its fixperm walks d! permutations): K chi and chi come to the host, the
+        // Float64 solve runs there with fixperm as an assignment problem, target and loss weights go back
+        const size_t nf = (size_t)e->N * d;
+        std::vector<float> ks(nf), chi(nf);
+        HIPCHK(hipMemcpyAsync(ks.data(), e->d_ks, nf * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(chi.data(), e->d_out + e->N * e->K * d, nf * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        std::vector<double> At, tgt;
+        std::vector<int> rp;
+        CHK(isa_solve_host(e, ks, chi, e->N, d, At, rp, &tgt));
+        std::vector<float> tf(nf), w;
+        for (size_t i = 0; i < nf; ++i) tf[i] = (float)tgt[i];
+        loss_weights_host(tf, e->N, d, w);
+        HIPCHK(hipMemcpyAsync(e->d_target, tf.data(), nf * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->d_lossw, w.data(), (size_t)d * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        e->have_target = true;
+        return ISK_OK;
+    }
     IsaArgs ia;
     ia.ks = e->d_ks; ia.chi = e->d_out + e->N * e->K * d; ia.work = e->d_isa_work; ia.target = e->d_target;
     ia.lossw = e->d_lossw; ia.status = e->d_status; ia.N = e->N; ia.d = d;

@@ -316,6 +316,12 @@ void bf16_weight_images_ensure(isk_engine* e, bool want_wt, bool want_wf);      
 int bf16_planes(const isk_engine* e);
 bool wide_forward_shape_ok(const isk_engine* e);         // the fused wide forward covers this network (hidden widths <= 512, nout <= 16)
 // ---- engine_isa_host.hip ---------------------------------------------------------------
+// ISA (src/isotarget.jl:74-127): up to ISK_ISA_DEV_MAXD outputs the whole target runs on the device (kernels_isa.hip: fixperm as the
+// reference's search over d! permutations); beyond, chi and K chi come to the host for the Float64 solve with fixperm as a linear
+// assignment problem (engine_isa_host.hip) -- as the reference itself does its ISA on the host (`|> cpu`, src/isotarget.jl:101-103)
+#define ISK_ISA_DEV_MAXD 8
+#define ISK_ISA_HOST_MAXD 64
+std::vector<int> assign_min_cost(const std::vector<double>& Cst, int d);
 int isa_solve_host(const isk_engine* e, const std::vector<float>& ks, const std::vector<float>& chi, long long N, int d,
                    std::vector<double>& At, std::vector<int>& rowperm, std::vector<double>* target_out);
 void loss_weights_host(const std::vector<float>& tgt, long long N, int d, std::vector<float>& w);

@@ -70,6 +70,7 @@ extern "C" int isk_dp_ks_chi_dev(isk_engine* e, void** ks_dev, void** chi_dev, i
 extern "C" int isk_dp_isa_dev(isk_engine* e, const float* ks_all_dev, const float* chi_all_dev, int64_t n_global, int64_t first) {
     CHK(need_data(e));
     if (e->cfg.target_kind != ISK_TARGET_ISA) return fail(ISK_EINVAL, "engine is not configured for TransformISA");
+    if (e->nout > ISK_ISA_DEV_MAXD) return fail(ISK_EUNSUPPORTED, "the device ISA chain covers up to 8 outputs: gather to the host (isk_dp_get_ks_chi, isk_isa_solve, isk_dp_isa_apply)");
     if (!ks_all_dev || !chi_all_dev || n_global < e->N || first < 0 || first + e->N > n_global) return fail(ISK_EINVAL, "bad gathered arrays");
     const int d = e->nout;
     if (e->isa_work_dp_rows < n_global) {

@@ -178,6 +178,7 @@ static int dp_target_native(isk_engine* e) {            // the caller has run fe
         return ISK_OK;
     }
     if (e->cfg.target_kind != ISK_TARGET_ISA) return fail(ISK_EINVAL, "host-side target transform: no native data-parallel run");
+    if (d > ISK_ISA_DEV_MAXD && !coll) return compute_target(e, false, e->cfg.featurize_every_iteration != 0);   // one rank: the host solve of isk_run
     CHK(forward_resident(e, 3, e->cfg.featurize_every_iteration != 0));
     side_featurize_hook(e);
     ScopedTimer t(e, ISK_T_TARGET);
@@ -261,6 +262,8 @@ extern "C" int isk_dp_run(isk_engine* e, int32_t n, int32_t epochs, int32_t loca
             if (perms[i] < 0 || perms[i] >= e->N) { bad(ISK_EINVAL, "permutation entry out of range"); break; }
     if (e->cfg.target_kind != ISK_TARGET_SHIFTSCALE && e->cfg.target_kind != ISK_TARGET_ISA)
         bad(ISK_EINVAL, "host-side target transform: no native data-parallel run");
+    if (e->cfg.target_kind == ISK_TARGET_ISA && e->nout > ISK_ISA_DEV_MAXD && coll)
+        bad(ISK_EUNSUPPORTED, "TransformISA with more than 8 outputs is solved on the host: use the host-driven data-parallel hooks");
     if (lst == ISK_OK && dp_prepare(e) != ISK_OK) { lst = ISK_ENOMEM; lmsg = isk_last_error(); }
     if (coll) CHK(dp_agree(e, lst, lmsg));
     else if (lst != ISK_OK) return fail(lst, lmsg);

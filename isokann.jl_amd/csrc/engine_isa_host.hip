@@ -2,6 +2,7 @@
 // the host-driven data-parallel hooks (ragged shards, gloo groups) and isk_isa_solve.  src/isotarget.jl:81-127 of the
 // reference; PCCAPlus.indexmap restated from the published algorithm.
 #include "engine.hpp"
+#include <limits>
 
 // ---- host Float64 ISA (src/isotarget.jl:81-127; PCCAPlus.indexmap restated) -----------
 static std::vector<int> indexmap_host(std::vector<double> X /* N x d row-major */, long long N, int d) {
@@ -112,6 +113,44 @@ static bool inv_sqrt_sym(std::vector<double>& C, int d) {
     return true;
 }
 
+// fixperm for larger systems: argmin over row permutations p of sum_i Cst[p_i * d + i] as a linear assignment problem -- what the
+// reference's own TODO names ("use the hungarian algorithm for larger systems", src/isotarget.jl:121); its brute force is d! steps.
+// Shortest augmenting paths with row / column potentials (Kuhn-Munkres in its O(d^3) form), Float64.  Where the minimiser is
+// unique -- always, up to exact ties of Float64 sums -- it is the brute force's.
+std::vector<int> assign_min_cost(const std::vector<double>& Cst, int d) {
+    const double INF = std::numeric_limits<double>::infinity();
+    std::vector<double> u(d + 1, 0.0), v(d + 1, 0.0);
+    std::vector<int> match(d + 1, 0), way(d + 1, 0);          // match[a'] = chi row assigned to target row a' (1-based, 0 = none)
+    for (int i = 1; i <= d; ++i) {                           // rows: chi row i - 1; columns: target row a - 1; cost = Cst[(a-1) d + (i-1)]
+        match[0] = i;
+        int j0 = 0;
+        std::vector<double> minv(d + 1, INF);
+        std::vector<char> used(d + 1, 0);
+        do {
+            used[j0] = 1;
+            const int i0 = match[j0];
+            double delta = INF;
+            int j1 = 0;
+            for (int j = 1; j <= d; ++j) {
+                if (used[j]) continue;
+                const double cur = Cst[(size_t)(j - 1) * d + (i0 - 1)] - u[i0] - v[j];
+                if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+                if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+            }
+            if (!(delta < INF)) { j1 = 0; for (int j = 1; j <= d; ++j) if (!used[j]) { j1 = j; break; } delta = 0; }   // non-finite costs: any completion
+            for (int j = 0; j <= d; ++j) {
+                if (used[j]) { u[match[j]] += delta; v[j] -= delta; }
+                else minv[j] -= delta;
+            }
+            j0 = j1;
+        } while (match[j0] != 0);
+        do { const int j1 = way[j0]; match[j0] = match[j1]; j0 = j1; } while (j0);
+    }
+    std::vector<int> p(d);
+    for (int a = 1; a <= d; ++a) p[match[a] - 1] = a - 1;    // p[i] = target row that lands on chi row i
+    return p;
+}
+
 // ks, chi: [N][d] (fp32, as downloaded).  Produces At (A' row-major: target = At * ks[n]) and the row permutation.
 int isa_solve_host(const isk_engine* e, const std::vector<float>& ks, const std::vector<float>& chi, long long N, int d,
                           std::vector<double>& At, std::vector<int>& rowperm, std::vector<double>* target_out) {
@@ -160,16 +199,21 @@ int isa_solve_host(const isk_engine* e, const std::vector<float>& ks, const std:
         for (long long n = 0; n < N; ++n)
             for (int a = 0; a < d; ++a)
                 for (int i = 0; i < d; ++i) Cst[a * d + i] += std::fabs(tgt[n * d + a] - (double)chi[n * d + i]);
-        std::vector<int> p(d), best(d);
-        std::iota(p.begin(), p.end(), 0);
-        double bc = INFINITY;
-        bool first = true;
-        do {
-            double c = 0;
-            for (int i = 0; i < d; ++i) c += Cst[p[i] * d + i];
-            if (first || c < bc) { bc = c; best = p; first = false; }
-        } while (std::next_permutation(p.begin(), p.end()));
-        rowperm = best;
+        if (d <= ISK_ISA_DEV_MAXD) {
+            // the reference's search itself (and the device chain's): every permutation in lexicographic order, first minimiser
+            std::vector<int> p(d), best(d);
+            std::iota(p.begin(), p.end(), 0);
+            double bc = INFINITY;
+            bool first = true;
+            do {
+                double c = 0;
+                for (int i = 0; i < d; ++i) c += Cst[p[i] * d + i];
+                if (first || c < bc) { bc = c; best = p; first = false; }
+            } while (std::next_permutation(p.begin(), p.end()));
+            rowperm = best;
+        } else {
+            rowperm = assign_min_cost(Cst, d);
+        }
     }
     if (target_out) {
         target_out->resize((size_t)N * d);
@@ -195,7 +239,7 @@ void loss_weights_host(const std::vector<float>& tgt, long long N, int d, std::v
 
 extern "C" int isk_isa_solve(const float* ks, const float* chi, int64_t N, int32_t d, int32_t permute, int32_t whitening,
                              double* At, int32_t* rowperm) {
-    if (!ks || !chi || !At || !rowperm || N < 1 || d < 2 || d > 8) return fail(ISK_EINVAL, "bad argument");
+    if (!ks || !chi || !At || !rowperm || N < 1 || d < 2 || d > ISK_ISA_HOST_MAXD) return fail(ISK_EINVAL, "bad argument");
     isk_engine tmp;
     tmp.cfg.isa_permute = permute; tmp.cfg.isa_whitening = whitening;
     std::vector<float> k(ks, ks + (size_t)N * d), c(chi, chi + (size_t)N * d);

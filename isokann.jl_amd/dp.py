@@ -141,8 +141,8 @@ class HipLocal:
     def isa_device(self, comm, counts) -> bool:
         """device-resident path: all-gather the local ks / chi slices with RCCL and run the Float64
         ISA kernel on the gathered arrays on every rank (no host round trip).  Needs equal shards."""
-        if len(set(counts)) != 1 or (comm.on and comm.dist.get_backend() != "nccl"):
-            return False
+        if len(set(counts)) != 1 or (comm.on and comm.dist.get_backend() != "nccl") or self.nout > 8:
+            return False                      # (more than 8 outputs: the Float64 solve runs on the host, isk_isa_solve)
         torch = comm.torch
         ks_p, chi_p, n = C.c_void_p(), C.c_void_p(), C.c_int64()
         capi.check(self.lib.isk_dp_ks_chi_dev(self.h, C.byref(ks_p), C.byref(chi_p), C.byref(n)))
@@ -307,6 +307,7 @@ def dp_run(local, comm: Comm, n: int, epochs: int, minibatch: int, rng: Optional
     import os
     if (hasattr(local, "comm_init_native") and len(set(counts)) == 1 and os.environ.get("ISK_DP_HOST", "0") != "1"
             and (minibatch == 0 or comm.world == 1 or local.n_local * comm.world >= minibatch) and n * epochs > 0
+            and not (comm.world > 1 and getattr(local, "kind", "") == "isa" and getattr(local, "nout", 0) > 8)
             and _native_ready(local, comm)):
         # equal shards on an RCCL group: the whole run inside the engine, collectives on its stream
         bl, nb, gb = batch_plan(minibatch, counts, comm.world, local.n_local)

@@ -400,6 +400,14 @@ def fixperm(new: np.ndarray, old: np.ndarray) -> np.ndarray:
 
 def fixperm_index(new, old) -> Tuple[int, ...]:
     n = new.shape[0]
+    if n > 8:
+        # "TODO: use the hungarian algorithm for larger systems" (src/isotarget.jl:121): the reference's own search is n! steps.
+        # cost(p) = sum_i sum_n |new[p_i, n] - old[i, n]| is a linear assignment problem on C[a, i] = sum_n |new[a, n] - old[i, n]|;
+        # its minimiser is the brute force's wherever that is unique.  scipy's solver: an implementation independent of the product's.
+        from scipy.optimize import linear_sum_assignment
+        C = np.abs(new[:, None, :] - old[None, :, :]).sum(axis=2)          # C[a, i]
+        rows, cols = linear_sum_assignment(C.T)                            # for every old row i (rows) a new row a (cols)
+        return tuple(int(a) for a in cols[np.argsort(rows)])
     best, bestp = None, None
     for p in itertools.permutations(range(n)):
         c = np.abs(new[list(p), :] - old).sum()

@@ -327,3 +327,37 @@ def test_product_pseudoinv_host_algebra_has_analytic_answers(pkg):
     assert np.abs(t3 - chi).sum() <= best * (1 + 1e-6)
     with pytest.raises(ValueError):
         api._pseudoinv_target(plain, chi[:1], kchi[:1])
+
+
+@pytest.mark.parametrize("d", [9, 12, 20])
+def test_isa_solve_beyond_eight_outputs_uses_an_assignment_solve(pkg, d):
+    """isk_isa_solve is host code (no GPU): TransformISA for d > 8 (src/isotarget.jl:81-127).  fixperm there is the linear
+    assignment problem the reference's TODO names (src/isotarget.jl:121) instead of d! permutations; checked against (1) the
+    oracle, whose solver is scipy's, (2) the planted answer: chi = a known row permutation of the ISA target, (3) at d = 9 the
+    reference's own brute force over all 362 880 permutations"""
+    from oracle import isokann_oracle as O
+    lib = pkg.capi.load()
+    rng = np.random.default_rng(40 + d)
+    N = 600
+    # membership-like K chi: a noisy convex mixture of d vertices, so the simplex is well conditioned
+    V = rng.uniform(0.2, 1.0, size=(d, d)) + 2.0 * np.eye(d)
+    Wt = rng.dirichlet(np.ones(d) * 0.3, size=N)
+    ks = (Wt @ V).T.astype(np.float32)                                     # (d, N)
+    A = O.myisa(ks.T.astype(np.float64))
+    t = A.T @ ks.astype(np.float64)
+    planted = rng.permutation(d)
+    chi = (t[planted] + 0.01 * rng.normal(size=t.shape)).astype(np.float32)     # old = the target in another row order, plus noise
+    At = np.zeros(d * d, np.float64)
+    rp = np.zeros(d, np.int32)
+    pkg.capi.check(lib.isk_isa_solve(pkg.capi.ptr_f32(np.asfortranarray(ks)), pkg.capi.ptr_f32(np.asfortranarray(chi)), N, d, 1, 0,
+                                     pkg.capi.ptr_f64(At), pkg.capi.ptr_i32(rp)))
+    np.testing.assert_allclose(At.reshape(d, d), A.T, rtol=1e-9, atol=1e-12)             # target = At * ks
+    assert list(rp) == list(planted)
+    assert tuple(rp) == O.fixperm_index(t, chi.astype(np.float64))
+    if d == 9:
+        import itertools
+        C = np.abs(t[:, None, :] - chi.astype(np.float64)[None, :, :]).sum(axis=2)       # C[a, i]
+        best = min(itertools.permutations(range(d)), key=lambda p: sum(C[p[i], i] for i in range(d)))
+        assert tuple(rp) == best
+    assert lib.isk_isa_solve(pkg.capi.ptr_f32(np.asfortranarray(ks)), pkg.capi.ptr_f32(np.asfortranarray(chi)), N, 65, 1, 0,
+                             pkg.capi.ptr_f64(np.zeros(65 * 65)), pkg.capi.ptr_i32(np.zeros(65, np.int32))) == pkg.capi.EINVAL

@@ -92,13 +92,13 @@ def test_villin_shape_pullback_matches_torch_autograd(gpu_pkg):
 
 def test_documented_shape_limits_are_error_codes(gpu_pkg):
     """what the kernels do not cover is refused with ISK_EUNSUPPORTED at isk_create / at the call, never computed wrongly:
-    TransformISA beyond 8 outputs (the reference's fixperm takes any n, src/isotarget.jl:120-127: d! permutations), a layer wider
-    than 4096, the coordinate pullback beyond 2048 features (src/utils/pairdists.jl:153-196 has no such bound)"""
+    TransformISA beyond 64 outputs (up to 8 the device chain, up to 64 the host solve: test_isa_with_more_than_eight_outputs), a
+    layer wider than 4096, the coordinate pullback beyond 2048 features (src/utils/pairdists.jl:153-196 has no such bound)"""
     pkg = gpu_pkg
     rng = np.random.default_rng(0)
     xs, ys = rng.normal(size=(12, 40)), rng.normal(size=(12, 2, 40))
     with pytest.raises(pkg.capi.IskError) as ei:
-        pkg.Iso(pkg.SimulationData(xs, ys, pkg.identity), model=pkg.densenet([12, 16, 9], layernorm=True), target=pkg.TransformISA(), minibatch=0)
+        pkg.Iso(pkg.SimulationData(xs, ys, pkg.identity), model=pkg.densenet([12, 80, 65], layernorm=True), target=pkg.TransformISA(), minibatch=0)
     assert ei.value.status == pkg.capi.EUNSUPPORTED
     with pytest.raises(pkg.capi.IskError) as ei:
         pkg.Iso(pkg.SimulationData(xs, ys, pkg.identity), model=pkg.densenet([12, 4100, 1], layernorm=False), minibatch=0)
@@ -305,3 +305,31 @@ def test_wide_network_backward_head_as_one_launch(gpu_pkg, widths, N, mb):
             np.testing.assert_allclose(isos[1].model.get_params(), om.get_flat(), atol=5e-5, rtol=5e-4)
         for iso in isos.values():
             iso.close()
+
+
+@pytest.mark.parametrize("d,every_iter", [(9, False), (12, True)])
+def test_isa_with_more_than_eight_outputs(gpu_pkg, d, every_iter):
+    """TransformISA takes any number of outputs in the reference (src/isotarget.jl:100-127; fixperm walks d! permutations,
+    "TODO: use the hungarian algorithm for larger systems").  Up to 8 the target runs on the device; beyond, chi and K chi come to
+    the host for the Float64 solve with fixperm as an assignment problem.  Target, known answer (the simplex columns are unit
+    vectors) and three training iterations against the oracle."""
+    pkg = gpu_pkg
+    from tests.test_gpu_parity import _coords_case, _mk_model
+    data, odata, om = _coords_case(pkg, 24, 120, 320, 3, d, seed=70 + d)
+    iso = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(1e-3, 1e-4), target=pkg.TransformISA(), minibatch=64,
+                  featurize_every_iteration=every_iter)
+    t = pkg.isotarget(iso)
+    want = O.isotarget(O.TransformISA(), om, *odata.features)
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(t, want, atol=5e-4 * scale)
+    idx = O.indexmap(pkg.koopman(iso).astype(np.float64).T)
+    sel = t[:, idx]
+    assert np.allclose(np.sort(sel, axis=0)[-1], 1.0, atol=1e-3) and np.allclose(np.abs(sel).sum(axis=0), 1.0, atol=1e-2)
+    oiso = O.Iso(odata, om, O.setup(O.AdamRegularized(1e-3, 1e-4), om), target=O.TransformISA(), minibatch=64)
+    rng = np.random.default_rng(d)
+    perms = np.stack([rng.permutation(320) for _ in range(3)])
+    pkg.run(iso, 3, 1, perms=perms)
+    O.run(oiso, 3, 1, perms=list(perms))
+    np.testing.assert_allclose(iso.losses, oiso.losses, rtol=5e-3)
+    np.testing.assert_allclose(pkg.chis(iso), O.chis(oiso), atol=2e-4)
+    iso.close()
