@@ -411,11 +411,16 @@ def main():
 
     # roofline of the dominant kernel (fused MLP forward), HIP events on the engine's stream, outside the timed region
     roof = None
+    # (every rank runs the profiled iterations: in a data-parallel run they contain collectives.  Until round 5 only rank 0 ran
+    # them -- found by the two-rank rehearsal on one GPU (tests/test_gpu_bench_rehearsal.py): rank 0 waited in its first all-reduce
+    # for peers that had moved on)
+    arm("profiled steps")
+    iso.timers(enable=True, reset=True)
+    step(args.profile_steps)
+    sync(); barrier(); sync()
+    tm = iso.timers(enable=False)
+    arm("")
     if rank == 0:
-        iso.timers(enable=True, reset=True)
-        step(args.profile_steps)
-        sync()
-        tm = iso.timers(enable=False)
         ffwd, fwd_flops, step_flops = algorithmic_flops(widths, N, K, nb_rows)
         ms, cnt = tm["fwd_ys"]
         # HBM bytes per launch of this kernel: NOT measured in this run (PMC counters need rocprofv3 passes of their own) -- the

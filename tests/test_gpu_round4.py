@@ -311,25 +311,29 @@ def test_wide_network_backward_head_as_one_launch(gpu_pkg, widths, N, mb):
 def test_isa_with_more_than_eight_outputs(gpu_pkg, d, every_iter):
     """TransformISA takes any number of outputs in the reference (src/isotarget.jl:100-127; fixperm walks d! permutations,
     "TODO: use the hungarian algorithm for larger systems").  Up to 8 the target runs on the device; beyond, chi and K chi come to
-    the host for the Float64 solve with fixperm as an assignment problem.  Target, known answer (the simplex columns are unit
-    vectors) and three training iterations against the oracle."""
+    the host for the Float64 solve with fixperm as an assignment problem.  At a random initialisation a 9- or 12-vertex simplex is
+    badly conditioned (the forward's 2e-7 is amplified beyond any tolerance), so the stages are checked on their own: the target
+    against the oracle's Float64 solve evaluated on the engine's OWN chi / K chi (as the full-N C3 test does), its known answer,
+    and one training epoch on that target against the oracle's train_batch!."""
     pkg = gpu_pkg
     from tests.test_gpu_parity import _coords_case, _mk_model
-    data, odata, om = _coords_case(pkg, 24, 120, 320, 3, d, seed=70 + d)
+    N = 320
+    data, odata, om = _coords_case(pkg, 24, 120, N, 3, d, seed=70 + d)
     iso = pkg.Iso(data, model=_mk_model(pkg, om), opt=pkg.AdamRegularized(1e-3, 1e-4), target=pkg.TransformISA(), minibatch=64,
                   featurize_every_iteration=every_iter)
+    np.testing.assert_allclose(pkg.chis(iso), om(odata.features[0]), atol=2e-5)
     t = pkg.isotarget(iso)
-    want = O.isotarget(O.TransformISA(), om, *odata.features)
+    k64, c64 = pkg.koopman(iso).astype(np.float64), pkg.chis(iso).astype(np.float64)
+    want = O.fixperm(O.myisa(k64.T).T @ k64, c64)
+    assert np.abs(t - want).max() <= 2e-5 * np.abs(want).max()
+    sel = t[:, O.indexmap(k64.T)]                                   # the simplex columns are unit vectors (in some row order)
     scale = np.abs(want).max()
-    np.testing.assert_allclose(t, want, atol=5e-4 * scale)
-    idx = O.indexmap(pkg.koopman(iso).astype(np.float64).T)
-    sel = t[:, idx]
-    assert np.allclose(np.sort(sel, axis=0)[-1], 1.0, atol=1e-3) and np.allclose(np.abs(sel).sum(axis=0), 1.0, atol=1e-2)
-    oiso = O.Iso(odata, om, O.setup(O.AdamRegularized(1e-3, 1e-4), om), target=O.TransformISA(), minibatch=64)
-    rng = np.random.default_rng(d)
-    perms = np.stack([rng.permutation(320) for _ in range(3)])
-    pkg.run(iso, 3, 1, perms=perms)
-    O.run(oiso, 3, 1, perms=list(perms))
-    np.testing.assert_allclose(iso.losses, oiso.losses, rtol=5e-3)
-    np.testing.assert_allclose(pkg.chis(iso), O.chis(oiso), atol=2e-4)
+    assert np.allclose(np.sort(sel, axis=0)[-1], 1.0, atol=1e-5 * scale) and np.allclose(np.abs(sel).sum(axis=0), 1.0, atol=1e-4 * scale)
+    # one epoch (five optimizer steps of 64 rows) on that target
+    perm = np.random.default_rng(d).permutation(N)
+    st = O.setup(O.AdamRegularized(1e-3, 1e-4), om)
+    lo = O.train_batch(om, odata.features[0], t.astype(np.float64), st, 64, perm=perm)
+    pkg.run(iso, 1, 1, perms=perm[None, :])
+    np.testing.assert_allclose(iso.losses[-1], lo, rtol=2e-4)
+    np.testing.assert_allclose(pkg.chis(iso), om(odata.features[0]), atol=5e-5)
     iso.close()
