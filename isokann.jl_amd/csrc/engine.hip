@@ -83,6 +83,7 @@ static void free_data(isk_engine* e) {
     e->d_xscale = e->d_xscale_alt = e->d_xs32 = nullptr;
     free_dev(e->d_target); free_dev(e->d_kw); e->d_kw = nullptr; free_dev(e->d_z1); free_dev(e->d_tail_cnt); e->d_tail_cnt = nullptr; free_dev(e->d_delta1); free_dev(e->d_part); free_dev(e->d_perm); free_dev(e->d_isa_work);
     e->d_isa_work = nullptr;
+    free_dev(e->d_ks64); e->d_ks64 = nullptr;
     free_dev(e->d_actA); free_dev(e->d_actB); e->d_actA = e->d_actB = nullptr;
     free_dev(e->dbg_st); free_dev(e->dbg_rows); e->dbg_st = nullptr; e->dbg_rows = nullptr;      // (dbg_rows is sized by the data)
     bf16_train_release(e);
@@ -441,7 +442,7 @@ extern "C" void isk_destroy(isk_engine* e) {
     free_dev(e->d_G0); free_dev(e->d_D0); free_dev(e->d_zero);
     for (int l = 0; l < ISK_MAX_LAYERS; ++l) { free_dev(e->b16.Wt[l]); free_dev(e->b16.Wf[l]); }
     dp_comm_release(e);
-    free_dev(e->d_gks); free_dev(e->d_gchi);
+    free_dev(e->d_gks); free_dev(e->d_gchi); free_dev(e->d_gks64);
     drain_timers(e);
     for (auto& ep : e->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (e->ev_fwd_done) (void)hipEventDestroy(e->ev_fwd_done);
@@ -723,8 +724,10 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
     HIPCHK(hipMalloc((void**)&e->d_part, (size_t)isk_train_part_floats(ts, (int)N) * sizeof(float)));
     HIPCHK(hipMalloc((void**)&e->d_perm, (size_t)N * sizeof(int)));
     HIPCHK(hipHostMalloc((void**)&e->h_perm, (size_t)N * sizeof(int), hipHostMallocDefault));
-    if (e->cfg.target_kind == ISK_TARGET_ISA && e->nout <= ISK_ISA_DEV_MAXD)
+    if (e->cfg.target_kind == ISK_TARGET_ISA && e->nout <= ISK_ISA_DEV_MAXD) {
         HIPCHK(hipMalloc((void**)&e->d_isa_work, (size_t)isk_isa_work_doubles(N, e->nout) * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&e->d_ks64, (size_t)N * e->nout * sizeof(double)));       // K chi unrounded, for the Float64 solve
+    }
     if (e->layered) {
         int mh = 32;
         for (int l = 1; l < e->L; ++l) mh = std::max(mh, isk_pad32(e->cfg.widths[l]));
@@ -937,7 +940,7 @@ hipError_t zero_loss_acc(isk_engine* e) {
 
 void launch_kmean(isk_engine* e) {
     KmeanArgs k;
-    k.out_ys = e->d_out; k.ks = e->d_ks; k.w = e->d_kw; k.N = e->N; k.K = (int)e->K; k.nout = e->nout;
+    k.out_ys = e->d_out; k.ks = e->d_ks; k.ks64 = e->d_ks64; k.w = e->d_kw; k.N = e->N; k.K = (int)e->K; k.nout = e->nout;
     k.zero2 = e->d_loss_acc;             // the coming epoch's loss accumulator: zeroed here instead of by a memset node of its own
     isk_launch_kmean(k, e->stream);
     e->loss_acc_zeroed = true;
@@ -1019,7 +1022,7 @@ int compute_target(isk_engine* e, bool check, bool ahead) {
         return ISK_OK;
     }
     IsaArgs ia;
-    ia.ks = e->d_ks; ia.chi = e->d_out + e->N * e->K * d; ia.work = e->d_isa_work; ia.target = e->d_target;
+    ia.ks = e->d_ks; ia.ks64 = e->d_ks64; ia.chi = e->d_out + e->N * e->K * d; ia.work = e->d_isa_work; ia.target = e->d_target;
     ia.lossw = e->d_lossw; ia.status = e->d_status; ia.N = e->N; ia.d = d;
     ia.permute = e->cfg.isa_permute; ia.whitening = e->cfg.isa_whitening;
     ia.out_first = 0; ia.out_count = e->N;

@@ -201,6 +201,8 @@ struct isk_engine {
     double* d_At = nullptr;      // host-driven data-parallel ISA: the Float64 simplex inverse (applied in Float64, as on the device path)
     int* d_rowperm = nullptr;
     double* d_isa_work = nullptr;
+    double* d_ks64 = nullptr;                     // K chi of the resident data as the K-mean summed it in double (IsaArgs.ks64)
+    double* d_gks64 = nullptr;                    // ... all-gathered (native data-parallel run)
     // native data-parallel run (isk_dp_run): RCCL communicator + gathered ks / chi
     ncclComm_t comm = nullptr;
     int dp_rank = 0, dp_world = 1;
@@ -285,6 +287,7 @@ void launch_kmean(isk_engine* e);
 hipError_t zero_loss_acc(isk_engine* e);
 int check_status(isk_engine* e);
 int compute_target(isk_engine* e, bool check, bool ahead = false);
+int dp_isa_dev(isk_engine* e, const float* ks_all_dev, const double* ks64_all_dev, const float* chi_all_dev, long long n_global, long long first);
 int pick_slabs(int B);
 void layered_epoch_gather(isk_engine* e, const int* d_perm, long long bs, long long nb);
 void layered_epoch_end(isk_engine* e);

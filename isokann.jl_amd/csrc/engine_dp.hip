@@ -68,10 +68,15 @@ extern "C" int isk_dp_ks_chi_dev(isk_engine* e, void** ks_dev, void** chi_dev, i
 }
 
 extern "C" int isk_dp_isa_dev(isk_engine* e, const float* ks_all_dev, const float* chi_all_dev, int64_t n_global, int64_t first) {
+    return dp_isa_dev(e, ks_all_dev, nullptr, chi_all_dev, n_global, first);
+}
+// ks64_all_dev: the gathered K chi as the K-means summed it in double (the engine's own native run), or nullptr (hosts that gather
+// the Float32 slices themselves)
+int dp_isa_dev(isk_engine* e, const float* ks_all_dev, const double* ks64_all_dev, const float* chi_all_dev, long long n_global, long long first) {
     CHK(need_data(e));
     if (e->cfg.target_kind != ISK_TARGET_ISA) return fail(ISK_EINVAL, "engine is not configured for TransformISA");
     if (e->nout > ISK_ISA_DEV_MAXD) return fail(ISK_EUNSUPPORTED, "the device ISA chain covers up to 8 outputs: gather to the host (isk_dp_get_ks_chi, isk_isa_solve, isk_dp_isa_apply)");
-    if (!ks_all_dev || !chi_all_dev || n_global < e->N || first < 0 || first + e->N > n_global) return fail(ISK_EINVAL, "bad gathered arrays");
+    if ((!ks_all_dev && !ks64_all_dev) || !chi_all_dev || n_global < e->N || first < 0 || first + e->N > n_global) return fail(ISK_EINVAL, "bad gathered arrays");
     const int d = e->nout;
     if (e->isa_work_dp_rows < n_global) {
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -81,7 +86,7 @@ extern "C" int isk_dp_isa_dev(isk_engine* e, const float* ks_all_dev, const floa
         e->isa_work_dp_rows = n_global;
     }
     IsaArgs ia;
-    ia.ks = ks_all_dev; ia.chi = chi_all_dev; ia.work = e->d_isa_work_dp; ia.target = e->d_target;
+    ia.ks = ks_all_dev; ia.ks64 = ks64_all_dev; ia.chi = chi_all_dev; ia.work = e->d_isa_work_dp; ia.target = e->d_target;
     ia.lossw = e->d_lossw; ia.status = e->d_status; ia.N = n_global; ia.d = d;
     ia.permute = e->cfg.isa_permute; ia.whitening = e->cfg.isa_whitening;
     ia.out_first = first; ia.out_count = e->N;

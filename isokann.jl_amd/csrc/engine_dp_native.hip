@@ -117,10 +117,11 @@ static int dp_prepare(isk_engine* e) {
     const long long n_global = e->N * e->dp_world;
     if (e->gather_rows < n_global) {
         HIPCHK(hipStreamSynchronize(e->stream));
-        free_dev(e->d_gks); free_dev(e->d_gchi);
-        e->d_gks = e->d_gchi = nullptr; e->gather_rows = 0;
+        free_dev(e->d_gks); free_dev(e->d_gchi); free_dev(e->d_gks64);
+        e->d_gks = e->d_gchi = nullptr; e->d_gks64 = nullptr; e->gather_rows = 0;
         HIPCHK(hipMalloc((void**)&e->d_gks, (size_t)n_global * d * sizeof(float)));
         HIPCHK(hipMalloc((void**)&e->d_gchi, (size_t)n_global * d * sizeof(float)));
+        HIPCHK(hipMalloc((void**)&e->d_gks64, (size_t)n_global * d * sizeof(double)));
         e->gather_rows = n_global;
     }
     if (e->isa_work_dp_rows < n_global) {
@@ -184,6 +185,7 @@ static int dp_target_native(isk_engine* e) {            // the caller has run fe
     ScopedTimer t(e, ISK_T_TARGET);
     launch_kmean(e);
     const float* ks = e->d_ks;
+    const double* ks64 = e->d_ks64;                       // K chi unrounded (the K-mean's double sums): what the Float64 solve reads
     const float* chi = e->d_out + e->N * e->K * d;
     long long n_global = e->N, first = 0;
     if (coll) {
@@ -191,13 +193,15 @@ static int dp_target_native(isk_engine* e) {            // the caller has run fe
         if (e->gather_rows < n_global) return fail(ISK_ESTATE, "gather buffers not prepared");      // dp_prepare ran before the agreement
         // one group: RCCL aggregates the two small gathers into a single launch (each is latency, not bytes)
         if (g_rccl.GroupStart) RCCLCHK(g_rccl.GroupStart());
-        const ncclResult_t r1 = g_rccl.AllGather(ks, e->d_gks, (size_t)e->N * d, ncclFloat, e->comm, e->stream);
+        const ncclResult_t r1 = ks64 ? g_rccl.AllGather(ks64, e->d_gks64, (size_t)e->N * d, ncclDouble, e->comm, e->stream)
+                                     : g_rccl.AllGather(ks, e->d_gks, (size_t)e->N * d, ncclFloat, e->comm, e->stream);
         const ncclResult_t r2 = g_rccl.AllGather(chi, e->d_gchi, (size_t)e->N * d, ncclFloat, e->comm, e->stream);
         const ncclResult_t r3 = g_rccl.GroupEnd ? g_rccl.GroupEnd() : ncclSuccess;      // always closed, whatever r1 / r2 say
         RCCLCHK(r1); RCCLCHK(r2); RCCLCHK(r3);
         ks = e->d_gks; chi = e->d_gchi;
+        if (ks64) ks64 = e->d_gks64;
     }
-    return isk_dp_isa_dev(e, ks, chi, n_global, first);
+    return dp_isa_dev(e, ks, ks64, chi, n_global, first);
 }
 
 // a rank-local failure inside the step loop: remember the first one, raise the device flag the gradient kernels copy into the

@@ -301,6 +301,7 @@ void isk_launch_fold(const FoldArgs& a, hipStream_t st);
 struct KmeanArgs {
     const float* out_ys;    // [N*K][nout]
     float* ks;              // [N][nout]
+    double* ks64 = nullptr; // optional [N][nout]: the same means UNROUNDED, for the Float64 simplex solve (IsaArgs.ks64)
     const float* w;         // optional [N][K] sample weights (WeightedSamples / Girsanov): sum_k w*f / K
     long long N; int K, nout;
     double* zero2;          // optional: the coming epoch's accumulator [loss sum, collapsed flag, (status word), peer flag]: elements 0, 1
@@ -317,6 +318,11 @@ void isk_launch_isa_apply(const float* ks, const double* At /*[d*d] device, row-
 // device-side Float64 inner simplex algorithm + fixperm + loss weights (single workgroup)
 struct IsaArgs {
     const float* ks;        // [N][d]
+    const double* ks64 = nullptr;   // optional [N][d]: K chi as the K-mean summed it in double, before the rounding to Float32.  The reference
+                            // rounds here (expectation returns the model's eltype, src/isotarget.jl:18,103, and myisa widens it again:
+                            // :82); on villin-like data that one rounding, amplified by the simplex inverse iteration after iteration, IS
+                            // the "fp32 floor" of a run against a Float64 trajectory (scripts/floor_study.py: 2.5e-5 after 10 iterations
+                            // with everything else exact).  A wider intermediate, never a less accurate one.  nullptr: widen ks
     const float* chi;       // [N][d]
     double* work;           // isk_isa_work_doubles(N, d) Float64 scratch
     float* target;          // [N][d]

@@ -774,7 +774,11 @@ __global__ __launch_bounds__(256) void kmean_kernel(KmeanArgs a) {
         double s = 0.0;
         for (int i = lane; i < tot; i += WAVE) s += w ? (double)base[i] * (double)w[i / a.nout] : (double)base[i];
         for (int o = 32; o >= a.nout; o >>= 1) s += __shfl_xor(s, o, WAVE);
-        if (lane < a.nout) a.ks[n * a.nout + lane] = (float)(s / (double)a.K);
+        if (lane < a.nout) {
+            const double m = s / (double)a.K;
+            a.ks[n * a.nout + lane] = (float)m;
+            if (a.ks64) a.ks64[n * a.nout + lane] = m;
+        }
     } else if (a.nout < 64) {
         // nout does not divide 64 (C3: nout = 3): the first W = 64 - 64 % nout lanes walk the K x nout block with stride W,
         // so a lane keeps one output index; the W / nout partial sums per output are combined through LDS
@@ -790,13 +794,17 @@ __global__ __launch_bounds__(256) void kmean_kernel(KmeanArgs a) {
         if (lane < a.nout) {
             double t = 0.0;
             for (int j = lane; j < W; j += a.nout) t += part[wv][j];
-            a.ks[n * a.nout + lane] = (float)(t / (double)a.K);
+            const double m = t / (double)a.K;
+            a.ks[n * a.nout + lane] = (float)m;
+            if (a.ks64) a.ks64[n * a.nout + lane] = m;
         }
     } else {
         for (int o = lane; o < a.nout; o += WAVE) {
             double s = 0.0;
             for (int k = 0; k < a.K; ++k) s += w ? (double)base[k * a.nout + o] * (double)w[k] : (double)base[k * a.nout + o];
-            a.ks[n * a.nout + o] = (float)(s / (double)a.K);
+            const double m = s / (double)a.K;
+            a.ks[n * a.nout + o] = (float)m;
+            if (a.ks64) a.ks64[n * a.nout + o] = m;
         }
     }
 }

@@ -18,6 +18,9 @@
 #define ISA_ROWS (ISA_T * ISA_R)
 #define ISA_MAXD 8
 
+// K chi as the simplex solve sees it: the unrounded double K-mean where the engine has it (IsaArgs.ks64), else the widened Float32
+__device__ __forceinline__ double isa_ks(const IsaArgs& a, long long i) { return a.ks64 ? a.ks64[i] : (double)a.ks[i]; }
+
 // partial record of one workgroup: [0] max norm, [1] row index (as double), [2..2+D) that row of X
 template <int D> struct IsaLayout { static constexpr int PREC = 2 + D; };
 
@@ -172,12 +175,12 @@ __global__ __launch_bounds__(ISA_T) void isa_init_kernel(IsaArgs a, double* __re
 #pragma unroll
     for (int i = 0; i < D * D; ++i) cm[i] = 0;
     const long long base = (long long)blockIdx.x * ISA_ROWS + threadIdx.x;
-    float kv[ISA_R][D];
+    double kv[ISA_R][D];
 #pragma unroll
     for (int r = 0; r < ISA_R; ++r) {
         const long long n = base + (long long)r * ISA_T;
 #pragma unroll
-        for (int k = 0; k < D; ++k) kv[r][k] = (n < N) ? a.ks[n * D + k] : 0.f;
+        for (int k = 0; k < D; ++k) kv[r][k] = (n < N) ? isa_ks(a, n * D + k) : 0.0;
     }
 #pragma unroll
     for (int r = 0; r < ISA_R; ++r) {
@@ -393,17 +396,18 @@ __global__ __launch_bounds__(ISA_T) void isa_target_kernel(IsaArgs a, const doub
     double* T = a.work + N * D;
     // this thread's ks / chi rows: requested before the argmax is finalized and thread 0 inverts the simplex
     const long long base = (long long)blockIdx.x * ISA_ROWS + threadIdx.x;
-    float kv[ISA_R][D], cv[ISA_R][D];
+    double kv[ISA_R][D];
+    float cv[ISA_R][D];
 #pragma unroll
     for (int r = 0; r < ISA_R; ++r) {
         const long long n = base + (long long)r * ISA_T;
 #pragma unroll
-        for (int k = 0; k < D; ++k) { kv[r][k] = (n < N) ? a.ks[n * D + k] : 0.f; cv[r][k] = (n < N) ? a.chi[n * D + k] : 0.f; }
+        for (int k = 0; k < D; ++k) { kv[r][k] = (n < N) ? isa_ks(a, n * D + k) : 0.0; cv[r][k] = (n < N) ? a.chi[n * D + k] : 0.f; }
     }
     // thread 0: the simplex rows of the earlier steps (indices written by the kernels before this one) are requested before this
     // kernel's own argmax is finalized -- two dependent round trips that used to stand behind it
     int idx[D];
-    float kvs[D * D];
+    double kvs[D * D];
     int bad0 = 0;
     if (threadIdx.x == 0) {
 #pragma unroll
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(ISA_T) void isa_target_kernel(IsaArgs a, const doub
 #pragma unroll
         for (int i = 0; i < D - 1; ++i)
 #pragma unroll
-            for (int j = 0; j < D; ++j) kvs[i * D + j] = a.ks[(long long)idx[i] * D + j];
+            for (int j = 0; j < D; ++j) kvs[i * D + j] = isa_ks(a, (long long)idx[i] * D + j);
     }
     finalize_argmax<D>(Pin, G, shd, shi, vrow, a.status, N);
     if (threadIdx.x == 0) {
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(ISA_T) void isa_target_kernel(IsaArgs a, const doub
         // the last row in ONE more round trip (registers first): filled element by element, the pivoting matrix lives
         // in scratch memory and every load waited for the one before it -- d*d dependent round trips on one thread
 #pragma unroll
-        for (int j = 0; j < D; ++j) kvs[(D - 1) * D + j] = a.ks[(long long)idx[D - 1] * D + j];
+        for (int j = 0; j < D; ++j) kvs[(D - 1) * D + j] = isa_ks(a, (long long)idx[D - 1] * D + j);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (D <= 4) {
             // d <= 4 (the usual ISOKANN dimensions): the augmented matrix in REGISTERS -- every loop unrolled, the pivot row picked and

@@ -1,10 +1,10 @@
 """Generates tests/golden/c3sub_reference.npz: fp64 oracle trajectories of run!() on the C3 sub-sample cases of
 tests/benchshape_cases.py, and -- per case -- the FP32 FLOOR: how far the same oracle evaluated in float32 (NumPy/BLAS,
-two different sample orders, i.e. two summation orders) ends up from its own fp64 run.  The GPU tests hold the HIP path to
-max(north-star gate, 3 x floor): where the floor is above the gate (the ISA simplex at the plain initialisation amplifies
+eight summation orders: sample order x feature order) ends up from its own fp64 run -- a distribution (every sample is stored), whose
+largest member is the floor.  The GPU tests hold the HIP path, in every forward arithmetic, to max(north-star gate, 1 x floor): where the floor is above the gate (the ISA simplex at the plain initialisation amplifies
 every rounding error of K chi by ~250) no fp32 evaluation can meet the gate, the reference's own CPU path included.
 
-    python tests/golden/make_c3sub_reference.py          (about ten minutes of CPU)
+    python tests/golden/make_c3sub_reference.py          (about forty minutes of CPU)
 """
 import os
 import sys
@@ -18,11 +18,19 @@ from oracle import isokann_oracle as O  # noqa: E402
 import benchshape_cases as bc  # noqa: E402
 
 
-def run(name, dtype, order):
+def run(name, dtype, order, forder=None):
+    """order: storage order of the samples (changes the summation order of every sum over samples: gradients, K-means' neighbours in
+    BLAS blocks); forder: storage order of the FEATURES -- the same network on permuted inputs (first-layer columns and LayerNorm
+    affine permuted with them): changes the summation order of the layer-1 dot products and of the LayerNorm statistics"""
     niter, mb, opt, nout = bc.C3SUB_RUNS[name]
     N, K = bc.C3SUB["N"], bc.C3SUB["K"]
     fx, fy = bc.features64(bc.C3_ATOMS, bc.C3_F, N, K, bc.C3SUB["coords_seed"])
-    om = bc.model(bc.c3sub_widths(name), bc.C3SUB["model_seed"], True).astype(dtype)
+    om = bc.model(bc.c3sub_widths(name), bc.C3SUB["model_seed"], True)
+    if forder is not None:
+        fx, fy = fx[forder], fy[forder]
+        om.W[0] = np.ascontiguousarray(om.W[0][:, forder])
+        om.ln_scale, om.ln_bias = om.ln_scale[forder].copy(), om.ln_bias[forder].copy()
+    om = om.astype(dtype)
     rule = O.AdamRegularized() if opt == "adam" else O.NesterovRegularized()
     oiso = O.Iso(bc.oracle_data(fx[:, order], fy[:, :, order], dtype), om, O.setup(rule, om), minibatch=mb)
     inv = np.argsort(order)
@@ -36,16 +44,32 @@ def run(name, dtype, order):
     return np.asarray(oiso.losses, np.float64), O.chis(oiso).astype(np.float64)[:, inv], np.asarray(kappa)
 
 
+NORD = 8
+
+
+def fx_rows():
+    return bc.C3_F
+
+
 def main():
     out = {}
     N = bc.C3SUB["N"]
     for name in bc.C3SUB_RUNS:
         l64, c64, kappa = run(name, np.float64, np.arange(N))
-        floor_l, floor_c = 0.0, 0.0
-        for order in (np.arange(N), np.random.default_rng(1).permutation(N)):
-            l32, c32, _ = run(name, np.float32, order)
-            floor_l = max(floor_l, float(np.max(np.abs(l32 - l64) / np.abs(l64))))
-            floor_c = max(floor_c, float(np.max(np.abs(c32 - c64))))
+        # The floor is a DISTRIBUTION: the trajectory amplifies rounding-level differences of K chi a few hundredfold
+        # (scripts/floor_study.py: the Float32 rounding of K chi alone, everything else exact, ends 2.5e-5 away after 10 full-batch
+        # iterations), so two float32 evaluations that differ only in summation order end up to ~4x apart.  NORD evaluations
+        # (sample order x feature order); the bound of the GPU tests is the largest, every sample is kept in the file.
+        F = fx_rows()
+        samples = []
+        for k in range(NORD):
+            order = np.arange(N) if k % 2 == 0 else np.random.default_rng(1 + k).permutation(N)
+            forder = None if k < 2 else np.random.default_rng(50 + k).permutation(F)
+            l32, c32, _ = run(name, np.float32, order, forder)
+            samples.append([float(np.max(np.abs(l32 - l64) / np.abs(l64))), float(np.max(np.abs(c32 - c64)))])
+            print(f"   {name} float32 evaluation {k}: loss rel {samples[-1][0]:.2e}, chi {samples[-1][1]:.2e}", flush=True)
+        floor_l, floor_c = (float(v) for v in np.max(np.asarray(samples), axis=0))
+        out[name + "_fp32_floor_samples"] = np.asarray(samples)
         p0 = bc.model(bc.c3sub_widths(name), bc.C3SUB["model_seed"], True).get_flat()
         out[name + "_losses"], out[name + "_chi"], out[name + "_kappa"] = l64, c64, kappa
         out[name + "_fp32_floor"] = np.array([floor_l, floor_c])

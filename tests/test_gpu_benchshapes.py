@@ -140,18 +140,19 @@ def test_c3_subsample_runs_within_fp32_floor(gpu_pkg, fwd_mode, name, every_iter
     oracle evaluated in float32 ends up 8e-6 (3 iterations) .. 1.8e-5 (10) from its own fp64 run in chi -- at or beyond the
     1e-5 gate before any GPU is involved.
 
-    Round 4 found where the HIP path's 1.6 .. 2 x of that floor came from: the K-mean.  A float summation of K = 20 outputs per
-    start point carries more rounding error than the mean leaves of the forward's own (averaged-out) error, and K chi is exactly
-    what the simplex inverse amplifies; summed in double and rounded once (kmean_kernel), the split-f16 forward -- the arithmetic
-    bench.py runs -- ends 2.6e-6 (10 iterations), 2.2e-6 (3) and 1.1e-6 (minibatch 1000) from the fp64 trajectories: inside the
-    literal 1e-5 gate and 4 .. 7 x BELOW the CPU float32 floor; the minibatch-100 case (kappa 4 344) ends inside the floor.  That
-    mode is therefore held to max(gate, 1 x floor).  The f32-MFMA and split-bf16 forwards keep their own accumulation error
-    (3.4e-5 after 10 iterations: a 432-step float fma chain per output, against 54 x 3 roundings of 32-deep exact products on the
-    f16 planes) and the round-3 bound of 3 x floor.  Table: profiles/r04_c3sub_error_table.md"""
+    Round 5 established what that floor IS (scripts/floor_study.py, CPU): with everything else exact, the Float32 rounding of K chi
+    alone -- which the reference performs too: `expectation` returns the model's eltype (src/isotarget.jl:18,103) before myisa widens
+    it (:82) -- ends 2.5e-5 from the Float64 trajectory after 10 iterations; Float32 training or parameters contribute 7e-7 and less.
+    The run amplifies a perturbation of K chi ~500-fold, so float32 evaluations that differ only in summation order land up to ~4x
+    apart: the floor is a distribution.  The golden file now holds eight CPU float32 evaluations per case (sample order x feature
+    order) and the bound is the largest of them, once, for EVERY forward arithmetic (rounds 3 / 4 held the f32-MFMA and split-bf16
+    forwards to 3 x a two-sample floor and blamed their "432-step fma chain": the teacher-forced probe, scripts/parity_probe.py,
+    shows the three arithmetics with the same per-stage errors -- chi 2..3e-7, K chi 8..9e-8 -- i.e. at Float32 output resolution).
+    The engine itself no longer rounds K chi on its way into the Float64 solve (IsaArgs.ks64: the K-mean's double sums).
+    Table: profiles/r05_c3sub_error_table.md"""
     lerr, cerr, floor_l, floor_c = _c3sub_run(gpu_pkg, name, every_iter)
-    mult = 1 if fwd_mode == 3 else 3
-    assert lerr <= max(1e-4, mult * floor_l)
-    assert cerr <= max(1e-5, mult * floor_c)
+    assert lerr <= max(1e-4, floor_l)
+    assert cerr <= max(1e-5, floor_c)
 
 
 # ------------------------------------------------------------------ C3: the full-N ISA target -----
