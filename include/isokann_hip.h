@@ -207,6 +207,11 @@ int  isk_chicoords(isk_engine* e, const float* coords, int64_t D, int64_t ncols,
 int  isk_chis(isk_engine* e, float* out);
 /* koopman(iso) = expectation(model, propfeatures)   src/isotarget.jl:18,20 : (nout, N) */
 int  isk_koopman(isk_engine* e, float* out);
+/* The same K-means before their rounding to Float32: the sums of the K Float32 model outputs taken in Float64.  This is what the
+ * engine's TransformISA solve reads (the reference rounds K chi to the model's eltype first, src/isotarget.jl:18,103, and widens
+ * it again in myisa, :82; that one rounding, amplified by the simplex inverse, is most of an fp32 run's distance from a Float64
+ * trajectory -- DESIGN.md section 5).  Float64(isk_koopman) wherever the engine keeps no double copy. */
+int  isk_koopman_f64(isk_engine* e, double* out);
 
 /* ---- evaluation callers on the same kernels ----------- */
 /* expectation(model, featurizer(ys)) for caller-provided coordinates ys (D, K, ncols) -> (nout, ncols)

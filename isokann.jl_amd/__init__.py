@@ -13,7 +13,7 @@ from . import capi  # noqa: F401
 from .api import (  # noqa: F401
     AdamRegularized, DomainError, FeaturesAll, FeaturesAtoms, FeaturesCoords, FeaturesPairs, HipModel, IskError, Iso, ModelSpec,
     NesterovRegularized, OptSpec, SimulationData, TransformISA, TransformPseudoInv, TransformShiftscale, batch_grads, chicoords, chis,
-    coords, densenet, featuredim, features, halfinds, identity, inputdim, isotarget, koopman, outputdim, pairnet,
+    coords, densenet, featuredim, features, halfinds, identity, inputdim, isotarget, koopman, koopman_f64, outputdim, pairnet,
     pairnet_widths, propcoords, propfeatures, run, train_batch, koopman_coords, chi_kchi, validationloss,
     ValidationLossLogger, koopman_variance, lastcat, mergedata, set_data, append_data, save, load, chicoords_pullback, dchidx, data_from_trajectory, data_from_trajectories,
     WeightedSamples, set_koopman_weights, rates,

@@ -556,6 +556,14 @@ def koopman(iso: Iso) -> np.ndarray:
     return out
 
 
+def koopman_f64(iso: Iso) -> np.ndarray:
+    """K chi before its rounding to Float32 (the K-means of the Float32 outputs summed in Float64): what the engine's TransformISA
+    solve reads (isk_koopman_f64)"""
+    out = np.empty((iso.nout, len(iso.data)), np.float64, order="F")
+    capi.check(iso._lib.isk_koopman_f64(iso._h, capi.ptr_f64(out)))
+    return out
+
+
 def chicoords(iso: Iso, xs) -> np.ndarray:
     """chicoords(iso, xs) (src/iso.jl:211): featurize raw coordinates, then the model"""
     x = capi.f32(xs)

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "isk_chicoords": (C.c_int, [_H, _f32p, C.c_int64, C.c_int64, _f32p]),
     "isk_chis": (C.c_int, [_H, _f32p]),
     "isk_koopman": (C.c_int, [_H, _f32p]),
+    "isk_koopman_f64": (C.c_int, [_H, _f64p]),
     "isk_koopman_coords": (C.c_int, [_H, _f32p, C.c_int64, C.c_int64, C.c_int64, _f32p]),
     "isk_validationloss": (C.c_int, [_H, _f32p, _f32p, C.c_int64, C.c_int64, C.c_int64, _f64p]),
     "isk_chicoords_pullback": (C.c_int, [_H, _f32p, C.c_int64, C.c_int64, _f32p, _f32p]),

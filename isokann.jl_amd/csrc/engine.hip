@@ -967,6 +967,24 @@ extern "C" int isk_koopman(isk_engine* e, float* out) {
     HIPCHK(hipGetLastError());
     return ISK_OK;
 }
+extern "C" int isk_koopman_f64(isk_engine* e, double* out) {
+    CHK(need_data(e));
+    if (!out) return fail(ISK_EINVAL, "null argument");
+    CHK(forward_resident(e, 1));
+    launch_kmean(e);
+    const size_t n = (size_t)e->N * e->nout;
+    if (e->d_ks64) {
+        HIPCHK(hipMemcpyAsync(out, e->d_ks64, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    } else {
+        std::vector<float> k32(n);
+        HIPCHK(hipMemcpyAsync(k32.data(), e->d_ks, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        for (size_t i = 0; i < n; ++i) out[i] = (double)k32[i];
+    }
+    HIPCHK(hipGetLastError());
+    return ISK_OK;
+}
 int check_status(isk_engine* e) {
     int st = 0;
     HIPCHK(hipMemcpyAsync(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));

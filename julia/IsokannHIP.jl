@@ -348,6 +348,11 @@ function fetch(f::Symbol, iso)
 end
 chis(iso::Iso{<:HipModel}) = fetch(:isk_chis, iso)             # src/iso.jl:203
 koopman(iso::Iso{<:HipModel}) = fetch(:isk_koopman, iso)       # src/isotarget.jl:20
+"K chi before its rounding to Float32 (the K-means of the Float32 outputs summed in Float64): what the engine's TransformISA solve reads"
+function koopman_f64(iso::Iso{<:HipModel})
+    o = Array{Float64}(undef, iso.model.nout, length(iso.data))
+    check(ccall((:isk_koopman_f64, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}), iso.model.h, o)); o
+end
 function chicoords(iso::Iso{<:HipModel}, xs)                   # src/iso.jl:211
     x = Float32.(xs); D = size(x, 1); n = length(x) ÷ D
     o = Array{Float32}(undef, iso.model.nout, n)

@@ -100,7 +100,14 @@ def test_c3_full_n_training_epoch_vs_oracle(gpu_pkg, opt, mb):
 # ------------------------------------------------------------------ C3: run! on a sub-sample -----
 # The fp64 trajectories and, per case, the fp32 floor (how far the CPU oracle evaluated in float32 ends up from its own
 # fp64 run) are committed: tests/golden/c3sub_reference.npz, generated by tests/golden/make_c3sub_reference.py.
-def _c3sub_run(pkg, name, every_iter):
+# The end-of-run error of these trajectories is a draw: the run amplifies rounding-level differences of K chi ~500-fold
+# (scripts/floor_study.py), so evaluations that differ only in summation order land far apart -- eight CPU float32 evaluations per
+# case span 1.2e-5 .. 1.8e-5 (full_adam), the HIP path under four feature orders 8e-7 .. 3.6e-5 in every forward arithmetic (its
+# layer-1 sums are one long chain where NumPy's are blocked).  One bound for every arithmetic: FLOOR_MULT x the largest CPU sample.
+FLOOR_MULT = 2.5
+
+
+def _c3sub_run(pkg, name, every_iter, want_layered=None):
     niter, mb, opt, nout = bc.C3SUB_RUNS[name]
     N, K = bc.C3SUB["N"], bc.C3SUB["K"]
     gold = np.load(GOLD)
@@ -111,6 +118,8 @@ def _c3sub_run(pkg, name, every_iter):
     popt = pkg.AdamRegularized() if opt == "adam" else pkg.NesterovRegularized()
     iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_mk(pkg, om), opt=popt, minibatch=mb,
                   featurize_every_iteration=every_iter)
+    if want_layered is not None:
+        assert iso.get_option("layered") == int(want_layered)
     pkg.run(iso, niter, 1, perms=bc.run_perms(name))
     lerr = float(np.max(np.abs(np.asarray(iso.losses) - gold[name + "_losses"]) / gold[name + "_losses"]))
     cerr = float(np.max(np.abs(pkg.chis(iso) - gold[name + "_chi"])))
@@ -151,8 +160,54 @@ def test_c3_subsample_runs_within_fp32_floor(gpu_pkg, fwd_mode, name, every_iter
     The engine itself no longer rounds K chi on its way into the Float64 solve (IsaArgs.ks64: the K-mean's double sums).
     Table: profiles/r05_c3sub_error_table.md"""
     lerr, cerr, floor_l, floor_c = _c3sub_run(gpu_pkg, name, every_iter)
-    assert lerr <= max(1e-4, floor_l)
-    assert cerr <= max(1e-5, floor_c)
+    assert lerr <= max(1e-4, FLOOR_MULT * floor_l)
+    assert cerr <= max(1e-5, FLOOR_MULT * floor_c)
+
+
+@pytest.mark.parametrize("name", ["full_adam", "full3_adam", "mb1000_adam"])
+def test_c3_subsample_runs_on_the_layered_path(gpu_pkg, fwd_mode, name, monkeypatch):
+    """The same runs with the villin network forced onto the layered (wide-network) path (isk_config.force_layered: layer 1 through
+    the dense-block forward kernels -- a split-f16 request runs split-bf16 there --, training on the in-house MFMA GEMMs in Float32
+    arithmetic): held to the same bound as the fused path.  Measured (round 4's forced run of the whole suite, where these cases
+    stood out against the bounds tightened for the fused split-f16 arithmetic): chi 1.4e-5 .. 3.6e-5, losses 4.1e-5 .. 1.8e-4 --
+    1.8 .. 2.2 x the CPU float32 floor, like the fused f32 / split-bf16 forwards: the same draw, not a defect of the path."""
+    monkeypatch.setenv("ISK_FORCE_LAYERED", "1")
+    lerr, cerr, floor_l, floor_c = _c3sub_run(gpu_pkg, name, False, want_layered=True)
+    assert lerr <= max(1e-4, FLOOR_MULT * floor_l)
+    assert cerr <= max(1e-5, FLOOR_MULT * floor_c)
+
+
+@pytest.mark.own_fwd_mode
+def test_c3_subsample_error_is_a_draw_of_the_summation_order_not_of_the_arithmetic(gpu_pkg, monkeypatch):
+    """Why the bound above is a multiple of the CPU float32 floor, and the same one for every forward arithmetic: the SAME network
+    on permuted features (pair list, first-layer columns and LayerNorm affine permuted together -- another order of every layer-1
+    dot product and LayerNorm sum, nothing else) ends anywhere between 8e-7 and 3.6e-5 from the Float64 trajectory after the ten
+    iterations of `full_adam`, in EVERY mode (profiles/r05_perm_study_full_adam.txt; scripts/perm_study.py).  Asserted: under four
+    feature orders every arithmetic stays inside FLOOR_MULT x the floor, and every arithmetic gets below 1 x the floor at least
+    once -- none of them is the inaccurate one."""
+    pkg = gpu_pkg
+    monkeypatch.delenv("ISK_FWD_MODE", raising=False)
+    name = "full_adam"
+    gold = np.load(GOLD)
+    niter, mb, opt, nout = bc.C3SUB_RUNS[name]
+    N, K = bc.C3SUB["N"], bc.C3SUB["K"]
+    xs, ys, pairs = _coords(C3_ATOMS, C3_F, N, K, bc.C3SUB["coords_seed"])
+    pairs = np.asarray(pairs)
+    floor_c = float(gold[name + "_fp32_floor"][1])
+    for mode in (0, 1, 3):
+        errs = []
+        for t in range(4):
+            om = _model(bc.c3sub_widths(name), bc.C3SUB["model_seed"], True)
+            fo = np.arange(C3_F) if t == 0 else np.random.default_rng(900 + t).permutation(C3_F)
+            om.W[0] = np.ascontiguousarray(om.W[0][:, fo])
+            om.ln_scale, om.ln_bias = om.ln_scale[fo].copy(), om.ln_bias[fo].copy()
+            iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs([tuple(p) for p in pairs[fo]])), model=_mk(pkg, om),
+                          opt=pkg.AdamRegularized(), minibatch=mb, forward_mode=mode)
+            pkg.run(iso, niter, 1, perms=bc.run_perms(name))
+            errs.append(float(np.max(np.abs(pkg.chis(iso) - gold[name + "_chi"]))))
+            iso.close()
+        print(f"forward mode {mode}: chi error under four feature orders {errs} (CPU float32 floor {floor_c:.2e})")
+        assert max(errs) <= FLOOR_MULT * floor_c and min(errs) <= floor_c, (mode, errs)
 
 
 # ------------------------------------------------------------------ C3: the full-N ISA target -----
@@ -166,7 +221,10 @@ def test_c3_full_n_isa_target_vs_oracle(gpu_pkg):
     iso = pkg.Iso(pkg.SimulationData(xs, ys, pkg.FeaturesPairs(pairs)), model=_mk(pkg, om), minibatch=1000, featurize_every_iteration=True)
     ks, chi = pkg.koopman(iso), pkg.chis(iso)
     t = pkg.isotarget(iso)
-    k64, c64 = ks.astype(np.float64), chi.astype(np.float64)
+    # the chain reads K chi UNROUNDED (the K-mean's double sums, isk_koopman_f64), not its Float32 copy: at this random
+    # initialisation the simplex inverse amplifies that one rounding ~5000-fold (targets of +-800)
+    k64, c64 = pkg.koopman_f64(iso), chi.astype(np.float64)
+    np.testing.assert_array_equal(k64.astype(np.float32), ks)                   # ... whose Float32 rounding IS koopman(iso)
     A = O.myisa(k64.T)
     want = O.fixperm(A.T @ k64, c64)
     assert np.abs(t - want).max() <= 2e-6 * np.abs(want).max()
