@@ -1,5 +1,6 @@
 #!/bin/bash
 # regenerate the committed evidence under profiles/ (run on the GPU box): scripts/refresh_profiles.sh r01
+# (a gpurun call is limited to 20 minutes: SKIP_PROF=1 runs the bench variants only, SKIP_BENCH=1 the traces and counter passes only)
 tag=${1:-r05}
 mkdir -p gpurun_out/ref
 # no `set -e` (one failed trace must not stop the others), but every failed step is NAMED at the end and the script fails: a
@@ -36,6 +37,7 @@ b c4_shard_of_8 --shard-of 8 --no-cpu-baseline
 b c4_shard_of_4 --shard-of 4 --no-cpu-baseline
 b c4_shard_of_2 --shard-of 2 --no-cpu-baseline
 fi
+if [ -z "$SKIP_PROF" ]; then
 bash scripts/prof_bench.sh c3stats > gpurun_out/ref/prof.txt 2>&1 || fail "bash_prof_bench.sh_c3stats_prof.txt"
 cp gpurun_out/prof_c3stats/c3stats_kernel_stats.csv gpurun_out/ref/${tag}_kernel_stats_bench_c3.csv || fail "__tag__kernel_stats_bench_c3.csv"
 # The epoch graph of this configuration has 400 kernel nodes.  rocprofv3 (ROCm 7.2) segfaults INSIDE its interception of
@@ -70,5 +72,6 @@ bash scripts/pmc_tcc.sh c5 --workload c5shard --forward-mode 2 --train-bf16 > gp
 cp gpurun_out/pmc_tcc_c3.json gpurun_out/ref/${tag}_pmc_tcc_c3_raw.json 2>/dev/null || fail "cp_pmc_tcc_c3.json_tag_pmc_tcc_c3_raw.json_null"
 cp gpurun_out/pmc_tcc_c5.json gpurun_out/ref/${tag}_pmc_tcc_c5_raw.json 2>/dev/null || fail "cp_pmc_tcc_c5.json_tag_pmc_tcc_c5_raw.json_null"
 python3 scripts/c3sub_table.py > gpurun_out/ref/${tag}_c3sub_error_table.md 2> gpurun_out/ref/c3sub_table.err || fail "python3_c3sub_table.py_tag_c3sub_error_table.md_"
+fi   # SKIP_PROF
 if [ -n "$FAILED" ]; then echo "[refresh_profiles] steps that FAILED (their files under gpurun_out/ref are missing or stale):$FAILED" >&2; exit 1; fi
 echo "[refresh_profiles] all steps ok"
