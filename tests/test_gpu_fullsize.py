@@ -153,5 +153,10 @@ def test_c5_shard_full_size_bf16_path_properties(gpu_pkg, monkeypatch):
     assert len(iso.losses) == 3 and np.all(np.isfinite(iso.losses))
     assert np.abs(iso.model.get_params() - p0).max() > 0
     assert np.all(np.isfinite(pkg.chis(iso)))
+    # "training lowers the loss": run!() draws a NEW target every iteration, so its losses need not fall; against ONE fixed target
+    # they must -- three epochs of train_batch! (src/iso.jl:179-194) on the same target, 36 Adam steps on the bf16 GEMMs
+    t = pkg.isotarget(iso)
+    fixed = [pkg.train_batch(iso, t) for _ in range(3)]
+    assert np.all(np.isfinite(fixed)) and fixed[2] < fixed[1] < fixed[0], fixed
     iso.close()
 
