@@ -124,6 +124,57 @@ def read_sclk_mhz(device=0):
     return None
 
 
+
+def measure_traffic_live(argv_workload, kernel_substr, timeout_s=150.0):
+    """HBM-side bytes per launch of the dominant kernel, measured in THIS invocation: two rocprofv3 counter passes (FETCH_SIZE, then
+    WRITE_SIZE -- they do not fit one pass; --kernel-trace only, as MI355X_MICROARCH.md prescribes) of a short child run of this
+    script on the same workload.  gfx950 correction from the same guide: FETCH_SIZE tallies 64 B per 128-byte request of a wide
+    coalesced read -> doubled; WRITE_SIZE exact; both in KB.  Returns (bytes, description) or None (no rocprofv3, a pass failed or
+    timed out: the caller falls back to the committed counter summary)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3")
+    if not rp:
+        return None
+    tmp = tempfile.mkdtemp(prefix="isk_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", ISK_BENCH_NO_PMC="1")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", "python3",
+                   os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--profile-steps", "1",
+                   "--sustained-s", "0", "--no-f32-reference"] + argv_workload
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)          # (the group we started: never a pattern)
+                pr.wait()
+                return None
+            if rc != 0:
+                return None
+            per = {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+            if not per:
+                return None
+            vals[counter] = max(per.values())               # the full-size launch (the first launches of set_data are smaller)
+        b = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        return b, ("measured in this invocation: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes of a 3-iteration "
+                   "child run of this script); FETCH_SIZE x 2 + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md), per launch")
+    except Exception:      # noqa: BLE001 - the committed summary remains
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 class SclkSampler:
     """samples the shader clock from a host thread while a measurement runs"""
 
@@ -191,6 +242,9 @@ def main():
                     help="single GPU: also time the coordinate pullback d chi / d coords (isk_chicoords_pullback, the counterpart of the "
                          "reference's sqpairdist_bwd_kernel!, src/utils/pairdists.jl:153-196) on COLS columns of xs; host buffers in and out")
     ap.add_argument("--no-sub-records", action="store_true", help="multi-GPU: skip the weak-scaling and full-batch sub-records")
+    ap.add_argument("--no-pmc-traffic", action="store_true",
+                    help="single GPU: do not measure roofline.traffic in this invocation (two rocprofv3 counter passes of a short child "
+                         "run, ~40 s); the figure of the committed counter summary is reported instead")
     ap.add_argument("--train-bf16", action=argparse.BooleanOptionalAction, default=None,
                     help="wide networks (c5shard): training GEMMs on bf16 operands, f32 accumulate, f32 master weights.  Default: on for "
                          "--workload c5shard on its bf16 path (forward mode 2), off otherwise")
@@ -430,10 +484,21 @@ def main():
             wide_fwd = bool(iso.get_option("wide_fwd"))
         except Exception:
             wide_fwd = False
-        for pmf in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
+        live = None
+        if world == 1 and not use_dp and not args.no_pmc_traffic and not os.environ.get("ISK_BENCH_NO_PMC"):
+            wl_args = ["--workload", args.workload, "--minibatch", str(args.minibatch), "--opt", args.opt, "--forward-mode", str(args.forward_mode)]
+            wl_args += ["--cached-features"] if args.cached_features else []
+            wl_args += ["--train-bf16"] if args.train_bf16 else ["--no-train-bf16"]
+            arm("counter passes")
+            live = measure_traffic_live(wl_args, "wide_fwd" if wide_fwd else "mlp_fwd")
+            arm("")
+        for pmf in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
+            if live:
+                traffic, traffic_source = live
+                break
             try:
                 if wide_fwd and args.workload == "c5shard" and world == 1 and not args.shard_of:
-                    c5f = "r04_pmc_summary_c5.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_summary_c5.json")) else "r03_pmc_summary_c5.json"
+                    c5f = next(f for f in ("r05_pmc_summary_c5.json", "r04_pmc_summary_c5.json", "r03_pmc_summary_c5.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
                     pm = json.load(open(os.path.join(ROOT, "profiles", c5f)))
                     traffic = pm["mlp_fwd_traffic_bytes_per_launch"]
                     traffic_source = ("profiles/" + c5f + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this workload on its "

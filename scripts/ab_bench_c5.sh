@@ -6,6 +6,7 @@
 #   rm -rf /tmp/headtree && mkdir -p /tmp/headtree build_abl && git archive HEAD isokann.jl_amd/csrc include | tar -x -C /tmp/headtree
 #   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c /tmp/headtree/isokann.jl_amd/csrc/<unit>.hip -o /tmp/obj/<unit>_head.o
 #   hipcc --offload-arch=gfx950 -fPIC -shared $(sed "s#<unit's object>#/tmp/obj/<unit>_head.o#" /tmp/obj/last_objs.txt) -o build_abl/libisk_head.so
+export ISK_BENCH_NO_PMC=1     # (bench.py would otherwise run its own rocprofv3 counter passes for roofline.traffic)
 for i in 1 2 3; do
 for lib in "" build_abl/libisk_head.so; do
 ISK_LIB=$lib python bench.py --workload c5shard --forward-mode 2 --steps 10 --warmup 3 --no-cpu-baseline --train-bf16 2>/dev/null | python -c "

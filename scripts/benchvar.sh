@@ -1,4 +1,5 @@
 # usage: bash scripts/benchvar.sh "ENV=1 ENV2=2" "args"  -> one summary line
+export ISK_BENCH_NO_PMC=1     # (bench.py would otherwise run its own rocprofv3 counter passes for roofline.traffic)
 run() {
   env $1 timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline $2 2>/dev/null > gpurun_out/bv.json
   python - "$1 $2" <<'PY'

@@ -3,6 +3,7 @@
 #   scripts/pmc.sh                                                         the C3 bench
 #   scripts/pmc.sh c5 --workload c5shard --forward-mode 2 --train-bf16     the C5 shard on its bf16 path
 # separate passes, --kernel-trace only (never combined with other trace domains)
+export ISK_BENCH_NO_PMC=1     # (bench.py would otherwise run its own rocprofv3 counter passes for roofline.traffic)
 TAG=$1; [ $# -gt 0 ] && shift
 BARGS="$*"
 SUF=${TAG:+_$TAG}

@@ -3,6 +3,7 @@
 # One rocprofv3 --pmc pass per counter group (--kernel-trace only).  ISK_LIB=<ablation build> is honoured (bench.py loads it).  RDREQ counts the L2's memory-side read requests, RDREQ_32B the
 # 32-byte ones among them (the others are 64 B), HIT / MISS the L2 lookups: (RDREQ - RDREQ_32B) * 64 + RDREQ_32B * 32 is the byte
 # count FETCH_SIZE approximates.
+export ISK_BENCH_NO_PMC=1     # (bench.py would otherwise run its own rocprofv3 counter passes for roofline.traffic)
 TAG=$1; shift
 BARGS="$*"
 R=$(pwd); P=$R/gpurun_out/pmc_tcc_$TAG; mkdir -p $P

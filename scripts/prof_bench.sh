@@ -1,5 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel stats of a bench.py run: scripts/prof_bench.sh <tag> [bench args...]   (PROF_STEPS / PROF_WARMUP: iterations traced)
+export ISK_BENCH_NO_PMC=1     # (bench.py would otherwise run its own rocprofv3 counter passes for roofline.traffic)
 tag=$1; shift
 R=$(pwd); mkdir -p $R/gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp

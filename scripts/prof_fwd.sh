@@ -1,5 +1,6 @@
 #!/bin/bash
 # kernel-level timing of scripts/time_fwd.py under rocprofv3: scripts/prof_fwd.sh <mode> [tag]
+export ISK_BENCH_NO_PMC=1     # (bench.py would otherwise run its own rocprofv3 counter passes for roofline.traffic)
 mode=${1:-1}; tag=${2:-fwd}
 R=$(pwd); mkdir -p $R/gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp

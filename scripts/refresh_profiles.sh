@@ -6,12 +6,13 @@ mkdir -p gpurun_out/ref
 # no `set -e` (one failed trace must not stop the others), but every failed step is NAMED at the end and the script fails: a
 # stale or missing file under profiles/ is then visible instead of silent
 FAILED=""
+export ISK_BENCH_NO_PMC=1     # only the headline run (b c3) measures roofline.traffic itself: two more rocprofv3 passes per bench run otherwise
 set -o pipefail            # a bench that dies in front of `| tail -1` must count as failed
 fail() { FAILED="$FAILED $1"; echo "[refresh_profiles] FAILED: $1" >&2; }
 b() { name=$1; shift; python3 bench.py "$@" 2> gpurun_out/ref/$name.err | tail -1 > gpurun_out/ref/${tag}_bench_$name.json || fail bench_$name; python3 -c "
 import json,sys; d=json.load(open('gpurun_out/ref/${tag}_bench_$name.json')); print('$name', round(d['ms_per_step'],3), 'ms', round(d['value']/1e6,1), 'M/s frac', round(d['roofline']['frac'],3))" || fail bench_${name}_line; }
 if [ -z "$SKIP_BENCH" ]; then
-b c3
+ISK_BENCH_NO_PMC= b c3
 b c3_bf16x3fwd --forward-mode 1
 b c3_f32fwd --forward-mode 0
 b c3_cached --cached-features
