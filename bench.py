@@ -129,7 +129,7 @@ def measure_traffic_live(argv_workload, kernel_substr, timeout_s=150.0):
     """HBM-side bytes per launch of the dominant kernel, measured in THIS invocation: two rocprofv3 counter passes (FETCH_SIZE, then
     WRITE_SIZE -- they do not fit one pass; --kernel-trace only, as MI355X_MICROARCH.md prescribes) of a short child run of this
     script on the same workload.  gfx950 correction from the same guide: FETCH_SIZE tallies 64 B per 128-byte request of a wide
-    coalesced read -> doubled; WRITE_SIZE exact; both in KB.  Returns (bytes, description) or None (no rocprofv3, a pass failed or
+    coalesced read -> doubled; WRITE_SIZE exact; both in KB.  Returns (bytes, description, bytes of a whole iteration, per-kernel table) or None (no rocprofv3, a pass failed or
     timed out: the caller falls back to the committed counter summary)."""
     import csv
     import glob
@@ -142,7 +142,7 @@ def measure_traffic_live(argv_workload, kernel_substr, timeout_s=150.0):
         return None
     tmp = tempfile.mkdtemp(prefix="isk_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", ISK_BENCH_NO_PMC="1")
-    vals = {}
+    vals, kernels = {}, {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
@@ -158,17 +158,37 @@ def measure_traffic_live(argv_workload, kernel_substr, timeout_s=150.0):
                 return None
             if rc != 0:
                 return None
-            per = {}
+            per, allk = {}, {}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    if r["Counter_Name"] != counter:
+                        continue
+                    name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+                    d = allk.setdefault(name, {})
+                    d[r["Dispatch_Id"]] = d.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+                    if kernel_substr in r["Kernel_Name"]:
                         per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
             if not per:
                 return None
             vals[counter] = max(per.values())               # the full-size launch (the first launches of set_data are smaller)
+            kernels[counter] = allk
         b = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        # the whole iteration: every kernel's bytes x its launches per iteration (the child ran ITER iterations; the featurizer's and the
+        # forward's extra launches at set_data are smaller: their largest launch counts once per iteration)
+        ITER = 4
+        step_bytes, table = 0.0, {}
+        for name in kernels["FETCH_SIZE"]:
+            fd, wd = kernels["FETCH_SIZE"][name], kernels["WRITE_SIZE"].get(name, {})
+            if name.startswith("__amd_rocclr"):
+                continue                                    # (runtime fills / copies of the set-up)
+            once = "featurize" in name or "mlp_fwd" in name or "wide_fwd" in name
+            per_launch = ((2.0 * max(fd.values()) + (max(wd.values()) if wd else 0.0)) if once else
+                          (2.0 * sum(fd.values()) / len(fd) + (sum(wd.values()) / len(wd) if wd else 0.0))) * 1024.0
+            n_it = 1 if once else max(1, round(len(fd) / ITER))
+            table[name] = {"launches_per_iteration": n_it, "bytes_per_launch": per_launch}
+            step_bytes += per_launch * n_it
         return b, ("measured in this invocation: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes of a 3-iteration "
-                   "child run of this script); FETCH_SIZE x 2 + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md), per launch")
+                   "child run of this script); FETCH_SIZE x 2 + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md), per launch"), step_bytes, table
     except Exception:      # noqa: BLE001 - the committed summary remains
         return None
     finally:
@@ -494,7 +514,7 @@ def main():
             arm("")
         for pmf in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
             if live:
-                traffic, traffic_source = live
+                traffic, traffic_source = live[0], live[1]
                 break
             try:
                 if wide_fwd and args.workload == "c5shard" and world == 1 and not args.shard_of:
@@ -577,7 +597,12 @@ def main():
             if "atoms" in c and not args.cached_features:
                 isa = 1 if widths[-1] > 1 else 0
                 sbytes = 4 * 3 * c["atoms"] * N * (K + isa + 1)
-                roof["step"] = {"algorithmic_bytes": sbytes, "algorithmic_flops": step_flops, "ms": step_ms,
+                roof["step"] = {"traffic_bytes": live[2] if live else None,
+                                "traffic_over_algorithmic": (live[2] / sbytes) if live else None,
+                                "traffic_by_kernel": live[3] if live else None,
+                                "traffic_note": "FETCH_SIZE x 2 + WRITE_SIZE summed over every kernel of one iteration, measured in this invocation "
+                                                "(L2-side request counters: Infinity-Cache hits are counted too)" if live else None,
+                                "algorithmic_bytes": sbytes, "algorithmic_flops": step_flops, "ms": step_ms,
                                 "GB_per_s": sbytes / (step_ms * 1e-3) / 1e9, "frac_of_8TBps": sbytes / (step_ms * 1e-3) / 8e12,
                                 "TFLOP_per_s": step_flops / (step_ms * 1e-3) / 1e12,
                                 "frac_of_157.3_f32_mfma": step_flops / (step_ms * 1e-3) / 157.3e12}
