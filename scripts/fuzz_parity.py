@@ -18,19 +18,21 @@ pkg = ge.load_package()
 
 def sweep(ncases, seed, verbose=True):
   rng = np.random.default_rng(seed)
+  big = bool(os.environ.get("FUZZ_BIG"))          # larger shapes: hidden widths to 400 (beyond 160 the layered path takes over), N to 3000
   fails = 0
   skipped = 0
   failed = []
   for case in range(ncases):
-      A = int(rng.integers(3, 40))
+      A = int(rng.integers(3, 70 if big else 40))
       kind = rng.choice(["identity", "all", "pairs"])
-      N = int(rng.integers(5, 400))
+      N = int(rng.integers(5, 3000 if big else 400))
       K = int(rng.integers(1, 9))
       nout = int(rng.choice([1, 1, 2, 3, 4, 5, 8, 10]))
       mode = int(rng.choice([0, 1, 3]))
       every = bool(rng.integers(0, 2))
       optk = rng.choice(["adam", "nesterov"])
       ln = bool(rng.integers(0, 4) > 0)
+      layered = bool(rng.integers(0, 4) == 0)          # the wide-network path forced onto a small network
       if kind == "identity":
           F = int(rng.integers(1, 70))
           if ln and F < 4:
@@ -43,7 +45,7 @@ def sweep(ncases, seed, verbose=True):
               F = A * (A - 1) // 2
               feat, ofeat = pkg.FeaturesAll(), O.FeaturesAll()
           else:
-              F = int(rng.integers(4 if ln else 1, min(300, A * (A - 1) // 2) + 1)) if A * (A - 1) // 2 >= 4 else A * (A - 1) // 2
+              F = int(rng.integers(4 if ln else 1, min(900 if big else 300, A * (A - 1) // 2) + 1)) if A * (A - 1) // 2 >= 4 else A * (A - 1) // 2
               pairs = O.random_pairs(A, F, seed=int(rng.integers(0, 1 << 30)))
               feat, ofeat = pkg.FeaturesPairs(pairs), O.FeaturesPairs(pairs)
       if ln and F < 4:
@@ -55,9 +57,9 @@ def sweep(ncases, seed, verbose=True):
           else:
               xs, ys = O.synthetic_coords(A, N, K, seed=int(rng.integers(0, 1 << 30)))
       nl = int(rng.integers(1, 5))
-      widths = [F] + [int(rng.integers(max(nout, 1), 60)) for _ in range(nl - 1)] + [nout]
+      widths = [F] + [int(rng.integers(max(nout, 1), 400 if big else 60)) for _ in range(nl - 1)] + [nout]
       mb = int(rng.choice([0, 0, 7, 16, 33, 100, 1000]))
-      desc = dict(case=case, kind=kind, A=A, F=F, N=N, K=K, widths=widths, mode=mode, every=every, opt=optk, ln=ln, mb=mb)
+      desc = dict(case=case, kind=kind, A=A, F=F, N=N, K=K, widths=widths, mode=mode, every=every, opt=optk, ln=ln, mb=mb, layered=layered)
       try:
           om = O.glorot_model(widths, rng, layernorm=ln)
           for b in om.b:
@@ -71,7 +73,7 @@ def sweep(ncases, seed, verbose=True):
           oopt = O.AdamRegularized(1e-3, 1e-4) if optk == "adam" else O.NesterovRegularized(1e-3, 1e-4)
           x64, y64 = np.asarray(xs, np.float32).astype(np.float64), np.asarray(ys, np.float32).astype(np.float64)
           odata = O.SimulationData(x64, y64, ofeat)
-          iso = pkg.Iso(pkg.SimulationData(xs, ys, feat), model=m, opt=popt, minibatch=mb, featurize_every_iteration=every, forward_mode=mode)
+          iso = pkg.Iso(pkg.SimulationData(xs, ys, feat), model=m, opt=popt, minibatch=mb, featurize_every_iteration=every, forward_mode=mode, force_layered=layered)
           oiso = O.Iso(odata, om, O.setup(oopt, om), minibatch=mb)
           chi0, ks0 = pkg.chis(iso), pkg.koopman(iso)
           assert np.abs(chi0 - O.chis(oiso)).max() <= 3e-5, ("chi0", np.abs(chi0 - O.chis(oiso)).max())
