@@ -230,19 +230,16 @@ end
 
 # ---- optimizer state <-> Optimisers state tree (Flux.setup order == trainables order) ----------------------------------
 # Flux.setup(rule, model) returns a tree of Optimisers.Leaf; every leaf carries the same rule
-function optimiser_rule(tree::NamedTuple)
-    r = Ref{Any}(nothing)
-    Optimisers.fmapstructure(l -> (l isa Optimisers.Leaf && r[] === nothing && (r[] = l.rule); l), tree;
-                             exclude = l -> l isa Optimisers.Leaf)
-    r[]
-end
+# (walked by hand -- Tuples and NamedTuples in field order, which is the order of Flux.trainables -- rather than through
+# Functors.fmapstructure: the extension then needs nothing beyond ISOKANN, Flux and Optimisers in scope)
+collect_leaves!(out, x::Optimisers.Leaf) = (push!(out, x); out)
+collect_leaves!(out, x::Union{Tuple,NamedTuple}) = (foreach(v -> collect_leaves!(out, v), x); out)
+collect_leaves!(out, x) = out
 
 "leaves of an Optimisers state tree in trainables order"
-function leaves(tree)
-    out = Optimisers.Leaf[]
-    Optimisers.fmapstructure(l -> (l isa Optimisers.Leaf && push!(out, l); l), tree; exclude = l -> l isa Optimisers.Leaf)
-    out
-end
+leaves(tree) = collect_leaves!(Optimisers.Leaf[], tree)
+
+optimiser_rule(tree::NamedTuple) = (ls = leaves(tree); isempty(ls) ? nothing : first(ls).rule)
 
 "engine <- state tree: OptimiserChain state per leaf is (nothing | (), rule state); Adam (mt, vt, betat), Nesterov velocity"
 function push_opt_state!(m::HipModel, tree)
@@ -342,12 +339,12 @@ function train_batch!(m::HipModel, xs, target::AbstractMatrix, opt, minibatch; k
                 m.h, Float32.(target), minibatch, C_NULL, loss)); loss[]
 end
 
-function fetch(f::Symbol, iso)
+function fetch_rows(f::Symbol, iso)              # (not `fetch`: that is Base's)
     o = Array{Float32}(undef, iso.model.nout, length(iso.data))
     check(ccall((f, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float32}), iso.model.h, o)); o
 end
-chis(iso::Iso{<:HipModel}) = fetch(:isk_chis, iso)             # src/iso.jl:203
-koopman(iso::Iso{<:HipModel}) = fetch(:isk_koopman, iso)       # src/isotarget.jl:20
+chis(iso::Iso{<:HipModel}) = fetch_rows(:isk_chis, iso)             # src/iso.jl:203
+koopman(iso::Iso{<:HipModel}) = fetch_rows(:isk_koopman, iso)       # src/isotarget.jl:20
 "K chi before its rounding to Float32 (the K-means of the Float32 outputs summed in Float64): what the engine's TransformISA solve reads"
 function koopman_f64(iso::Iso{<:HipModel})
     o = Array{Float64}(undef, iso.model.nout, length(iso.data))

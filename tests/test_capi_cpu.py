@@ -129,7 +129,7 @@ def test_config_struct_agrees_between_header_ctypes_and_julia_shim(pkg):
     assert jl_names == names
     assert f"const ABI_VERSION = Int32({pkg.capi.ISK_ABI_VERSION})" in jl
     # every entry point the shim calls is declared in the header
-    called = set(re.findall(r"\(:(isk_[a-z0-9_]+), LIB\[\]\)", jl)) | set(re.findall(r"fetch\(:(isk_[a-z0-9_]+)", jl))
+    called = set(re.findall(r"\(:(isk_[a-z0-9_]+), LIB\[\]\)", jl)) | set(re.findall(r"fetch_rows\(:(isk_[a-z0-9_]+)", jl))
     assert called and called <= set(pkg.capi.PROTOTYPES), called - set(pkg.capi.PROTOTYPES)
 
 
@@ -250,7 +250,7 @@ def test_argument_types_agree_between_header_ctypes_and_julia_shim(pkg):
     seen = set()
     for sym, ret, tup in calls:
         jargs = [t.strip() for t in re.split(r",\s*(?![^{]*\})", tup) if t.strip()]
-        names = [sym[1:]] if sym != "f" else ["isk_chis", "isk_koopman"]           # fetch(f, iso) is called with these two
+        names = [sym[1:]] if sym != "f" else ["isk_chis", "isk_koopman"]           # fetch_rows(f, iso) is called with these two
         for name in names:
             hret, hargs = protos[name]
             seen.add(name)
