@@ -721,7 +721,7 @@ static int set_data_impl(isk_engine* e, const float* xs, const float* ys, int64_
     }
     HIPCHK(hipMalloc((void**)&e->d_delta1, (size_t)Bpad * H1p * sizeof(float)));
     const TrainShape ts = train_shape(e);
-    HIPCHK(hipMalloc((void**)&e->d_part, (size_t)isk_train_part_floats(ts, (int)N) * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&e->d_part, ((size_t)isk_train_part_floats(ts, (int)N) + 4) * sizeof(float)));      // (+4: kernels_train_chain.hip reads float4s that may end 3 floats past the last partial)
     HIPCHK(hipMalloc((void**)&e->d_perm, (size_t)N * sizeof(int)));
     HIPCHK(hipHostMalloc((void**)&e->h_perm, (size_t)N * sizeof(int), hipHostMallocDefault));
     if (e->cfg.target_kind == ISK_TARGET_ISA && e->nout <= ISK_ISA_DEV_MAXD) {
@@ -1214,7 +1214,8 @@ static bool train_epoch_persist(isk_engine* e, long long bs, long long nb) {
     if (!e->opt.train_persist || e->tp_disabled || e->layered || !e->native || nb < 1 || e->ncu < 1) return false;
     const TrainShape s = train_shape(e);
     EpochPlan p;
-    if (!isk_train_epoch_plan(s, e->Fp, (int)bs, e->ncu, &p)) return false;
+    const bool chain = e->opt.train_persist == 2;              // small batches on the workgroups of one XCD (kernels_train_chain.hip)
+    if (!(chain ? isk_train_chain_plan(s, e->Fp, (int)bs, &p) : isk_train_epoch_plan(s, e->Fp, (int)bs, e->ncu, &p))) return false;
     const int H1p = isk_pad16(e->cfg.widths[1]);
     const size_t zp_floats = (size_t)p.KS * p.zrows * H1p, lp_floats = (size_t)p.KS * p.nt * 2 * p.cps * 16;
     if (e->ep_zp_floats < zp_floats) {
@@ -1250,7 +1251,7 @@ static bool train_epoch_persist(isk_engine* e, long long bs, long long nb) {
         (void)hipMemsetAsync(e->dbg_st, 0, 64 * 8, e->stream);
         a.dbg = e->dbg_st;
     }
-    if (isk_launch_train_epoch(s, p, a, e->stream) != 0) { (void)hipGetLastError(); e->tp_disabled = true; return false; }
+    if ((chain ? isk_launch_train_chain(s, p, a, e->stream) : isk_launch_train_epoch(s, p, a, e->stream)) != 0) { (void)hipGetLastError(); e->tp_disabled = true; return false; }
     // what launch_grads / launch_opt keep track of on the host
     for (long long b = 0; b < nb; ++b) { e->bt1 *= e->cfg.beta1; e->bt2 *= e->cfg.beta2; }
     e->bt_dev_valid = false;             // the device copy of beta^t did not take part
@@ -1263,7 +1264,9 @@ static bool train_epoch_persist(isk_engine* e, long long bs, long long nb) {
         (void)hipStreamSynchronize(e->stream);
         unsigned long long h[64];
         (void)hipMemcpy(h, e->dbg_st, sizeof(h), hipMemcpyDeviceToHost);
-        static const char* nm[14] = {"step", "P1", "pubA", "waitA+C", "Kreduce", "tail", "pubB", "waitB", "P3", "loss+E1", "E2+pubSib", "E4", "E5", "E6+pubC"};
+        static const char* nm_ep[14] = {"step", "P1", "pubA", "waitA+C", "Kreduce", "tail", "pubB", "waitB", "P3", "loss+E1", "E2+pubSib", "E4", "E5", "E6+pubC"};
+        static const char* nm_ch[14] = {"step", "A", "pubA", "waitA", "Kreduce", "tail", "pubB+xload", "waitB", "stage-delta1", "G-mfma", "D+prefetch", "opt", "-", "-"};
+        const char* const* nm = chain ? nm_ch : nm_ep;
         for (int g = 0; g < 2; ++g) {
             fprintf(stderr, "[epoch stamps] wg %s:", g == 0 ? "0 (tail role)" : "G-1");
             unsigned long long prev = h[32 * g];

@@ -40,7 +40,7 @@ const OptDesc kOptions[] = {
     {"g16_waves", &IskOptions::g16_waves, 0, 8},
     {"epoch_gather", &IskOptions::epoch_gather, 0, 1},
     {"fuse_opt_rows", &IskOptions::fuse_opt_rows, 0, 1024},
-    {"train_persist", &IskOptions::train_persist, 0, 1},
+    {"train_persist", &IskOptions::train_persist, 0, 2},
     {"debug_feat_copy", &IskOptions::debug_feat_copy, 0, 64},
     {"debug_stamps", &IskOptions::debug_stamps, 0, 1},
     {"debug_rowmod", &IskOptions::debug_rowmod, 0, 1 << 30},

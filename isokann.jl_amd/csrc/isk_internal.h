@@ -441,6 +441,9 @@ struct EpochArgs {
 // false: the shape is not covered (the caller keeps the four-kernel chain).  ncu: compute units (the grid must be co-resident)
 bool isk_train_epoch_plan(const TrainShape& s, int Fp, int B, int ncu, EpochPlan* p);
 int  isk_launch_train_epoch(const TrainShape& s, const EpochPlan& p, EpochArgs a, hipStream_t st);
+// kernels_train_chain.hip: the same for batches of at most 128 rows on the workgroups of ONE XCD (option train_persist = 2)
+bool isk_train_chain_plan(const TrainShape& s, int Fp, int B, EpochPlan* p);
+int  isk_launch_train_chain(const TrainShape& s, const EpochPlan& p, EpochArgs a, hipStream_t st);
 #define ISK_MAX_SLABS 8
 int  isk_train_tail_nblocks(int B);
 long long isk_train_part_floats(const TrainShape& s, int maxB);
