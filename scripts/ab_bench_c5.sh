@@ -8,7 +8,7 @@
 #   hipcc --offload-arch=gfx950 -fPIC -shared $(sed "s#<unit's object>#/tmp/obj/<unit>_head.o#" /tmp/obj/last_objs.txt) -o build_abl/libisk_head.so
 export ISK_BENCH_NO_PMC=1     # (bench.py would otherwise run its own rocprofv3 counter passes for roofline.traffic)
 for i in 1 2 3; do
-for lib in "" build_abl/libisk_head.so; do
+for lib in "" ${ABLIBS:-build_abl/libisk_head.so}; do
 ISK_LIB=$lib python bench.py --workload c5shard --forward-mode 2 --steps 10 --warmup 3 --no-cpu-baseline --train-bf16 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib' or 'product', round(d['ms_per_step'],3), round(d['roofline']['training_chain']['us_per_step'],1))
