@@ -225,7 +225,8 @@ int  isk_validationloss(isk_engine* e, const float* vxs, const float* vys, int64
 /* Zygote-style pullback of chicoords: grad (D, ncols) = (d chi(coords_n) / d coords_n)' * cot[:, n], through
  * the MLP, the LayerNorm and the pairwise-distance featurizer.  Counterpart of the reference's
  * sqpairdist_bwd_kernel! + rrule (src/utils/pairdists.jl:153-196); consumers: src/utils/minimumpath.jl:3-13,
- * src/simulators/metadynamics.jl:40-43, src/simulators/openmm.jl:659-664.  cot is (nout, ncols). */
+ * src/simulators/metadynamics.jl:40-43, src/simulators/openmm.jl:659-664.  cot is (nout, ncols).
+ * Covers every shape isk_create accepts (round 5: also beyond 2048 features / 682 atoms). */
 int  isk_chicoords_pullback(isk_engine* e, const float* coords, int64_t D, int64_t ncols, const float* cot, float* grad);
 
 /* ---- target: isotarget(iso)   src/isotarget.jl:10-42, 74-127 ------------------- */

@@ -278,6 +278,14 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
     } else if (cfg->featurizer != ISK_FEAT_IDENTITY) {
         return fail(ISK_EINVAL, "unknown featurizer");
     }
+    {
+        // rows the register-resident featurizer does not cover (> 2048 features, > 682 atoms) go through the LDS-stash kernel: four
+        // waves, each with one sample's coordinates and feature row in LDS
+        const long long Dp = cfg->featurizer != ISK_FEAT_IDENTITY ? ((Din + 3) & ~3) : 0;
+        const bool reg = isk_pad32(F) <= 2048 && (cfg->featurizer == ISK_FEAT_IDENTITY || Din <= 2048);
+        if (!reg && (size_t)4 * (size_t)(Dp + isk_pad32(F)) * sizeof(float) > (size_t)160 * 1024)
+            return fail(ISK_EUNSUPPORTED, "features + coordinates per sample > 10240 (beyond 2048 features / 682 atoms the featurizer keeps a sample in LDS)");
+    }
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) return fail(ISK_EINVAL, "device ordinal out of range");

@@ -138,7 +138,8 @@ extern "C" int isk_chicoords_pullback(isk_engine* e, const float* coords, int64_
     HIPCHK(hipSetDevice(e->cfg.device));
     const bool is_coords = e->cfg.featurizer != ISK_FEAT_IDENTITY;
     if (is_coords && !e->d_packed) return fail(ISK_EUNSUPPORTED, "pullback needs the register featurizer (<= 65535 atoms)");
-    if (e->Fp > 2048 || D > 2048) return fail(ISK_EUNSUPPORTED, "pullback covers <= 2048 features / coordinates per sample");
+    // (vjp_back_kernel keeps delta1, d xhat and the coordinate gradient of a sample in LDS: (H1p + Fp + D) floats -- inside its 160 KiB for
+    // every shape isk_create accepts: features + coordinates <= 10240 beyond the register featurizer's range, first hidden width <= 4096)
     const int H1p = isk_pad16(e->cfg.widths[1]);
     const TrainShape ts = train_shape(e);
     if (e->layered) ensure_folded(e);            // the layer-by-layer pullback reads the f32 weight images (forward and transposed)

@@ -71,8 +71,10 @@ __global__ __launch_bounds__(256) void featurize_kernel(FeatArgs a) {
         __syncthreads();
         if (active) {
             float* orow = a.xhat + s * (long long)a.Fp;
-            for (int c = lane * 4; c < a.Fp; c += WAVE * 4) {
+            if (a.stats && lane == 0) { a.stats[2 * s] = mu; a.stats[2 * s + 1] = rstd; }          // kept for the coordinate pullback, as the
+            for (int c = lane * 4; c < a.Fp; c += WAVE * 4) {                                         // register variant does
                 f32x4 v = *(const f32x4*)(stash + c);
+                if (a.raw) *(f32x4*)(a.raw + s * (long long)a.Fp + c) = v;                          // (un-normalised features, zero padding)
                 if (a.normalize) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = (c + j < a.F) ? (v[j] - mu) * rstd : 0.f;

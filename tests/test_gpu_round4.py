@@ -93,7 +93,7 @@ def test_villin_shape_pullback_matches_torch_autograd(gpu_pkg):
 def test_documented_shape_limits_are_error_codes(gpu_pkg):
     """what the kernels do not cover is refused with ISK_EUNSUPPORTED at isk_create / at the call, never computed wrongly:
     TransformISA beyond 64 outputs (up to 8 the device chain, up to 64 the host solve: test_isa_with_more_than_eight_outputs), a
-    layer wider than 4096, the coordinate pullback beyond 2048 features (src/utils/pairdists.jl:153-196 has no such bound)"""
+    layer wider than 4096, more than 10240 features + coordinates per sample beyond the register featurizer's range (src/utils/pairdists.jl has no such bound)"""
     pkg = gpu_pkg
     rng = np.random.default_rng(0)
     xs, ys = rng.normal(size=(12, 40)), rng.normal(size=(12, 2, 40))
@@ -103,13 +103,20 @@ def test_documented_shape_limits_are_error_codes(gpu_pkg):
     with pytest.raises(pkg.capi.IskError) as ei:
         pkg.Iso(pkg.SimulationData(xs, ys, pkg.identity), model=pkg.densenet([12, 4100, 1], layernorm=False), minibatch=0)
     assert ei.value.status == pkg.capi.EUNSUPPORTED
-    F = 2100
-    xw, yw = rng.normal(size=(F, 8)), rng.normal(size=(F, 2, 8))
-    iso = pkg.Iso(pkg.SimulationData(xw, yw, pkg.identity), model=pkg.densenet([F, 24, 4, 1], layernorm=True), minibatch=0)
-    assert np.all(np.isfinite(pkg.chis(iso)))                       # the forward itself covers this width
+    # beyond the register featurizer's range (2048 features / 682 atoms) a sample's coordinates and feature row are staged in LDS: more than
+    # 10240 of them together are refused at isk_create (round 5: up to there forward, training AND the coordinate pullback run --
+    # tests/test_gpu_pullback_wide.py; before, the pullback stopped at 2048 features and larger rows failed at the first launch)
+    F = 10300
+    xw, yw = rng.normal(size=(F, 4)), rng.normal(size=(F, 2, 4))
     with pytest.raises(pkg.capi.IskError) as ei:
-        pkg.chicoords_pullback(iso, xw[:, :2], np.ones((1, 2)))
+        pkg.Iso(pkg.SimulationData(xw, yw, pkg.identity), model=pkg.densenet([F, 24, 4, 1], layernorm=True), minibatch=0)
     assert ei.value.status == pkg.capi.EUNSUPPORTED
+    F = 9000
+    xw, yw = rng.normal(size=(F, 4)), rng.normal(size=(F, 2, 4))
+    iso = pkg.Iso(pkg.SimulationData(xw, yw, pkg.identity), model=pkg.densenet([F, 24, 4, 1], layernorm=True), minibatch=0)
+    assert np.all(np.isfinite(pkg.chis(iso)))
+    g = pkg.chicoords_pullback(iso, xw[:, :2], np.ones((1, 2)))
+    assert g.shape == (F, 2) and np.all(np.isfinite(g)) and np.abs(g).max() > 0
     iso.close()
 
 
