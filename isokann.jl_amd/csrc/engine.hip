@@ -256,7 +256,7 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
         return fail(ISK_EINVAL, "TransformISA does not work with one dimensional chi functions");
     if (cfg->target_kind == ISK_TARGET_ISA && nout > ISK_ISA_HOST_MAXD) return fail(ISK_EUNSUPPORTED, "TransformISA: at most 64 outputs");
     for (int l = 1; l <= cfg->n_layers; ++l)
-        if (cfg->widths[l] > 4096) return fail(ISK_EUNSUPPORTED, "layer width > 4096");
+        if (cfg->widths[l] > 16384) return fail(ISK_EUNSUPPORTED, "layer width > 16384");
     int F = cfg->widths[0], Din = F;
     std::vector<int2> pairs;
     if (cfg->featurizer == ISK_FEAT_ALLPAIRS) {
@@ -399,8 +399,8 @@ extern "C" int isk_create(const isk_config* cfg, isk_engine** out) {
             ALLOC(e->d_W16L[l], (size_t)isk_bf16_chunks(layer_kp(e, l)) * 32 * isk_pad16(cfg->widths[l + 1]) * 3 * sizeof(uint16_t));
         ALLOC(e->d_G0, (size_t)F * cfg->widths[1] * sizeof(float));
         ALLOC(e->d_D0, (size_t)cfg->widths[1] * sizeof(float));
-        ALLOC(e->d_zero, (size_t)4096 * sizeof(float));
-        (void)hipMemset(e->d_zero, 0, (size_t)4096 * sizeof(float));
+        ALLOC(e->d_zero, (size_t)16384 * sizeof(float));                 // a zero bias as wide as the widest layer allowed
+        (void)hipMemset(e->d_zero, 0, (size_t)16384 * sizeof(float));
         if (bf16_weight_images_alloc(e) != ISK_OK) { isk_destroy(e); return fail(ISK_ENOMEM, "hipMalloc: bf16 weight images"); }
     }
 #undef ALLOC

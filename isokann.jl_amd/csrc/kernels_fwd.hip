@@ -476,6 +476,7 @@ void isk_launch_featurize(const FeatArgs& a, hipStream_t st) {
 // so that  W1*(g.*xhat + beta) + b1 == W1g*xhat + bias1  and the forward kernel consumes the
 // standardised rows directly.
 // =====================================================================================
+#define FOLD_NB 2048             /* output columns per pass of the transpose tile (16 x 2049 floats = 128 KiB of LDS) */
 __global__ __launch_bounds__(256) void fold_kernel(FoldArgs a) {
     ISK_LATENCY_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float tile[];     // [16][Np + 1]
@@ -538,30 +539,37 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldArgs a) {
     if ((int)blockIdx.x < nchunks) {
         // one 16-feature chunk: coalesced read of W[:, 16c .. 16c+15] (Flux layout: o fastest),
         // LDS transpose, coalesced write of the chunk's nt fragment-linear KiB
+        // (output columns in blocks of FOLD_NB: the transpose tile is [16][block + 1] floats -- a 4096-wide layer in one piece would
+        // need 262 KB of LDS, the launch failed with "invalid argument"; up to FOLD_NB columns this is the single pass it always was)
         const int c = blockIdx.x;
-        const int ld = Np + 1;
-        const int nel = 16 * N;
+        const int ld = (Np < FOLD_NB ? Np : FOLD_NB) + 1;
         const float* Wc = W + (long long)c * 16 * N;
-        for (int e0 = 0; e0 < nel; e0 += 256 * 4) {
-            float v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * 256 + tid;
-                const int kl = e / N;
-                v[u] = (e < nel && c * 16 + kl < K) ? Wc[e] * (ln ? g[c * 16 + kl] : 1.f) : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * 256 + tid;
-                if (e < nel) { const int kl = e / N; tile[kl * ld + (e - kl * N)] = v[u]; }
-            }
-        }
-        __syncthreads();
         float* Wt = a.Wt[layer] + (long long)c * nt * 256;
-        for (int idx = tid; idx < nt * 256; idx += 256) {
-            const int j = idx & 3, lane = (idx >> 2) & 63, t = idx >> 8;
-            const int o = t * 16 + (lane & 15), kl = 4 * (lane >> 4) + j;
-            Wt[idx] = (o < N) ? tile[kl * ld + o] : 0.f;
+        for (int ob = 0; ob < Np; ob += FOLD_NB) {
+            const int nbw = (Np - ob < FOLD_NB) ? Np - ob : FOLD_NB;         // padded columns of this block (a multiple of 16)
+            const int nv = (N - ob < nbw) ? N - ob : nbw;                   // valid ones (>= 1: ob <= Np - 16 < N)
+            const int nel = 16 * nv;
+            for (int e0 = 0; e0 < nel; e0 += 256 * 4) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * 256 + tid;
+                    const int kl = e / nv;
+                    v[u] = (e < nel && c * 16 + kl < K) ? Wc[(long long)kl * N + ob + (e - kl * nv)] * (ln ? g[c * 16 + kl] : 1.f) : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * 256 + tid;
+                    if (e < nel) { const int kl = e / nv; tile[kl * ld + (e - kl * nv)] = v[u]; }
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < (nbw / 16) * 256; idx += 256) {
+                const int j = idx & 3, lane = (idx >> 2) & 63, t = idx >> 8;
+                const int ol = t * 16 + (lane & 15), kl = 4 * (lane >> 4) + j;
+                Wt[(ob / 16) * 256 + idx] = (ob + ol < N) ? tile[kl * ld + ol] : 0.f;
+            }
+            __syncthreads();
         }
         return;
     }
@@ -600,7 +608,8 @@ void isk_launch_fold(const FoldArgs& a, hipStream_t st) {
         bx = bx > (Kp / 16 + Np) ? bx : (Kp / 16 + Np);
         maxNp = maxNp > Np ? maxNp : Np;
     }
-    const size_t lds = (size_t)16 * (maxNp + 1) * sizeof(float);
+    const size_t lds = (size_t)16 * ((maxNp < FOLD_NB ? maxNp : FOLD_NB) + 1) * sizeof(float);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fold_kernel, dim3(bx, a.nlayers), dim3(256), lds, st, a);
 }
 

@@ -93,7 +93,7 @@ def test_villin_shape_pullback_matches_torch_autograd(gpu_pkg):
 def test_documented_shape_limits_are_error_codes(gpu_pkg):
     """what the kernels do not cover is refused with ISK_EUNSUPPORTED at isk_create / at the call, never computed wrongly:
     TransformISA beyond 64 outputs (up to 8 the device chain, up to 64 the host solve: test_isa_with_more_than_eight_outputs), a
-    layer wider than 4096, more than 10240 features + coordinates per sample beyond the register featurizer's range (src/utils/pairdists.jl has no such bound)"""
+    layer wider than 16384, more than 10240 features + coordinates per sample beyond the register featurizer's range (src/utils/pairdists.jl has no such bound)"""
     pkg = gpu_pkg
     rng = np.random.default_rng(0)
     xs, ys = rng.normal(size=(12, 40)), rng.normal(size=(12, 2, 40))
@@ -101,7 +101,7 @@ def test_documented_shape_limits_are_error_codes(gpu_pkg):
         pkg.Iso(pkg.SimulationData(xs, ys, pkg.identity), model=pkg.densenet([12, 80, 65], layernorm=True), target=pkg.TransformISA(), minibatch=0)
     assert ei.value.status == pkg.capi.EUNSUPPORTED
     with pytest.raises(pkg.capi.IskError) as ei:
-        pkg.Iso(pkg.SimulationData(xs, ys, pkg.identity), model=pkg.densenet([12, 4100, 1], layernorm=False), minibatch=0)
+        pkg.Iso(pkg.SimulationData(xs, ys, pkg.identity), model=pkg.densenet([12, 16400, 1], layernorm=False), minibatch=0)
     assert ei.value.status == pkg.capi.EUNSUPPORTED
     # beyond the register featurizer's range (2048 features / 682 atoms) a sample's coordinates and feature row are staged in LDS: more than
     # 10240 of them together are refused at isk_create (round 5: up to there forward, training AND the coordinate pullback run --
