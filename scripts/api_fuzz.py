@@ -43,14 +43,14 @@ def isa_undetermined(oiso, om, odata):
     return False
 
 
-def one_sequence(rng, verbose):
+def one_sequence(rng, verbose, bf16=False):
     kind = rng.choice(["identity", "pairs"])
     N = int(rng.integers(40, 300))
     K = int(rng.integers(1, 5))
     nout = int(rng.choice([1, 1, 2, 3]))
     every = bool(rng.integers(0, 2))
-    mode = int(rng.choice([0, 1, 3]))
-    layered = bool(rng.integers(0, 3) == 0)
+    mode = 2 if bf16 else int(rng.choice([0, 1, 3]))
+    layered = bool(rng.integers(0, 3) == 0) or (bf16 and bool(rng.integers(0, 2)))
     optk = str(rng.choice(["adam", "nesterov"]))
     if kind == "identity":
         F = int(rng.integers(6, 80))
@@ -66,7 +66,10 @@ def one_sequence(rng, verbose):
     widths = [F] + hidden + [nout]
     om = rand_model(widths, seed=int(rng.integers(1 << 30)))
     mb = int(rng.choice([0, 16, 33, 64]))
-    desc = dict(kind=kind, N=N, K=K, widths=widths, every=every, mode=mode, layered=layered, opt=optk, mb=mb)
+    train16 = bf16 and bool(rng.integers(0, 2))
+    # bf16 flavour (plain-bf16 forward, optionally bf16 training GEMMs): bf16 tolerances -- still far below what a stale weight image costs
+    ftol, ltol = (4e-2, 6e-2) if bf16 else (5e-4, 5e-3)
+    desc = dict(kind=kind, N=N, K=K, widths=widths, every=every, mode=mode, layered=layered, opt=optk, mb=mb, train16=train16)
     odata = O.SimulationData(np.asarray(xs, np.float64), np.asarray(ys, np.float64), feat_o) if feat_o is not None else \
         O.SimulationData(np.asarray(xs, np.float64), np.asarray(ys, np.float64))
     lr, reg = 1e-3, 1e-4
@@ -76,11 +79,13 @@ def one_sequence(rng, verbose):
     gtr = pkg.TransformISA() if nout > 1 else None
     oiso = O.Iso(odata, om, O.setup(orule, om), minibatch=mb, target=otr)
     iso = pkg.Iso(pkg.SimulationData(xs, ys, feat_g), model=mk_model(om), opt=grule, minibatch=mb, target=gtr, forward_mode=mode,
-                  featurize_every_iteration=every, force_layered=layered)
+                  featurize_every_iteration=every, force_layered=layered, options={"train_bf16": 1} if train16 else None)
     log = []
     try:
         for step in range(int(rng.integers(4, 9))):
             op = str(rng.choice(["run", "run", "chis", "koopman", "target", "train", "grads", "setparams", "optstate", "minibatch", "chicoords"]))
+            if bf16 and op in ("run", "target", "grads"):          # (trajectories and the ISA solve amplify bf16 rounding: forward / one-epoch ops only)
+                op = str(rng.choice(["chis", "koopman", "train", "setparams", "chicoords"]))
             log.append(op)
             if op == "run":
                 n = 1                                           # (one iteration per op: the simplex is checked in front of each)
@@ -97,9 +102,9 @@ def one_sequence(rng, verbose):
                     return "skip", desc, log
                 assert np.all(np.abs(a - b) <= 5e-3 * np.abs(b) + 1e-9), ("run losses", a, b)
             elif op == "chis":
-                assert np.abs(pkg.chis(iso) - O.chis(oiso)).max() <= 5e-4, ("chis", np.abs(pkg.chis(iso) - O.chis(oiso)).max())
+                assert np.abs(pkg.chis(iso) - O.chis(oiso)).max() <= ftol * max(1.0, np.abs(O.chis(oiso)).max()), ("chis", np.abs(pkg.chis(iso) - O.chis(oiso)).max())
             elif op == "koopman":
-                assert np.abs(pkg.koopman(iso) - O.koopman(oiso)).max() <= 5e-4, "koopman"
+                assert np.abs(pkg.koopman(iso) - O.koopman(oiso)).max() <= ftol * max(1.0, np.abs(O.koopman(oiso)).max()), "koopman"
             elif op == "target":
                 try:
                     want = O.isotarget(otr, om, *odata.features)
@@ -116,7 +121,9 @@ def one_sequence(rng, verbose):
                 l = pkg.train_batch(iso, tgt, perm=perm)
                 if not np.isfinite(lo) or np.abs(om.get_flat()).max() > 1e3:
                     return "skip", desc, log
-                assert abs(l - lo) <= 5e-3 * abs(lo) + 1e-9, ("train loss", l, lo)
+                assert abs(l - lo) <= ltol * abs(lo) + 1e-9, ("train loss", l, lo)
+                if bf16:                                        # keep the two sides together: the oracle continues from the ENGINE's parameters
+                    om.set_flat(iso.model.get_params().astype(np.float64))
             elif op == "grads":
                 tgt = np.asarray(rng.uniform(size=(nout, N)), np.float32)
                 idx = rng.permutation(N)[: max(2, N // 3)]
@@ -138,7 +145,7 @@ def one_sequence(rng, verbose):
             elif op == "chicoords":
                 x = xs[:, : min(7, N)]
                 want = O.forward(om, odata.featurizer(np.asarray(x, np.float64)) if feat_o is not None else np.asarray(x, np.float64))
-                assert np.abs(pkg.chicoords(iso, x) - want).max() <= 5e-4, "chicoords"
+                assert np.abs(pkg.chicoords(iso, x) - want).max() <= ftol * max(1.0, np.abs(want).max()), "chicoords"
         return "ok", desc, log
     except AssertionError as ex:
         raise AssertionError((ex.args, desc, log)) from None
@@ -146,13 +153,13 @@ def one_sequence(rng, verbose):
         iso.close()
 
 
-def sweep(nseq, seed, verbose=True):
+def sweep(nseq, seed, verbose=True, bf16=False):
     rng = np.random.default_rng(seed)
     fails, skips, failed = 0, 0, []
     for i in range(nseq):
         sub = np.random.default_rng(rng.integers(1 << 62))
         try:
-            r, desc, log = one_sequence(sub, verbose)
+            r, desc, log = one_sequence(sub, verbose, bf16)
             skips += r == "skip"
         except AssertionError as ex:
             fails += 1
@@ -169,4 +176,4 @@ def sweep(nseq, seed, verbose=True):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     s = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    sys.exit(1 if sweep(n, s)[0] else 0)
+    sys.exit(1 if sweep(n, s, bf16=bool(os.environ.get("FUZZ_BF16")))[0] else 0)

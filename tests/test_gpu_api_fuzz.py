@@ -25,3 +25,16 @@ def test_random_api_sequences_against_the_oracle(gpu_pkg, seed, monkeypatch):
     fails, skipped, failed = fz.sweep(150, seed, verbose=False)
     assert fails == 0, failed
     assert skipped < 40
+
+
+def test_random_api_sequences_bf16_paths(gpu_pkg, monkeypatch):
+    """the same on the plain-bf16 forward (forward_mode 2: the fused wide kernel on the layered path, the one-plane kernel on the fused
+    one) with and without the bf16 training GEMMs: forward / one-epoch operations only, bf16 tolerances (4e-2 on chi, 6e-2 on a loss) --
+    an order of magnitude below what a stale weight image costs after set_params"""
+    monkeypatch.delenv("ISK_FWD_MODE", raising=False)
+    monkeypatch.delenv("ISK_FORCE_LAYERED", raising=False)
+    spec = importlib.util.spec_from_file_location("api_fuzz", os.path.join(ROOT, "scripts", "api_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    fails, skipped, failed = fz.sweep(150, 23, verbose=False, bf16=True)
+    assert fails == 0, failed
