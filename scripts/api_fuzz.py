@@ -83,7 +83,7 @@ def one_sequence(rng, verbose, bf16=False):
     log = []
     try:
         for step in range(int(rng.integers(4, 9))):
-            op = str(rng.choice(["run", "run", "chis", "koopman", "target", "train", "grads", "setparams", "optstate", "minibatch", "chicoords"]))
+            op = str(rng.choice(["run", "run", "chis", "koopman", "target", "train", "grads", "setparams", "optstate", "minibatch", "chicoords", "append", "saveload"]))
             if bf16 and op in ("run", "target", "grads"):          # (trajectories and the ISA solve amplify bf16 rounding: forward / one-epoch ops only)
                 op = str(rng.choice(["chis", "koopman", "train", "setparams", "chicoords"]))
             log.append(op)
@@ -142,6 +142,31 @@ def one_sequence(rng, verbose, bf16=False):
                 mb = int(rng.choice([0, 16, 33, 64]))
                 iso.minibatch = mb
                 oiso.minibatch = mb
+            elif op == "append":
+                # addcoords! / the cutoff window (src/iso.jl:238,288-290): drop start points at the front, append new ones
+                n_add = int(rng.integers(0, 20))
+                drop = int(rng.integers(0, max(1, min(10, N - 30))))
+                if kind == "identity":
+                    xn, yn = rng.normal(size=(F, n_add)), rng.normal(size=(F, K, n_add))
+                else:
+                    xn, yn = O.synthetic_coords(A, max(n_add, 1), K, seed=int(rng.integers(1 << 30)))
+                    xn, yn = xn[:, :n_add], yn[:, :, :n_add]
+                if n_add == 0 and drop == 0:
+                    continue
+                pkg.append_data(iso, xn if n_add else None, yn if n_add else None, drop_first=drop)
+                xs = np.concatenate([np.asarray(xs)[:, drop:], xn], axis=1) if n_add else np.asarray(xs)[:, drop:]
+                ys = np.concatenate([np.asarray(ys)[:, :, drop:], yn], axis=2) if n_add else np.asarray(ys)[:, :, drop:]
+                N = xs.shape[1]
+                odata = O.SimulationData(np.asarray(xs, np.float32).astype(np.float64), np.asarray(ys, np.float32).astype(np.float64), feat_o) if feat_o is not None else \
+                    O.SimulationData(np.asarray(xs, np.float32).astype(np.float64), np.asarray(ys, np.float32).astype(np.float64))
+                oiso.data = odata
+            elif op == "saveload":
+                # save / load (src/iso.jl:405-420): parameters, optimizer state, data and losses through one file, a NEW engine
+                path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"isk_api_fuzz_{os.getpid()}.npz")
+                pkg.save(path, iso)
+                iso.close()
+                iso = pkg.load(path, force_layered=layered, options={"train_bf16": 1} if train16 else None)
+                os.remove(path)
             elif op == "chicoords":
                 x = xs[:, : min(7, N)]
                 want = O.forward(om, odata.featurizer(np.asarray(x, np.float64)) if feat_o is not None else np.asarray(x, np.float64))
