@@ -44,8 +44,9 @@ def isa_undetermined(oiso, om, odata):
 
 
 def one_sequence(rng, verbose, bf16=False):
+    big = bool(os.environ.get("FUZZ_BIG"))            # larger problems: N to 3000, rows to 300 features, hidden widths to 400 (beyond 160: the layered path)
     kind = rng.choice(["identity", "pairs"])
-    N = int(rng.integers(40, 300))
+    N = int(rng.integers(40, 3000 if big else 300))
     K = int(rng.integers(1, 5))
     nout = int(rng.choice([1, 1, 2, 3]))
     every = bool(rng.integers(0, 2))
@@ -53,16 +54,16 @@ def one_sequence(rng, verbose, bf16=False):
     layered = bool(rng.integers(0, 3) == 0) or (bf16 and bool(rng.integers(0, 2)))
     optk = str(rng.choice(["adam", "nesterov"]))
     if kind == "identity":
-        F = int(rng.integers(6, 80))
+        F = int(rng.integers(6, 300 if big else 80))
         xs, ys = rng.normal(size=(F, N)), rng.normal(size=(F, K, N))
         feat_g, feat_o = pkg.identity, None
     else:
-        A = int(rng.integers(8, 40))
-        F = int(rng.integers(6, min(120, A * (A - 1) // 2)))
+        A = int(rng.integers(8, 80 if big else 40))
+        F = int(rng.integers(6, min(300 if big else 120, A * (A - 1) // 2)))
         xs, ys = O.synthetic_coords(A, N, K, seed=int(rng.integers(1 << 30)))
         pairs = O.random_pairs(A, F, seed=int(rng.integers(1 << 30)))
         feat_g, feat_o = pkg.FeaturesPairs(pairs), O.FeaturesPairs(pairs)
-    hidden = [int(rng.integers(3, 200 if layered else 60)) for _ in range(int(rng.integers(1, 4)))]
+    hidden = [int(rng.integers(3, (400 if big else 200) if layered else (160 if big else 60))) for _ in range(int(rng.integers(1, 4)))]
     widths = [F] + hidden + [nout]
     om = rand_model(widths, seed=int(rng.integers(1 << 30)))
     mb = int(rng.choice([0, 16, 33, 64]))
