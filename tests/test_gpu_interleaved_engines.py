@@ -1,0 +1,65 @@
+"""Several engines alive in one process on one GPU, their calls interleaved: every engine must produce exactly (bit for bit) what it
+produces alone -- nothing of one engine's state may live in a static of the library (function attributes, staging buffers, streams,
+graphs keyed by buffer, option defaults)."""
+import numpy as np
+import pytest
+
+from oracle import isokann_oracle as O
+from tests.test_gpu_parity import _mk_model, _rand_model
+
+pytestmark = [pytest.mark.gpu]
+
+
+def _mk(pkg, spec):
+    rng = np.random.default_rng(spec["seed"])
+    N, K = spec["N"], spec["K"]
+    if spec["kind"] == "pairs":
+        xs, ys = O.synthetic_coords(spec["A"], N, K, seed=spec["seed"])
+        feat = pkg.FeaturesPairs(O.random_pairs(spec["A"], spec["widths"][0], seed=spec["seed"] + 1))
+    else:
+        xs, ys = rng.normal(size=(spec["widths"][0], N)), rng.normal(size=(spec["widths"][0], K, N))
+        feat = pkg.identity
+    om = _rand_model(spec["widths"], seed=spec["seed"] + 2)
+    nout = spec["widths"][-1]
+    iso = pkg.Iso(pkg.SimulationData(xs, ys, feat), model=_mk_model(pkg, om), minibatch=spec["mb"], target=pkg.TransformISA() if nout > 1 else None,
+                  opt=pkg.AdamRegularized() if spec["opt"] == "adam" else pkg.NesterovRegularized(), forward_mode=spec["mode"],
+                  featurize_every_iteration=spec["every"], force_layered=spec.get("layered", False), options=spec.get("options"))
+    perms = np.stack([np.random.default_rng(spec["seed"] + 10 + i).permutation(N) for i in range(4)]).astype(np.int32)
+    return iso, perms
+
+
+SPECS = [
+    dict(kind="pairs", A=30, widths=[120, 40, 6, 3], N=384, K=3, mb=64, opt="adam", mode=3, every=True, seed=1),
+    dict(kind="identity", widths=[48, 300, 60, 1], N=257, K=2, mb=0, opt="nesterov", mode=1, every=False, seed=2, layered=True),
+    dict(kind="pairs", A=22, widths=[231, 38, 6, 1], N=500, K=4, mb=100, opt="nesterov", mode=0, every=True, seed=3),
+    dict(kind="pairs", A=40, widths=[200, 256, 256, 1], N=320, K=2, mb=64, opt="adam", mode=2, every=True, seed=4, layered=True, options={"train_bf16": 1}),
+]
+
+
+def test_interleaved_engines_equal_their_solo_runs(gpu_pkg):
+    pkg = gpu_pkg
+    solo = []
+    for spec in SPECS:
+        iso, perms = _mk(pkg, spec)
+        out = []
+        for it in range(4):
+            pkg.run(iso, 1, 1, perms=perms[it:it + 1])
+            out.append((iso.losses[-1], pkg.chis(iso).copy()))
+        solo.append((out, iso.model.get_params().copy()))
+        iso.close()
+    live = [_mk(pkg, spec) for spec in SPECS]
+    got = [[] for _ in SPECS]
+    order = [0, 1, 2, 3, 3, 1, 0, 2, 2, 0, 3, 1, 1, 2, 3, 0]                  # four iterations each, interleaved
+    nxt = [0] * len(SPECS)
+    for e in order:
+        iso, perms = live[e]
+        it = nxt[e]
+        pkg.run(iso, 1, 1, perms=perms[it:it + 1])
+        got[e].append((iso.losses[-1], pkg.chis(iso).copy()))
+        nxt[e] += 1
+    for e, (iso, _) in enumerate(live):
+        for it in range(4):
+            assert got[e][it][0] == solo[e][0][it][0], (e, it, got[e][it][0], solo[e][0][it][0])
+            np.testing.assert_array_equal(got[e][it][1], solo[e][0][it][1])
+        np.testing.assert_array_equal(iso.model.get_params(), solo[e][1])
+        iso.close()
