@@ -63,3 +63,39 @@ def test_interleaved_engines_equal_their_solo_runs(gpu_pkg):
             np.testing.assert_array_equal(got[e][it][1], solo[e][0][it][1])
         np.testing.assert_array_equal(iso.model.get_params(), solo[e][1])
         iso.close()
+
+
+def test_engines_on_concurrent_host_threads_equal_their_solo_runs(gpu_pkg):
+    """the ABI is re-entrant per handle: one host thread per engine, running at the same time (ctypes releases the
+    GIL around every call), must change nothing either"""
+    import threading
+    pkg = gpu_pkg
+    solo = []
+    for spec in SPECS:
+        iso, perms = _mk(pkg, spec)
+        pkg.run(iso, 4, 1, perms=perms)
+        solo.append((list(iso.losses), pkg.chis(iso).copy(), iso.model.get_params().copy()))
+        iso.close()
+    live = [_mk(pkg, spec) for spec in SPECS]
+    errs = []
+
+    def work(e):
+        try:
+            iso, perms = live[e]
+            for it in range(4):
+                pkg.run(iso, 1, 1, perms=perms[it:it + 1])
+                pkg.chis(iso)
+        except Exception as ex:  # noqa: BLE001
+            errs.append((e, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(e,)) for e in range(len(SPECS))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for e, (iso, _) in enumerate(live):
+        assert list(iso.losses) == solo[e][0], (e, iso.losses, solo[e][0])
+        np.testing.assert_array_equal(pkg.chis(iso), solo[e][1])
+        np.testing.assert_array_equal(iso.model.get_params(), solo[e][2])
+        iso.close()
