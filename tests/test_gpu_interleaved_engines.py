@@ -99,3 +99,25 @@ def test_engines_on_concurrent_host_threads_equal_their_solo_runs(gpu_pkg):
         np.testing.assert_array_equal(pkg.chis(iso), solo[e][1])
         np.testing.assert_array_equal(iso.model.get_params(), solo[e][2])
         iso.close()
+
+
+def test_engines_release_their_device_memory(gpu_pkg):
+    """isk_destroy gives everything back: 60 engines of the four kinds above created, run and destroyed in turn leave the device's free
+    memory where it was (to within an allocator granule)"""
+    import torch
+    pkg = gpu_pkg
+
+    def cycle(n):
+        for i in range(n):
+            iso, perms = _mk(pkg, SPECS[i % len(SPECS)])
+            pkg.run(iso, 1, 1, perms=perms[:1])
+            pkg.chicoords_pullback(iso, iso.data.coords[0][:, :2], np.ones((iso.nout, 2)))
+            iso.close()
+
+    cycle(8)                                            # (first use: code objects, the runtime's own pools)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    cycle(60)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0 - free1) / 2 ** 20
