@@ -461,7 +461,7 @@ def main():
     # evaluation-only work (K chi of the resident data: forward + K-mean, nothing that touches parameters, optimizer state or the
     # shuffle sequence); the W warm-up iterations and the K timed ones are exactly what they were.  Reported as `spinup_s`.
     spun = 0.0
-    if args.spinup_s > 0 and not use_dp:
+    if args.spinup_s > 0:                              # (data-parallel runs too: K chi of the LOCAL shard, no collective)
         arm("spin-up")
         ts = time.perf_counter()
         while time.perf_counter() - ts < args.spinup_s:
