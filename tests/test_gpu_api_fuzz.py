@@ -4,7 +4,7 @@ the front, append new ones: addcoords! / the cutoff window) and a save / load th
 problems -- both featurizers, one to three hidden layers, the fused and the forced-layered path, every Float32-equivalent forward
 arithmetic, per-iteration and cached featurization, both optimizers.  What it is after is the engine's cached derived state (weight
 images and their dirty flags, feature buffers written ahead on the side stream, epoch graphs, the device copy of beta^t).  Round 5:
-2 600 sequences, no mismatch once the oracle-side check for an UNDETERMINED ISA target was in place (an ill-conditioned simplex, or
+3 850 sequences, no mismatch once the oracle-side check for an UNDETERMINED ISA target was in place (an ill-conditioned simplex, or
 two permutations of fixperm at the same cost to rounding -- K chi of a deep sigmoid network at initialisation lies almost on a line)."""
 import importlib.util
 import os
