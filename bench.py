@@ -148,7 +148,8 @@ def measure_traffic_live(argv_workload, kernel_substr, timeout_s=150.0):
             out = os.path.join(tmp, counter)
             cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", "python3",
                    os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--profile-steps", "1",
-                   "--sustained-s", "0", "--no-f32-reference"] + argv_workload
+                   "--sustained-s", "0", "--no-f32-reference", "--spinup-s", "0"] + argv_workload      # (no spin-up: its hundreds of forward + K-mean
+                                                                                                          # launches would count as launches per iteration)
             pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
                 rc = pr.wait(timeout=timeout_s)

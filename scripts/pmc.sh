@@ -11,7 +11,7 @@ R=$(pwd); P=$R/gpurun_out/pmc$SUF; mkdir -p $P
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   n=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $P/$n -o $n -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 --sustained-s 0 --no-f32-reference $BARGS > /dev/null 2> $P/$n.err || { tail -5 $P/$n.err; return 1; }
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $P/$n -o $n -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 --sustained-s 0 --no-f32-reference --spinup-s 0 $BARGS > /dev/null 2> $P/$n.err || { tail -5 $P/$n.err; return 1; }
 }
 run fetch FETCH_SIZE && run write WRITE_SIZE && run sq SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
 cd $R && python3 scripts/pmc_summarize.py $P "$BARGS" > gpurun_out/pmc_summary$SUF.json && python3 - <<PY

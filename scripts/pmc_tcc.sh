@@ -9,7 +9,7 @@ BARGS="$*"
 R=$(pwd); P=$R/gpurun_out/pmc_tcc_$TAG; mkdir -p $P
 cd /tmp && export TMPDIR=/tmp
 run() { n=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $P/$n -o $n -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 --sustained-s 0 --no-f32-reference $BARGS > /dev/null 2> $P/$n.err || { echo "pass $n failed:"; tail -3 $P/$n.err; }
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $P/$n -o $n -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 --sustained-s 0 --no-f32-reference --spinup-s 0 $BARGS > /dev/null 2> $P/$n.err || { echo "pass $n failed:"; tail -3 $P/$n.err; }
 }
 run rd TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
 run rdw TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum

@@ -4,7 +4,7 @@ export ISK_BENCH_NO_PMC=1     # (bench.py would otherwise run its own rocprofv3 
 tag=$1; shift
 R=$(pwd); mkdir -p $R/gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -o $tag -- python3 $R/bench.py --steps ${PROF_STEPS:-30} --warmup ${PROF_WARMUP:-5} --no-cpu-baseline --sustained-s 0 --no-f32-reference "$@" > $R/gpurun_out/prof_$tag/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -o $tag -- python3 $R/bench.py --steps ${PROF_STEPS:-30} --warmup ${PROF_WARMUP:-5} --no-cpu-baseline --sustained-s 0 --no-f32-reference --spinup-s 0 "$@" > $R/gpurun_out/prof_$tag/log.txt 2>&1
 cd $R
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
